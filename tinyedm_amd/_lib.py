@@ -1,0 +1,102 @@
+"""ctypes binding of the C-ABI HIP library (include/tinyedm_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a kernel reports an error the
+call raises.  Only raw device pointers, sizes and a hipStream_t cross this boundary.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtinyedm_hip.so")
+
+P, I, L, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+U, U64 = ctypes.c_uint, ctypes.c_ulonglong
+
+# name -> argtypes (every function returns int status unless listed in _RET)
+SIGNATURES = {
+    "edm_version": [],
+    "edm_last_error": [],
+    # elementwise.hip
+    "edm_pixelnorm_silu_fwd": [P, P, P, P, L, I, P],
+    "edm_pixelnorm_silu_bwd": [P, P, P, F, P, P, L, I, P],
+    "edm_silu_fwd": [P, P, L, P],
+    "edm_silu_bwd": [P, P, P, F, P, L, P],
+    "edm_axpby": [P, F, P, F, P, L, P],
+    "edm_mod_silu_drop_fwd": [P, P, P, P, I, I, I, F, U64, U, U, P],
+    "edm_mod_silu_drop_bwd": [P, P, P, P, P, P, P, P, I, I, I, F, U64, U, U, P],
+    "edm_dropout_mask": [P, L, F, U64, U, U, P],
+    "edm_pool2": [P, P, I, I, I, I, F, P],
+    "edm_up2": [P, P, I, I, I, I, F, P],
+    "edm_reduce_hw": [P, L, P, L, P, I, I, I, F, P],
+    "edm_scalelong_fwd": [P, P, P, P, P, I, I, I, P],
+    "edm_scalelong_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "edm_concat_gate_fwd": [P, P, P, P, P, I, I, I, I, P],
+    "edm_concat_gate_bwd": [P, P, P, P, P, I, I, I, I, P],
+    "edm_precond_in": [P, P, I, F, P, I, I, I, I, P],
+    "edm_conv_out_fwd": [P, P, P, P, P, I, F, P, P, I, I, I, I, P],
+    "edm_conv_out_bwd": [P, P, P, P, P, P, I, F, P, P, P, I, I, I, I, P],
+    "edm_nchw_to_nhwc_bf16": [P, P, I, I, I, P],
+    "edm_nhwc_bf16_to_nchw": [P, P, I, I, I, P],
+    # conv_igemm.hip / conv_wgrad.hip
+    "edm_conv_igemm": [P, P, P, P, F, F, I, I, I, I, I, I, P],
+    "edm_conv_wgrad_nsplit": [I, I, I, I, I, I],
+    "edm_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, P],
+    # attention.hip
+    "edm_attention_fwd": [P, P, I, I, I, I, P],
+    "edm_attention_bwd": [P, P, P, P, I, I, I, I, P],
+    # linear.hip
+    "edm_linear_fwd": [P, P, P, I, I, I, P],
+    "edm_linear_dgrad": [P, P, P, I, I, I, I, P],
+    "edm_linear_wgrad": [P, P, P, I, I, I, I, P],
+    "edm_fourier_fwd": [P, I, P, P, P, I, I, P],
+    "edm_embed_combine_fwd": [P, P, P, F, I, P, P, I, I, P],
+    "edm_embed_combine_bwd": [P, P, P, F, I, P, P, I, I, P],
+    # optim.hip
+    "edm_diffuse": [P, P, P, F, F, I, L, U64, U, P],
+    "edm_diffuse_given": [P, P, P, P, P, F, F, I, L, P],
+    "edm_weighted_mse": [P, P, P, P, F, P, P, I, L, P],
+    "edm_adam_ema": [P, P, P, P, P, L, F, F, F, F, I, F, F, P],
+    "edm_heun_euler": [P, P, F, F, P, P, L, P],
+    "edm_heun_correct": [P, P, P, P, F, F, P, L, P],
+    "edm_scale_f32": [P, F, P, L, P],
+    # weights.hip
+    "edm_weight_prep": [P, I, I, I, I, P, P, P, P, I, P],
+    "edm_wgrad_finish": [P, I, P, P, P, I, I, I, I, F, I, P],
+}
+_RET = {"edm_last_error": ctypes.c_char_p}
+_NO_STATUS = {"edm_version", "edm_last_error", "edm_conv_wgrad_nsplit"}
+
+_lib = None
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the HIP library; raise loudly if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"tinyedm_amd: {LIB_PATH} is missing -- build it with `python -m tinyedm_amd.build` "
+                "(there is no CPU fallback for the HIP hot path)")
+        h = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError here = header/library out of sync
+            fn.argtypes = args
+            fn.restype = _RET.get(name, ctypes.c_int)
+        _lib = h
+    return _lib
+
+
+def call(name: str, *args):
+    """Invoke a status-returning entry point; raise HipKernelError on a non-zero status."""
+    h = lib()
+    rc = getattr(h, name)(*args)
+    if name in _NO_STATUS:
+        return rc
+    if rc != 0:
+        msg = h.edm_last_error()
+        raise HipKernelError(f"{name} failed (status {rc}): {msg.decode() if msg else '?'}")
+    return rc

@@ -1,0 +1,848 @@
+// HBM-bound elementwise / per-pixel / per-(sample,channel) kernels of the EDM2 U-Net.
+// Activations are NHWC bf16 ("pixels x channels", channel contiguous); each lane moves
+// 8 channels = 16 B per access (coalesced dwordx4), reductions are wavefront shuffles.
+// Reference semantics cited per kernel (file:line relative to /root/reference/src/tinyedm).
+#include "common.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+// ------------------------------------------------------------------ error plumbing
+static thread_local char g_err[512] = "";
+extern "C" void edm_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* edm_last_error() { return g_err; }
+extern "C" int edm_version() { return 1; }
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline int grid_for(long work, int block, int cap = 256 * 16) {
+  long g = (work + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ------------------------------------------------------------------ pixel_norm + mp_silu
+// networks.py:9-14 (pixel_norm over C), :83-84 (mp_silu), used at :249-252.
+// xn = x / (eps + ||x||/sqrt(C));  a = mp_silu(xn);  dsave = eps + ||x||/sqrt(C)
+template <int LPP>
+__global__ __launch_bounds__(256) void k_pnorm_silu_fwd(const bf16* __restrict__ x, bf16* __restrict__ xn,
+                                                          bf16* __restrict__ a, float* __restrict__ dsave, int P,
+                                                          int C) {
+  constexpr int GPW = 64 / LPP;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lig = lane % LPP, grp = lane / LPP;
+  const int CL = C >> 3;
+  const float rsC = rsqrtf((float)C);
+  const long stride = (long)gridDim.x * 4 * GPW;
+  for (long p0 = ((long)blockIdx.x * 4 + wave) * GPW; p0 < P; p0 += stride) {
+    const long p = p0 + grp;
+    const bool pv = p < P;
+    float v[2][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int c8 = lig + it * LPP;
+      if (pv && c8 < CL) {
+        load8(x + p * C + c8 * 8, v[it]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ss += v[it][i] * v[it][i];
+      }
+    }
+    ss = group_sum<LPP>(ss);
+    const float d = NORM_EPS + sqrtf(ss) * rsC;
+    const float inv = 1.0f / d;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int c8 = lig + it * LPP;
+      if (pv && c8 < CL) {
+        float o[8], s[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          o[i] = (float)(bf16)(v[it][i] * inv);
+          s[i] = mp_silu_f(o[i]);
+        }
+        store8(xn + p * C + c8 * 8, o);
+        store8(a + p * C + c8 * 8, s);
+      }
+    }
+    if (pv && lig == 0) dsave[p] = d;
+  }
+}
+
+// backward of the pair above.  g = gs*gxn + mp_silu'(xn)*ga ;  dx = (g - xn*<g,xn>*d/(C*(d-eps)))/d
+template <int LPP>
+__global__ __launch_bounds__(256) void k_pnorm_silu_bwd(const bf16* __restrict__ xn, const float* __restrict__ dsave,
+                                                          const bf16* __restrict__ gxn, float gs,
+                                                          const bf16* __restrict__ ga, bf16* __restrict__ gx, int P,
+                                                          int C) {
+  constexpr int GPW = 64 / LPP;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lig = lane % LPP, grp = lane / LPP;
+  const int CL = C >> 3;
+  const long stride = (long)gridDim.x * 4 * GPW;
+  for (long p0 = ((long)blockIdx.x * 4 + wave) * GPW; p0 < P; p0 += stride) {
+    const long p = p0 + grp;
+    const bool pv = p < P;
+    float y[2][8], g[2][8];
+    float dot = 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int c8 = lig + it * LPP;
+      if (pv && c8 < CL) {
+        load8(xn + p * C + c8 * 8, y[it]);
+        float t[8];
+        if (gxn) {
+          load8(gxn + p * C + c8 * 8, t);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) g[it][i] = gs * t[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) g[it][i] = 0.f;
+        }
+        if (ga) {
+          load8(ga + p * C + c8 * 8, t);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) g[it][i] += mp_silu_grad_f(y[it][i]) * t[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dot += g[it][i] * y[it][i];
+      }
+    }
+    dot = group_sum<LPP>(dot);
+    float d = pv ? dsave[p] : 1.f;
+    float s = d - NORM_EPS;
+    float coef = s > 0.f ? dot * d / ((float)C * s) : 0.f;
+    float inv = 1.0f / d;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int c8 = lig + it * LPP;
+      if (pv && c8 < CL) {
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (g[it][i] - y[it][i] * coef) * inv;
+        store8(gx + p * C + c8 * 8, o);
+      }
+    }
+  }
+}
+
+static int pick_lpp(int C) {
+  int cl = C / 8;
+  return cl <= 16 ? 16 : (cl <= 32 ? 32 : 64);
+}
+
+extern "C" int edm_pixelnorm_silu_fwd(const void* x, void* xn, void* a, float* dsave, long P, int C,
+                                      hipStream_t st) {
+  EDM_REQUIRE(P > 0 && C > 0 && C % 8 == 0 && C <= 1024, "pixelnorm_silu_fwd: bad P=%ld C=%d", P, C);
+  int lpp = pick_lpp(C);
+  int gpw = 64 / lpp;
+  int grid = grid_for(P, 4 * gpw);
+#define L(N) hipLaunchKernelGGL(k_pnorm_silu_fwd<N>, dim3(grid), dim3(256), 0, st, (const bf16*)x, (bf16*)xn, (bf16*)a, dsave, (int)P, C)
+  if (lpp == 16) L(16); else if (lpp == 32) L(32); else L(64);
+#undef L
+  EDM_CHECK_LAUNCH("pixelnorm_silu_fwd");
+  return EDM_OK;
+}
+
+extern "C" int edm_pixelnorm_silu_bwd(const void* xn, const float* dsave, const void* gxn, float gxn_scale,
+                                      const void* ga, void* gx, long P, int C, hipStream_t st) {
+  EDM_REQUIRE(P > 0 && C > 0 && C % 8 == 0 && C <= 1024, "pixelnorm_silu_bwd: bad P=%ld C=%d", P, C);
+  int lpp = pick_lpp(C);
+  int gpw = 64 / lpp;
+  int grid = grid_for(P, 4 * gpw);
+#define L(N) hipLaunchKernelGGL(k_pnorm_silu_bwd<N>, dim3(grid), dim3(256), 0, st, (const bf16*)xn, dsave, (const bf16*)gxn, gxn_scale, (const bf16*)ga, (bf16*)gx, (int)P, C)
+  if (lpp == 16) L(16); else if (lpp == 32) L(32); else L(64);
+#undef L
+  EDM_CHECK_LAUNCH("pixelnorm_silu_bwd");
+  return EDM_OK;
+}
+
+// ------------------------------------------------------------------ plain mp_silu (decoder residual branch, networks.py:316)
+__global__ void k_silu_fwd(const bf16* __restrict__ x, bf16* __restrict__ a, long n8) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float v[8];
+    load8(x + i * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = mp_silu_f(v[j]);
+    store8(a + i * 8, v);
+  }
+}
+// gx = mp_silu'(x)*ga + s*ge   (ge optional)
+__global__ void k_silu_bwd(const bf16* __restrict__ x, const bf16* __restrict__ ga, const bf16* __restrict__ ge,
+                           float s, bf16* __restrict__ gx, long n8) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float v[8], g[8], e[8];
+    load8(x + i * 8, v);
+    load8(ga + i * 8, g);
+    if (ge) load8(ge + i * 8, e);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = mp_silu_grad_f(v[j]) * g[j] + (ge ? s * e[j] : 0.f);
+    store8(gx + i * 8, g);
+  }
+}
+extern "C" int edm_silu_fwd(const void* x, void* a, long n, hipStream_t st) {
+  EDM_REQUIRE(n > 0 && n % 8 == 0, "silu_fwd: n=%ld must be a positive multiple of 8", n);
+  hipLaunchKernelGGL(k_silu_fwd, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, (const bf16*)x, (bf16*)a, n / 8);
+  EDM_CHECK_LAUNCH("silu_fwd");
+  return EDM_OK;
+}
+extern "C" int edm_silu_bwd(const void* x, const void* ga, const void* gextra, float extra_scale, void* gx, long n,
+                            hipStream_t st) {
+  EDM_REQUIRE(n > 0 && n % 8 == 0, "silu_bwd: n=%ld must be a positive multiple of 8", n);
+  hipLaunchKernelGGL(k_silu_bwd, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, (const bf16*)x, (const bf16*)ga,
+                     (const bf16*)gextra, extra_scale, (bf16*)gx, n / 8);
+  EDM_CHECK_LAUNCH("silu_bwd");
+  return EDM_OK;
+}
+
+// ------------------------------------------------------------------ out = alpha*a + beta*b  (mp_add, networks.py:87-88)
+__global__ void k_axpby(const bf16* __restrict__ a, float alpha, const bf16* __restrict__ b, float beta,
+                        bf16* __restrict__ o, long n8) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float u[8], v[8];
+    load8(a + i * 8, u);
+    if (b) load8(b + i * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) u[j] = alpha * u[j] + (b ? beta * v[j] : 0.f);
+    store8(o + i * 8, u);
+  }
+}
+extern "C" int edm_axpby(const void* a, float alpha, const void* b, float beta, void* out, long n, hipStream_t st) {
+  EDM_REQUIRE(n > 0 && n % 8 == 0, "axpby: n=%ld must be a positive multiple of 8", n);
+  hipLaunchKernelGGL(k_axpby, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, (const bf16*)a, alpha, (const bf16*)b,
+                     beta, (bf16*)out, n / 8);
+  EDM_CHECK_LAUNCH("axpby");
+  return EDM_OK;
+}
+
+// ------------------------------------------------------------------ embedding modulation + mp_silu + dropout
+// networks.py:255-260 / 319-324:  a = dropout(mp_silu(r * (lin*gain + 1)))
+// lin is the per-block embed Linear output (B,C) fp32, gain a device scalar.
+__device__ __forceinline__ bool keep_elem(uint32_t r, float p) { return u32_to_unit(r) >= p; }
+
+__global__ void k_mod_silu_drop_fwd(const bf16* __restrict__ r, const float* __restrict__ lin,
+                                    const float* __restrict__ gain, bf16* __restrict__ a, int HW, int C, long n8,
+                                    float pdrop, uint32_t seed_lo, uint32_t seed_hi, uint32_t sub, uint32_t step) {
+  const int CL = C >> 3;
+  const float g = *gain;
+  const float keep_scale = pdrop > 0.f ? 1.0f / (1.0f - pdrop) : 1.0f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % CL);
+    const long pix = i / CL;
+    const int b = (int)(pix / HW);
+    float v[8];
+    load8(r + i * 8, v);
+    const float* lp = lin + (long)b * C + c8 * 8;
+    Philox4 r0, r1;
+    if (pdrop > 0.f) {
+      r0 = philox4x32_10((uint32_t)(2 * i), (uint32_t)((2 * i) >> 32), sub, step, seed_lo, seed_hi);
+      r1 = philox4x32_10((uint32_t)(2 * i + 1), (uint32_t)((2 * i + 1) >> 32), sub, step, seed_lo, seed_hi);
+    }
+    uint32_t rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float m = lp[j] * g + 1.0f;
+      float o = mp_silu_f(v[j] * m);
+      if (pdrop > 0.f) o = keep_elem(rr[j], pdrop) ? o * keep_scale : 0.f;
+      v[j] = o;
+    }
+    store8(a + i * 8, v);
+  }
+}
+
+// backward: gr = ga*keep*mp_silu'(u)*m ;  gm[b,c] += sum_hw ga*keep*mp_silu'(u)*r   (u = r*m)
+// block = CL*PS threads (thread -> fixed channel chunk), grid = (B, ceil(HW/PIXW))
+__global__ void k_mod_silu_drop_bwd(const bf16* __restrict__ r, const float* __restrict__ lin,
+                                    const float* __restrict__ gain, const bf16* __restrict__ ga,
+                                    bf16* __restrict__ gr, float* __restrict__ gm, int HW, int C, int PIXW,
+                                    float pdrop, uint32_t seed_lo, uint32_t seed_hi, uint32_t sub, uint32_t step) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int CL = C >> 3;
+  const int PS = blockDim.x / CL;
+  const int c8 = threadIdx.x % CL, ps = threadIdx.x / CL;
+  const int b = blockIdx.x;
+  const int p_begin = blockIdx.y * PIXW;
+  const int p_end = min(HW, p_begin + PIXW);
+  const float g = *gain;
+  const float keep_scale = pdrop > 0.f ? 1.0f / (1.0f - pdrop) : 1.0f;
+  float m[8], acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    m[j] = lin[(long)b * C + c8 * 8 + j] * g + 1.0f;
+    acc[j] = 0.f;
+  }
+  for (int p = p_begin + ps; p < p_end; p += PS) {
+    const long i = ((long)b * HW + p) * CL + c8;
+    float v[8], gg[8];
+    load8(r + i * 8, v);
+    load8(ga + i * 8, gg);
+    Philox4 r0, r1;
+    if (pdrop > 0.f) {
+      r0 = philox4x32_10((uint32_t)(2 * i), (uint32_t)((2 * i) >> 32), sub, step, seed_lo, seed_hi);
+      r1 = philox4x32_10((uint32_t)(2 * i + 1), (uint32_t)((2 * i + 1) >> 32), sub, step, seed_lo, seed_hi);
+    }
+    uint32_t rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float gu = gg[j] * mp_silu_grad_f(v[j] * m[j]);
+      if (pdrop > 0.f) gu = keep_elem(rr[j], pdrop) ? gu * keep_scale : 0.f;
+      acc[j] += gu * v[j];
+      gg[j] = gu * m[j];
+    }
+    store8(gr + i * 8, gg);
+  }
+  // reduce the PS partial sums per channel through LDS, one atomic per (b,c)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[ps * C + c8 * 8 + j] = acc[j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int q = 0; q < PS; ++q) s += red[q * C + c];
+    atomicAdd(gm + (long)b * C + c, s);
+  }
+}
+// glin = gm*gain ; ggain += sum gm*lin
+__global__ void k_mod_finish(const float* __restrict__ gm, const float* __restrict__ lin,
+                             const float* __restrict__ gain, float* __restrict__ glin, float* __restrict__ ggain,
+                             long n) {
+  const float g = *gain;
+  float part = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = gm[i];
+    glin[i] = v * g;
+    part += v * lin[i];
+  }
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0) atomicAdd(ggain, part);
+}
+
+static int block_for_chunks(int CL) { return (256 / CL) * CL; }
+
+extern "C" int edm_mod_silu_drop_fwd(const void* r, const float* lin, const float* gain, void* a, int B, int HW,
+                                     int C, float pdrop, unsigned long long seed, unsigned sub, unsigned step,
+                                     hipStream_t st) {
+  EDM_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && C > 0 && pdrop >= 0.f && pdrop < 1.f, "mod_silu_drop_fwd: bad args");
+  long n8 = (long)B * HW * C / 8;
+  hipLaunchKernelGGL(k_mod_silu_drop_fwd, dim3(grid_for(n8, 256)), dim3(256), 0, st, (const bf16*)r, lin, gain,
+                     (bf16*)a, HW, C, n8, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), sub, step);
+  EDM_CHECK_LAUNCH("mod_silu_drop_fwd");
+  return EDM_OK;
+}
+
+// gm must be zero-filled [B,C] fp32 scratch; glin [B,C]; ggain device scalar accumulated (+=).
+extern "C" int edm_mod_silu_drop_bwd(const void* r, const float* lin, const float* gain, const void* ga, void* gr,
+                                     float* gm, float* glin, float* ggain, int B, int HW, int C, float pdrop,
+                                     unsigned long long seed, unsigned sub, unsigned step, hipStream_t st) {
+  EDM_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && C > 0 && C <= 1024, "mod_silu_drop_bwd: bad args");
+  int CL = C / 8, block = block_for_chunks(CL), PS = block / CL;
+  int PIXW = HW >= 256 ? 128 : HW;
+  hipLaunchKernelGGL(k_mod_silu_drop_bwd, dim3(B, cdiv(HW, PIXW)), dim3(block), PS * C * sizeof(float), st,
+                     (const bf16*)r, lin, gain, (const bf16*)ga, (bf16*)gr, gm, HW, C, PIXW, pdrop, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), sub, step);
+  EDM_CHECK_LAUNCH("mod_silu_drop_bwd");
+  hipLaunchKernelGGL(k_mod_finish, dim3(grid_for((long)B * C, 256, 64)), dim3(256), 0, st, gm, lin, gain, glin,
+                     ggain, (long)B * C);
+  EDM_CHECK_LAUNCH("mod_finish");
+  return EDM_OK;
+}
+
+// exported for tests: the keep-mask the two kernels above derive from (seed, sub, step)
+__global__ void k_dropout_mask(uint8_t* __restrict__ mask, long n8, float pdrop, uint32_t seed_lo, uint32_t seed_hi,
+                               uint32_t sub, uint32_t step) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    Philox4 r0 = philox4x32_10((uint32_t)(2 * i), (uint32_t)((2 * i) >> 32), sub, step, seed_lo, seed_hi);
+    Philox4 r1 = philox4x32_10((uint32_t)(2 * i + 1), (uint32_t)((2 * i + 1) >> 32), sub, step, seed_lo, seed_hi);
+    uint32_t rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mask[i * 8 + j] = keep_elem(rr[j], pdrop) ? 1 : 0;
+  }
+}
+extern "C" int edm_dropout_mask(unsigned char* mask, long n, float pdrop, unsigned long long seed, unsigned sub,
+                                unsigned step, hipStream_t st) {
+  EDM_REQUIRE(n > 0 && n % 8 == 0, "dropout_mask: n must be a multiple of 8");
+  hipLaunchKernelGGL(k_dropout_mask, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, mask, n / 8, pdrop,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), sub, step);
+  EDM_CHECK_LAUNCH("dropout_mask");
+  return EDM_OK;
+}
+
+// ------------------------------------------------------------------ 2x resampling (networks.py:72, :80)
+// avgpool:  y[b,h,w,c] = s * sum_{i,j<2} x[b,2h+i,2w+j,c]     (H,W = OUTPUT dims)
+__global__ void k_pool2(const bf16* __restrict__ x, bf16* __restrict__ y, int H, int W, int CL, long n8, float s) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    int c8 = (int)(i % CL);
+    long pix = i / CL;
+    int w = (int)(pix % W);
+    long t = pix / W;
+    int h = (int)(t % H);
+    long b = t / H;
+    const long row = (long)2 * W * CL;
+    const bf16* src = x + (((b * 2 * H + 2 * h) * 2 * W + 2 * w) * CL + c8) * 8;
+    float a0[8], a1[8], a2[8], a3[8];
+    load8(src, a0);
+    load8(src + CL * 8, a1);
+    load8(src + row * 8, a2);
+    load8(src + row * 8 + CL * 8, a3);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a0[j] = s * (a0[j] + a1[j] + a2[j] + a3[j]);
+    store8(y + i * 8, a0);
+  }
+}
+// nearest-exact x2:  y[b,h,w,c] = s * x[b,h/2,w/2,c]   (H,W = OUTPUT dims)
+__global__ void k_up2(const bf16* __restrict__ x, bf16* __restrict__ y, int H, int W, int CL, long n8, float s) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    int c8 = (int)(i % CL);
+    long pix = i / CL;
+    int w = (int)(pix % W);
+    long t = pix / W;
+    int h = (int)(t % H);
+    long b = t / H;
+    const bf16* src = x + (((b * (H / 2) + h / 2) * (W / 2) + w / 2) * CL + c8) * 8;
+    float a0[8];
+    load8(src, a0);
+    if (s != 1.0f) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a0[j] *= s;
+    }
+    store8(y + i * 8, a0);
+  }
+}
+extern "C" int edm_pool2(const void* x, void* y, int B, int Hout, int Wout, int C, float scale, hipStream_t st) {
+  EDM_REQUIRE(B > 0 && Hout > 0 && Wout > 0 && C % 8 == 0, "pool2: bad args");
+  long n8 = (long)B * Hout * Wout * C / 8;
+  hipLaunchKernelGGL(k_pool2, dim3(grid_for(n8, 256)), dim3(256), 0, st, (const bf16*)x, (bf16*)y, Hout, Wout, C / 8,
+                     n8, scale);
+  EDM_CHECK_LAUNCH("pool2");
+  return EDM_OK;
+}
+extern "C" int edm_up2(const void* x, void* y, int B, int Hout, int Wout, int C, float scale, hipStream_t st) {
+  EDM_REQUIRE(B > 0 && Hout > 0 && Wout > 0 && Hout % 2 == 0 && Wout % 2 == 0 && C % 8 == 0, "up2: bad args");
+  long n8 = (long)B * Hout * Wout * C / 8;
+  hipLaunchKernelGGL(k_up2, dim3(grid_for(n8, 256)), dim3(256), 0, st, (const bf16*)x, (bf16*)y, Hout, Wout, C / 8,
+                     n8, scale);
+  EDM_CHECK_LAUNCH("up2");
+  return EDM_OK;
+}
+
+// ------------------------------------------------------------------ ScaleLong skip gate (networks.py:106-118) + concat (:311)
+// sum over HW of  x (optionally x*y)  per (b,c)  -> out[b,c] += scale * sum      (out pre-zeroed)
+__global__ void k_reduce_hw(const bf16* __restrict__ x, long xs, const bf16* __restrict__ y, long ys,
+                            float* __restrict__ out, int HW, int C, int PIXW, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int CL = C >> 3;
+  const int PS = blockDim.x / CL;
+  const int c8 = threadIdx.x % CL, ps = threadIdx.x / CL;
+  const int b = blockIdx.x;
+  const int p_begin = blockIdx.y * PIXW, p_end = min(HW, p_begin + PIXW);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int p = p_begin + ps; p < p_end; p += PS) {
+    const long pix = (long)b * HW + p;
+    float v[8], u[8];
+    load8(x + pix * xs + c8 * 8, v);
+    if (y) {
+      load8(y + pix * ys + c8 * 8, u);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += v[j] * u[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[ps * C + c8 * 8 + j] = acc[j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int q = 0; q < PS; ++q) s += red[q * C + c];
+    atomicAdd(out + (long)b * C + c, s * scale);
+  }
+}
+// x: rows of xs elements (uses first C), y optional rows of ys elements; out[b,c] += scale*sum_hw x*(y)
+extern "C" int edm_reduce_hw(const void* x, long x_stride, const void* y, long y_stride, float* out, int B, int HW,
+                             int C, float scale, hipStream_t st) {
+  EDM_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && C > 0 && C <= 1024 && x_stride % 8 == 0 && y_stride % 8 == 0,
+              "reduce_hw: bad args");
+  int CL = C / 8, block = block_for_chunks(CL), PS = block / CL;
+  int PIXW = HW >= 256 ? 128 : HW;
+  hipLaunchKernelGGL(k_reduce_hw, dim3(B, cdiv(HW, PIXW)), dim3(block), PS * C * sizeof(float), st, (const bf16*)x,
+                     x_stride, (const bf16*)y, y_stride, out, HW, C, PIXW, scale);
+  EDM_CHECK_LAUNCH("reduce_hw");
+  return EDM_OK;
+}
+
+// per-sample gate MLP, fp32:  m=[mean;1] -> z1=W1 m -> h=mp_silu(z1) -> z2=W2 h -> gate=sigmoid(z2)
+// W1h [R][C+1], W2h [C][R] are effective (normalised, /sqrt(fan_in)) fp32 weights.
+__global__ void k_scalelong_fwd(const float* __restrict__ mean, const float* __restrict__ W1, const float* __restrict__ W2,
+                                float* __restrict__ gate, float* __restrict__ z1save, int C, int R) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // m[C+1], h[R]
+  float* m = sm;
+  float* h = sm + C + 1;
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) m[c] = mean[(long)b * C + c];
+  if (threadIdx.x == 0) m[C] = 1.0f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int r = wave; r < R; r += nw) {
+    float s = 0.f;
+    for (int c = lane; c <= C; c += 64) s += W1[(long)r * (C + 1) + c] * m[c];
+    s = wave_sum(s);
+    if (lane == 0) {
+      z1save[(long)b * R + r] = s;
+      h[r] = mp_silu_f(s);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += W2[(long)c * R + r] * h[r];
+    gate[(long)b * C + c] = sigmoidf_(s);
+  }
+}
+// backward: ggate[b,C] -> gmean[b,C], gW1 += , gW2 += (fp32 atomics; tiny)
+__global__ void k_scalelong_bwd(const float* __restrict__ mean, const float* __restrict__ W1, const float* __restrict__ W2,
+                                const float* __restrict__ gate, const float* __restrict__ z1save,
+                                const float* __restrict__ ggate, float* __restrict__ gmean, float* __restrict__ gW1,
+                                float* __restrict__ gW2, int C, int R) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // m[C+1], h[R], gz2[C], gz1[R]
+  float* m = sm;
+  float* h = m + C + 1;
+  float* gz2 = h + R;
+  float* gz1 = gz2 + C;
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    m[c] = mean[(long)b * C + c];
+    float g = gate[(long)b * C + c];
+    gz2[c] = ggate[(long)b * C + c] * g * (1.0f - g);
+  }
+  if (threadIdx.x == 0) m[C] = 1.0f;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) h[r] = mp_silu_f(z1save[(long)b * R + r]);
+  __syncthreads();
+  // gW2[c][r] += gz2[c]*h[r]
+  for (int i = threadIdx.x; i < C * R; i += blockDim.x) atomicAdd(gW2 + i, gz2[i / R] * h[i % R]);
+  // gh[r] = sum_c W2[c][r] gz2[c] ; gz1 = gh * mp_silu'(z1)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int r = wave; r < R; r += nw) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += W2[(long)c * R + r] * gz2[c];
+    s = wave_sum(s);
+    if (lane == 0) gz1[r] = s * mp_silu_grad_f(z1save[(long)b * R + r]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < R * (C + 1); i += blockDim.x) atomicAdd(gW1 + i, gz1[i / (C + 1)] * m[i % (C + 1)]);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += W1[(long)r * (C + 1) + c] * gz1[r];
+    gmean[(long)b * C + c] = s;
+  }
+}
+extern "C" int edm_scalelong_fwd(const float* mean, const float* W1h, const float* W2h, float* gate, float* z1save,
+                                 int B, int C, int R, hipStream_t st) {
+  EDM_REQUIRE(B > 0 && C > 0 && R > 0 && C <= 4096, "scalelong_fwd: bad args");
+  hipLaunchKernelGGL(k_scalelong_fwd, dim3(B), dim3(256), (C + 1 + R) * sizeof(float), st, mean, W1h, W2h, gate,
+                     z1save, C, R);
+  EDM_CHECK_LAUNCH("scalelong_fwd");
+  return EDM_OK;
+}
+extern "C" int edm_scalelong_bwd(const float* mean, const float* W1h, const float* W2h, const float* gate,
+                                 const float* z1save, const float* ggate, float* gmean, float* gW1h, float* gW2h,
+                                 int B, int C, int R, hipStream_t st) {
+  EDM_REQUIRE(B > 0 && C > 0 && R > 0 && C <= 4096, "scalelong_bwd: bad args");
+  hipLaunchKernelGGL(k_scalelong_bwd, dim3(B), dim3(256), (2 * C + 1 + 2 * R) * sizeof(float), st, mean, W1h, W2h,
+                     gate, z1save, ggate, gmean, gW1h, gW2h, C, R);
+  EDM_CHECK_LAUNCH("scalelong_bwd");
+  return EDM_OK;
+}
+
+// cat[b,p,:Ci] = inp ; cat[b,p,Ci:] = skip*gate[b,:]     (and optionally s = mp_silu(cat))
+__global__ void k_concat_gate_fwd(const bf16* __restrict__ inp, const bf16* __restrict__ skip,
+                                  const float* __restrict__ gate, bf16* __restrict__ cat, bf16* __restrict__ sil,
+                                  int HW, int Ci, int Cs, long n8) {
+  const int CLt = (Ci + Cs) >> 3, CLi = Ci >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    int c8 = (int)(i % CLt);
+    long pix = i / CLt;
+    float v[8];
+    if (c8 < CLi) {
+      load8(inp + pix * Ci + c8 * 8, v);
+    } else {
+      int cs = (c8 - CLi) * 8;
+      int b = (int)(pix / HW);
+      load8(skip + pix * Cs + cs, v);
+      const float* gp = gate + (long)b * Cs + cs;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (float)(bf16)(v[j] * gp[j]);
+    }
+    store8(cat + i * 8, v);
+    if (sil) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = mp_silu_f(v[j]);
+      store8(sil + i * 8, v);
+    }
+  }
+}
+// ginp = gcat[..., :Ci] ; gskip = gcat[..., Ci:]*gate + gmean/HW
+__global__ void k_concat_gate_bwd(const bf16* __restrict__ gcat, const float* __restrict__ gate,
+                                  const float* __restrict__ gmean, bf16* __restrict__ ginp, bf16* __restrict__ gskip,
+                                  int HW, int Ci, int Cs, long n8, float inv_hw) {
+  const int CLt = (Ci + Cs) >> 3, CLi = Ci >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    int c8 = (int)(i % CLt);
+    long pix = i / CLt;
+    float v[8];
+    load8(gcat + i * 8, v);
+    if (c8 < CLi) {
+      store8(ginp + pix * Ci + c8 * 8, v);
+    } else {
+      int cs = (c8 - CLi) * 8;
+      int b = (int)(pix / HW);
+      const float* gp = gate + (long)b * Cs + cs;
+      const float* mp = gmean + (long)b * Cs + cs;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = v[j] * gp[j] + mp[j] * inv_hw;
+      store8(gskip + pix * Cs + cs, v);
+    }
+  }
+}
+extern "C" int edm_concat_gate_fwd(const void* inp, const void* skip, const float* gate, void* cat, void* silu_out,
+                                   int B, int HW, int Ci, int Cs, hipStream_t st) {
+  EDM_REQUIRE(B > 0 && HW > 0 && Ci % 8 == 0 && Cs % 8 == 0 && Ci > 0 && Cs > 0, "concat_gate_fwd: bad args");
+  long n8 = (long)B * HW * (Ci + Cs) / 8;
+  hipLaunchKernelGGL(k_concat_gate_fwd, dim3(grid_for(n8, 256)), dim3(256), 0, st, (const bf16*)inp,
+                     (const bf16*)skip, gate, (bf16*)cat, (bf16*)silu_out, HW, Ci, Cs, n8);
+  EDM_CHECK_LAUNCH("concat_gate_fwd");
+  return EDM_OK;
+}
+extern "C" int edm_concat_gate_bwd(const void* gcat, const float* gate, const float* gmean, void* ginp, void* gskip,
+                                   int B, int HW, int Ci, int Cs, hipStream_t st) {
+  EDM_REQUIRE(B > 0 && HW > 0 && Ci % 8 == 0 && Cs % 8 == 0 && Ci > 0 && Cs > 0, "concat_gate_bwd: bad args");
+  long n8 = (long)B * HW * (Ci + Cs) / 8;
+  hipLaunchKernelGGL(k_concat_gate_bwd, dim3(grid_for(n8, 256)), dim3(256), 0, st, (const bf16*)gcat, gate, gmean,
+                     (bf16*)ginp, (bf16*)gskip, HW, Ci, Cs, n8, 1.0f / (float)HW);
+  EDM_CHECK_LAUNCH("concat_gate_bwd");
+  return EDM_OK;
+}
+
+// ------------------------------------------------------------------ preconditioning (networks.py:578-587, 602-603)
+// out[b,h,w,:] = [ c_in(b)*noisy[b,:,h,w] , 1 , 0... ]  bf16, CP channels
+__global__ void k_precond_in(const float* __restrict__ noisy, const float* __restrict__ sigma, int sstride, float sd,
+                             bf16* __restrict__ out, int Cimg, int HW, int CP, long npix) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+    long b = p / HW;
+    int hw = (int)(p % HW);
+    float s = sigma[b * sstride];
+    float cin = rsqrtf(sd * sd + s * s);
+    bf16* o = out + p * CP;
+    for (int c0 = 0; c0 < CP; c0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int c = c0 + j;
+        v[j] = c < Cimg ? cin * noisy[(b * Cimg + c) * HW + hw] : (c == Cimg ? 1.0f : 0.0f);
+      }
+      store8(o + c0, v);
+    }
+  }
+}
+extern "C" int edm_precond_in(const float* noisy, const float* sigma, int sigma_stride, float sigma_data, void* out,
+                              int B, int Cimg, int HW, int CP, hipStream_t st) {
+  EDM_REQUIRE(B > 0 && Cimg > 0 && HW > 0 && CP % 8 == 0 && CP > Cimg && (sigma_stride == 0 || sigma_stride == 1),
+              "precond_in: bad args");
+  long npix = (long)B * HW;
+  hipLaunchKernelGGL(k_precond_in, dim3(grid_for(npix, 256)), dim3(256), 0, st, noisy, sigma, sigma_stride,
+                     sigma_data, (bf16*)out, Cimg, HW, CP, npix);
+  EDM_CHECK_LAUNCH("precond_in");
+  return EDM_OK;
+}
+
+// conv_out (1x1, C -> Co<=8) fused with the output preconditioning:
+//   F[b,o,hw] = sum_c x[p,c]*wh[o,c] ;  D = F*gain_out*c_out(b) + noisy*c_skip(b)     (D, F fp32 NCHW)
+template <int LPP>
+__global__ __launch_bounds__(256) void k_conv_out_fwd(const bf16* __restrict__ x, const float* __restrict__ wh,
+                                                        const float* __restrict__ gain_out,
+                                                        const float* __restrict__ noisy,
+                                                        const float* __restrict__ sigma, int sstride, float sd,
+                                                        float* __restrict__ D, float* __restrict__ Fraw, int HW,
+                                                        int C, int Co, long npix) {
+  constexpr int GPW = 64 / LPP;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lig = lane % LPP, grp = lane / LPP;
+  const int CL = C >> 3;
+  const float go = *gain_out;
+  const long stride = (long)gridDim.x * 4 * GPW;
+  for (long p0 = ((long)blockIdx.x * 4 + wave) * GPW; p0 < npix; p0 += stride) {
+    const long p = p0 + grp;
+    const bool pv = p < npix;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (pv) {
+      for (int c8 = lig; c8 < CL; c8 += LPP) {
+        float v[8];
+        load8(x + p * C + c8 * 8, v);
+        for (int o = 0; o < Co; ++o) {
+          const float* wp = wh + (long)o * C + c8 * 8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[o] += v[j] * wp[j];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = group_sum<LPP>(acc[o]);
+    if (pv && lig == 0) {
+      long b = p / HW;
+      int hw = (int)(p % HW);
+      float s = sigma[b * sstride];
+      float den = s * s + sd * sd;
+      float cskip = sd * sd / den, cout = s * sd * rsqrtf(den);
+      for (int o = 0; o < Co; ++o) {
+        long idx = (b * Co + o) * HW + hw;
+        if (Fraw) Fraw[idx] = acc[o];
+        D[idx] = acc[o] * go * cout + noisy[idx] * cskip;
+      }
+    }
+  }
+}
+extern "C" int edm_conv_out_fwd(const void* x, const float* w_hat, const float* gain_out, const float* noisy,
+                                const float* sigma, int sigma_stride, float sigma_data, float* D, float* Fraw, int B,
+                                int HW, int C, int Co, hipStream_t st) {
+  EDM_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && Co >= 1 && Co <= 8 && (sigma_stride == 0 || sigma_stride == 1),
+              "conv_out_fwd: bad args (Co<=8 required)");
+  long npix = (long)B * HW;
+  hipLaunchKernelGGL(k_conv_out_fwd<32>, dim3(grid_for(npix, 8)), dim3(256), 0, st, (const bf16*)x, w_hat, gain_out,
+                     noisy, sigma, sigma_stride, sigma_data, D, Fraw, HW, C, Co, npix);
+  EDM_CHECK_LAUNCH("conv_out_fwd");
+  return EDM_OK;
+}
+
+// backward of conv_out + preconditioning.  dD fp32 NCHW.
+//   dF = dD*c_out*gain_out ; gx[p,c] = sum_o dF[p,o]*wh[o,c]
+__global__ void k_conv_out_bwd_x(const float* __restrict__ dD, const float* __restrict__ wh,
+                                 const float* __restrict__ gain_out, const float* __restrict__ sigma, int sstride,
+                                 float sd, bf16* __restrict__ gx, int HW, int C, int Co, long n8) {
+  const int CL = C >> 3;
+  const float go = *gain_out;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    int c8 = (int)(i % CL);
+    long p = i / CL;
+    long b = p / HW;
+    int hw = (int)(p % HW);
+    float s = sigma[b * sstride];
+    float cout = s * sd * rsqrtf(s * s + sd * sd) * go;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int o = 0; o < Co; ++o) {
+      float df = dD[(b * Co + o) * HW + hw] * cout;
+      const float* wp = wh + (long)o * C + c8 * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += df * wp[j];
+    }
+    store8(gx + i * 8, v);
+  }
+}
+//   gwh[o,c] += sum_p dF[p,o]*x[p,c] ;  ggain += sum dD*c_out*F
+// block = 64 threads (one chunk each), grid = (ceil(CL/64), ceil(npix/PIXW))
+__global__ void k_conv_out_bwd_w(const bf16* __restrict__ x, const float* __restrict__ dD,
+                                 const float* __restrict__ Fraw, const float* __restrict__ gain_out,
+                                 const float* __restrict__ sigma, int sstride, float sd, float* __restrict__ gwh,
+                                 float* __restrict__ ggain, int HW, int C, int Co, long npix, int PIXW) {
+  const int CL = C >> 3;
+  const int c8 = blockIdx.x * 64 + threadIdx.x;
+  const long p0 = (long)blockIdx.y * PIXW, p1 = min(npix, p0 + PIXW);
+  const float go = *gain_out;
+  float acc[8][8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[o][j] = 0.f;
+  float gg = 0.f;
+  for (long p = p0; p < p1; ++p) {
+    long b = p / HW;
+    int hw = (int)(p % HW);
+    float s = sigma[b * sstride];
+    float cout = s * sd * rsqrtf(s * s + sd * sd);
+    float v[8];
+    if (c8 < CL) load8(x + p * C + c8 * 8, v);
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      if (o < Co) {
+        long idx = (b * Co + o) * HW + hw;
+        float d = dD[idx] * cout;
+        if (blockIdx.x == 0 && threadIdx.x == 0) gg += d * Fraw[idx];
+        d *= go;
+        if (c8 < CL) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[o][j] += d * v[j];
+        }
+      }
+    }
+  }
+  if (c8 < CL) {
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+      if (o < Co) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(gwh + (long)o * C + c8 * 8 + j, acc[o][j]);
+      }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ggain, gg);
+}
+// gw_hat [Co,C] and ggain are accumulated (+=): caller zero-fills.
+extern "C" int edm_conv_out_bwd(const void* x, const float* w_hat, const float* gain_out, const float* Fraw,
+                                const float* dD, const float* sigma, int sigma_stride, float sigma_data, void* gx,
+                                float* gw_hat, float* ggain, int B, int HW, int C, int Co, hipStream_t st) {
+  EDM_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && Co >= 1 && Co <= 8 && (sigma_stride == 0 || sigma_stride == 1),
+              "conv_out_bwd: bad args");
+  long npix = (long)B * HW, n8 = npix * C / 8;
+  hipLaunchKernelGGL(k_conv_out_bwd_x, dim3(grid_for(n8, 256)), dim3(256), 0, st, dD, w_hat, gain_out, sigma,
+                     sigma_stride, sigma_data, (bf16*)gx, HW, C, Co, n8);
+  EDM_CHECK_LAUNCH("conv_out_bwd_x");
+  const int PIXW = 256;
+  hipLaunchKernelGGL(k_conv_out_bwd_w, dim3(cdiv(C / 8, 64), cdiv(npix, PIXW)), dim3(64), 0, st, (const bf16*)x, dD,
+                     Fraw, gain_out, sigma, sigma_stride, sigma_data, gw_hat, ggain, HW, C, Co, npix, PIXW);
+  EDM_CHECK_LAUNCH("conv_out_bwd_w");
+  return EDM_OK;
+}
+
+// ------------------------------------------------------------------ layout helpers (boundary <-> kernel layout)
+// NCHW fp32 -> NHWC bf16 and back (tests / boundary plumbing; C multiple of 8)
+__global__ void k_nchw_f32_to_nhwc_bf16(const float* __restrict__ x, bf16* __restrict__ y, int C, int HW, long n8) {
+  const int CL = C >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    int c8 = (int)(i % CL);
+    long p = i / CL;
+    long b = p / HW;
+    int hw = (int)(p % HW);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = x[(b * C + c8 * 8 + j) * HW + hw];
+    store8(y + i * 8, v);
+  }
+}
+__global__ void k_nhwc_bf16_to_nchw_f32(const bf16* __restrict__ x, float* __restrict__ y, int C, int HW, long n8) {
+  const int CL = C >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    int c8 = (int)(i % CL);
+    long p = i / CL;
+    long b = p / HW;
+    int hw = (int)(p % HW);
+    float v[8];
+    load8(x + i * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[(b * C + c8 * 8 + j) * HW + hw] = v[j];
+  }
+}
+extern "C" int edm_nchw_to_nhwc_bf16(const float* x, void* y, int B, int C, int HW, hipStream_t st) {
+  EDM_REQUIRE(B > 0 && C % 8 == 0 && HW > 0, "nchw_to_nhwc_bf16: bad args");
+  long n8 = (long)B * HW * C / 8;
+  hipLaunchKernelGGL(k_nchw_f32_to_nhwc_bf16, dim3(grid_for(n8, 256)), dim3(256), 0, st, x, (bf16*)y, C, HW, n8);
+  EDM_CHECK_LAUNCH("nchw_to_nhwc_bf16");
+  return EDM_OK;
+}
+extern "C" int edm_nhwc_bf16_to_nchw(const void* x, float* y, int B, int C, int HW, hipStream_t st) {
+  EDM_REQUIRE(B > 0 && C % 8 == 0 && HW > 0, "nhwc_bf16_to_nchw: bad args");
+  long n8 = (long)B * HW * C / 8;
+  hipLaunchKernelGGL(k_nhwc_bf16_to_nchw_f32, dim3(grid_for(n8, 256)), dim3(256), 0, st, (const bf16*)x, y, C, HW, n8);
+  EDM_CHECK_LAUNCH("nhwc_bf16_to_nchw");
+  return EDM_OK;
+}

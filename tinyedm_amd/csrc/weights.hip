@@ -1,0 +1,133 @@
+// Weight-side kernels: forced weight normalisation + effective-weight packing, and the matching
+// gradient finish (split-K slab reduction + projection through the normalisation).
+//
+// Reference semantics (networks.py:32-37 / 55-60, normalize at :17-19):
+//   training forward:  w <- w / (eps + ||w_o|| / sqrt(n))            (in place, no grad)
+//   always:            w_hat = w / (eps + ||w_o|| / sqrt(n)) / sqrt(n)   (differentiable)
+// with n = fan_in = I*taps and the norm taken per output row o.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+  return s;
+}
+
+// one workgroup per packed output row r (master row mo = perm ? perm[r] : r)
+__global__ __launch_bounds__(256) void k_weight_prep(float* __restrict__ w, int O, int I, int taps, int Ipad,
+                                                       bf16* __restrict__ wp_fwd, bf16* __restrict__ wp_dgrad,
+                                                       float* __restrict__ w_hat, const int* __restrict__ perm,
+                                                       int normalize_inplace) {
+  __shared__ float red[8];
+  const int r = blockIdx.x;
+  const int mo = perm ? perm[r] : r;
+  const int n = I * taps;
+  float* row = w + (long)mo * n;
+  const float rsn = rsqrtf((float)n);
+  float ss = 0.f;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) ss += row[e] * row[e];
+  ss = block_sum(ss, red);
+  float d = NORM_EPS + sqrtf(ss) * rsn;
+  float pre = 1.0f;  // factor applied to the stored master row
+  if (normalize_inplace) {
+    pre = 1.0f / d;
+    // norm of the re-normalised row, recomputed from the rounded fp32 values like the reference does
+    float ss2 = 0.f;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+      float v = row[e] * pre;
+      ss2 += v * v;
+    }
+    ss2 = block_sum(ss2, red);
+    d = NORM_EPS + sqrtf(ss2) * rsn;
+  }
+  const float post = rsn / d;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    const float wm = row[e] * pre;
+    if (normalize_inplace) row[e] = wm;
+    const float wh = wm * post;
+    const int i = e / taps, t = e - i * taps;
+    if (wp_fwd) wp_fwd[((long)t * O + r) * Ipad + i] = (bf16)wh;
+    if (wp_dgrad) wp_dgrad[((long)(taps - 1 - t) * I + i) * O + r] = (bf16)wh;
+    if (w_hat) w_hat[(long)mo * n + e] = wh;
+  }
+  if (wp_fwd && Ipad > I) {
+    const int padn = (Ipad - I) * taps;
+    for (int e = threadIdx.x; e < padn; e += blockDim.x) {
+      const int t = e / (Ipad - I), i = I + e % (Ipad - I);
+      wp_fwd[((long)t * O + r) * Ipad + i] = (bf16)0.f;
+    }
+  }
+}
+
+// grad[mo, i, t] (=|+=) projection( scale * sum_s slabs[s, t, r, i] ) through w_hat = w/(d*sqrt(n))
+__global__ __launch_bounds__(256) void k_wgrad_finish(const float* __restrict__ slabs, int S, const float* __restrict__ w,
+                                                        float* __restrict__ grad, const int* __restrict__ perm, int O,
+                                                        int I, int Ipad, int taps, float scale, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) float g[];  // n floats
+  __shared__ float red[8];
+  const int r = blockIdx.x;
+  const int mo = perm ? perm[r] : r;
+  const int n = I * taps;
+  const float* row = w + (long)mo * n;
+  const long slab_stride = (long)taps * O * Ipad;
+  float dot = 0.f, ss = 0.f;
+  // iterate in packed order (t major, i minor) for coalesced slab reads
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    const int t = e / I, i = e - t * I;
+    const float* sp = slabs + ((long)t * O + r) * Ipad + i;
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += sp[s * slab_stride];
+    a *= scale;
+    const float wv = row[i * taps + t];
+    g[i * taps + t] = a;
+    dot += a * wv;
+    ss += wv * wv;
+  }
+  dot = block_sum(dot, red);
+  ss = block_sum(ss, red);
+  const float rn = sqrtf(ss);
+  const float sqn = sqrtf((float)n);
+  const float d = NORM_EPS + rn / sqn;
+  const float c0 = 1.0f / (d * sqn);
+  const float c1 = rn > 0.f ? dot / (d * rn * sqn) : 0.f;
+  __syncthreads();
+  float* out = grad + (long)mo * n;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    float v = c0 * (g[e] - row[e] * c1);
+    out[e] = accumulate ? out[e] + v : v;
+  }
+}
+
+}  // namespace
+
+// w [O, I, taps] fp32 master (taps = k*k, OIHW flattened).  Any of wp_fwd / wp_dgrad / w_hat may be null.
+//   wp_fwd   bf16 [taps, O, Ipad]   (ci >= I zero-filled)      -> edm_conv_igemm forward
+//   wp_dgrad bf16 [taps, I, O]      (taps flipped)             -> edm_conv_igemm as dgrad
+//   w_hat    fp32 [O, I*taps]       (master order, unpermuted) -> fp32 linears / gates / conv_out
+// perm (device int32 [O], nullable): packed row r reads master row perm[r].
+extern "C" int edm_weight_prep(float* w, int O, int I, int taps, int Ipad, void* wp_fwd, void* wp_dgrad,
+                               float* w_hat, const int* perm, int normalize_inplace, hipStream_t st) {
+  EDM_REQUIRE(w && O > 0 && I > 0 && taps > 0 && Ipad >= I, "weight_prep: bad args O=%d I=%d taps=%d Ipad=%d", O, I, taps, Ipad);
+  hipLaunchKernelGGL(k_weight_prep, dim3(O), dim3(256), 0, st, w, O, I, taps, Ipad, (bf16*)wp_fwd, (bf16*)wp_dgrad,
+                     w_hat, perm, normalize_inplace);
+  EDM_CHECK_LAUNCH("weight_prep");
+  return EDM_OK;
+}
+
+// slabs fp32 [S, taps, O, Ipad] (packed row order) -> grad fp32 [O, I, taps] (master order).
+extern "C" int edm_wgrad_finish(const float* slabs, int S, const float* w, float* grad, const int* perm, int O, int I,
+                                int Ipad, int taps, float scale, int accumulate, hipStream_t st) {
+  EDM_REQUIRE(slabs && w && grad && S > 0 && O > 0 && I > 0 && taps > 0 && Ipad >= I, "wgrad_finish: bad args");
+  EDM_REQUIRE((long)I * taps * 4 <= 64 * 1024, "wgrad_finish: fan_in %d too large for the LDS row buffer", I * taps);
+  hipLaunchKernelGGL(k_wgrad_finish, dim3(O), dim3(256), (size_t)I * taps * sizeof(float), st, slabs, S, w, grad, perm,
+                     O, I, Ipad, taps, scale, accumulate);
+  EDM_CHECK_LAUNCH("wgrad_finish");
+  return EDM_OK;
+}

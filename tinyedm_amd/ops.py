@@ -1,0 +1,324 @@
+"""Tensor-level wrappers around the C-ABI kernels: validate shapes/dtypes on the host (a kernel
+that faults can take the whole GPU node down), then pass raw pointers + the current stream.
+
+Layout conventions: activations are NHWC bf16 tensors of shape (B, H, W, C) (contiguous);
+"rows" means B*H*W.  Per-(sample,channel) quantities are fp32 (B, C).
+"""
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+bf16, f32 = torch.bfloat16, torch.float32
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(t: torch.Tensor, dtype, name: str, shape=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a CUDA/HIP tensor -- tinyedm_amd has no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+def _nhwc(t, name):
+    _chk(t, bf16, name)
+    if t.dim() != 4:
+        raise ValueError(f"{name}: expected (B,H,W,C)")
+    return t.shape
+
+
+# ------------------------------------------------------------------ elementwise
+def pixelnorm_silu_fwd(x):
+    B, H, W, C = _nhwc(x, "x")
+    xn, a = torch.empty_like(x), torch.empty_like(x)
+    d = torch.empty(B * H * W, device=x.device, dtype=f32)
+    _lib.call("edm_pixelnorm_silu_fwd", _p(x), _p(xn), _p(a), _p(d), B * H * W, C, _stream())
+    return xn, a, d
+
+
+def pixelnorm_silu_bwd(xn, d, gxn, gxn_scale, ga):
+    B, H, W, C = _nhwc(xn, "xn")
+    _chk(d, f32, "d", (B * H * W,))
+    if gxn is not None:
+        _chk(gxn, bf16, "gxn", xn.shape)
+    if ga is not None:
+        _chk(ga, bf16, "ga", xn.shape)
+    gx = torch.empty_like(xn)
+    _lib.call("edm_pixelnorm_silu_bwd", _p(xn), _p(d), _p(gxn), float(gxn_scale), _p(ga), _p(gx), B * H * W, C, _stream())
+    return gx
+
+
+def silu_fwd(x):
+    _chk(x, bf16, "x")
+    a = torch.empty_like(x)
+    _lib.call("edm_silu_fwd", _p(x), _p(a), x.numel(), _stream())
+    return a
+
+
+def silu_bwd(x, ga, gextra=None, extra_scale=1.0):
+    _chk(x, bf16, "x")
+    _chk(ga, bf16, "ga", x.shape)
+    if gextra is not None:
+        _chk(gextra, bf16, "gextra", x.shape)
+    gx = torch.empty_like(x)
+    _lib.call("edm_silu_bwd", _p(x), _p(ga), _p(gextra), float(extra_scale), _p(gx), x.numel(), _stream())
+    return gx
+
+
+def axpby(a, alpha, b=None, beta=0.0):
+    _chk(a, bf16, "a")
+    if b is not None:
+        _chk(b, bf16, "b", a.shape)
+    out = torch.empty_like(a)
+    _lib.call("edm_axpby", _p(a), float(alpha), _p(b), float(beta), _p(out), a.numel(), _stream())
+    return out
+
+
+def mod_silu_drop_fwd(r, lin, gain, pdrop, seed, sub, step):
+    B, H, W, C = _nhwc(r, "r")
+    _chk(lin, f32, "lin", (B, C))
+    _chk(gain, f32, "gain")
+    a = torch.empty_like(r)
+    _lib.call("edm_mod_silu_drop_fwd", _p(r), _p(lin), _p(gain), _p(a), B, H * W, C, float(pdrop), int(seed), int(sub),
+              int(step), _stream())
+    return a
+
+
+def mod_silu_drop_bwd(r, lin, gain, ga, pdrop, seed, sub, step):
+    B, H, W, C = _nhwc(r, "r")
+    _chk(lin, f32, "lin", (B, C))
+    _chk(ga, bf16, "ga", r.shape)
+    gr = torch.empty_like(r)
+    gm = torch.zeros(B, C, device=r.device, dtype=f32)
+    glin = torch.empty(B, C, device=r.device, dtype=f32)
+    ggain = torch.zeros((), device=r.device, dtype=f32)
+    _lib.call("edm_mod_silu_drop_bwd", _p(r), _p(lin), _p(gain), _p(ga), _p(gr), _p(gm), _p(glin), _p(ggain), B, H * W, C,
+              float(pdrop), int(seed), int(sub), int(step), _stream())
+    return gr, glin, ggain
+
+
+def dropout_mask(n, pdrop, seed, sub, step, device):
+    m = torch.empty(n, device=device, dtype=torch.uint8)
+    _lib.call("edm_dropout_mask", _p(m), n, float(pdrop), int(seed), int(sub), int(step), _stream())
+    return m
+
+
+def pool2(x, scale=0.25):
+    B, H, W, C = _nhwc(x, "x")
+    if H % 2 or W % 2:
+        raise ValueError("pool2: H and W must be even")
+    y = torch.empty(B, H // 2, W // 2, C, device=x.device, dtype=bf16)
+    _lib.call("edm_pool2", _p(x), _p(y), B, H // 2, W // 2, C, float(scale), _stream())
+    return y
+
+
+def up2(x, scale=1.0):
+    B, H, W, C = _nhwc(x, "x")
+    y = torch.empty(B, 2 * H, 2 * W, C, device=x.device, dtype=bf16)
+    _lib.call("edm_up2", _p(x), _p(y), B, 2 * H, 2 * W, C, float(scale), _stream())
+    return y
+
+
+def reduce_hw(x, C=None, c_off=0, y=None, scale=1.0):
+    """out[b,c] = scale * sum_hw x[b,hw,c_off+c] (* y[b,hw,c])."""
+    B, H, W, Cx = _nhwc(x, "x")
+    C = Cx - c_off if C is None else C
+    if c_off % 8 or c_off + C > Cx:
+        raise ValueError("reduce_hw: bad channel slice")
+    out = torch.zeros(B, C, device=x.device, dtype=f32)
+    ys = 0
+    if y is not None:
+        By, Hy, Wy, Cy = _nhwc(y, "y")
+        if (By, Hy, Wy) != (B, H, W) or Cy < C:
+            raise ValueError("reduce_hw: y shape mismatch")
+        ys = Cy
+    xp = ctypes.c_void_p(x.data_ptr() + 2 * c_off)
+    _lib.call("edm_reduce_hw", xp, Cx, _p(y), ys, _p(out), B, H * W, C, float(scale), _stream())
+    return out
+
+
+def scalelong_fwd(mean, w1h, w2h):
+    B, C = mean.shape
+    R = w1h.shape[0]
+    _chk(mean, f32, "mean")
+    _chk(w1h, f32, "w1h", (R, C + 1))
+    _chk(w2h, f32, "w2h", (C, R))
+    gate = torch.empty(B, C, device=mean.device, dtype=f32)
+    z1 = torch.empty(B, R, device=mean.device, dtype=f32)
+    _lib.call("edm_scalelong_fwd", _p(mean), _p(w1h), _p(w2h), _p(gate), _p(z1), B, C, R, _stream())
+    return gate, z1
+
+
+def scalelong_bwd(mean, w1h, w2h, gate, z1, ggate):
+    B, C = mean.shape
+    R = w1h.shape[0]
+    _chk(ggate, f32, "ggate", (B, C))
+    gmean = torch.empty(B, C, device=mean.device, dtype=f32)
+    gw1 = torch.zeros_like(w1h)
+    gw2 = torch.zeros_like(w2h)
+    _lib.call("edm_scalelong_bwd", _p(mean), _p(w1h), _p(w2h), _p(gate), _p(z1), _p(ggate), _p(gmean), _p(gw1), _p(gw2),
+              B, C, R, _stream())
+    return gmean, gw1, gw2
+
+
+def concat_gate_fwd(inp, skip, gate, want_silu):
+    B, H, W, Ci = _nhwc(inp, "inp")
+    Bs, Hs, Ws, Cs = _nhwc(skip, "skip")
+    if (Bs, Hs, Ws) != (B, H, W):
+        raise ValueError("concat_gate_fwd: inp/skip spatial mismatch")
+    _chk(gate, f32, "gate", (B, Cs))
+    cat = torch.empty(B, H, W, Ci + Cs, device=inp.device, dtype=bf16)
+    sil = torch.empty_like(cat) if want_silu else None
+    _lib.call("edm_concat_gate_fwd", _p(inp), _p(skip), _p(gate), _p(cat), _p(sil), B, H * W, Ci, Cs, _stream())
+    return cat, sil
+
+
+def concat_gate_bwd(gcat, gate, gmean, Ci):
+    B, H, W, Ct = _nhwc(gcat, "gcat")
+    Cs = Ct - Ci
+    _chk(gate, f32, "gate", (B, Cs))
+    _chk(gmean, f32, "gmean", (B, Cs))
+    ginp = torch.empty(B, H, W, Ci, device=gcat.device, dtype=bf16)
+    gskip = torch.empty(B, H, W, Cs, device=gcat.device, dtype=bf16)
+    _lib.call("edm_concat_gate_bwd", _p(gcat), _p(gate), _p(gmean), _p(ginp), _p(gskip), B, H * W, Ci, Cs, _stream())
+    return ginp, gskip
+
+
+def _sigma_arg(sigma, B):
+    _chk(sigma, f32, "sigma")
+    if sigma.numel() == 1:
+        return 0
+    if sigma.numel() != B:
+        raise ValueError(f"sigma must have 1 or {B} elements, got {sigma.numel()}")
+    return 1
+
+
+def precond_in(noisy, sigma, sigma_data, CP):
+    _chk(noisy, f32, "noisy")
+    B, Cimg, H, W = noisy.shape
+    ss = _sigma_arg(sigma, B)
+    out = torch.empty(B, H, W, CP, device=noisy.device, dtype=bf16)
+    _lib.call("edm_precond_in", _p(noisy), _p(sigma), ss, float(sigma_data), _p(out), B, Cimg, H * W, CP, _stream())
+    return out
+
+
+def conv_out_fwd(x, w_hat, gain_out, noisy, sigma, sigma_data, want_fraw=True):
+    B, H, W, C = _nhwc(x, "x")
+    Co = w_hat.shape[0]
+    _chk(w_hat, f32, "w_hat", (Co, C))
+    _chk(noisy, f32, "noisy", (B, Co, H, W))
+    _chk(gain_out, f32, "gain_out")
+    ss = _sigma_arg(sigma, B)
+    D = torch.empty(B, Co, H, W, device=x.device, dtype=f32)
+    Fraw = torch.empty(B, Co, H, W, device=x.device, dtype=f32) if want_fraw else None
+    _lib.call("edm_conv_out_fwd", _p(x), _p(w_hat), _p(gain_out), _p(noisy), _p(sigma), ss, float(sigma_data), _p(D),
+              _p(Fraw), B, H * W, C, Co, _stream())
+    return D, Fraw
+
+
+def conv_out_bwd(x, w_hat, gain_out, Fraw, dD, sigma, sigma_data):
+    B, H, W, C = _nhwc(x, "x")
+    Co = w_hat.shape[0]
+    _chk(dD, f32, "dD", (B, Co, H, W))
+    _chk(Fraw, f32, "Fraw", (B, Co, H, W))
+    ss = _sigma_arg(sigma, B)
+    gx = torch.empty_like(x)
+    gw = torch.zeros_like(w_hat)
+    gg = torch.zeros((), device=x.device, dtype=f32)
+    _lib.call("edm_conv_out_bwd", _p(x), _p(w_hat), _p(gain_out), _p(Fraw), _p(dD), _p(sigma), ss, float(sigma_data),
+              _p(gx), _p(gw), _p(gg), B, H * W, C, Co, _stream())
+    return gx, gw, gg
+
+
+def nchw_to_nhwc_bf16(x):
+    _chk(x, f32, "x")
+    B, C, H, W = x.shape
+    y = torch.empty(B, H, W, C, device=x.device, dtype=bf16)
+    _lib.call("edm_nchw_to_nhwc_bf16", _p(x), _p(y), B, C, H * W, _stream())
+    return y
+
+
+def nhwc_bf16_to_nchw(x):
+    B, H, W, C = _nhwc(x, "x")
+    y = torch.empty(B, C, H, W, device=x.device, dtype=f32)
+    _lib.call("edm_nhwc_bf16_to_nchw", _p(x), _p(y), B, C, H * W, _stream())
+    return y
+
+
+# ------------------------------------------------------------------ convolution
+def conv_igemm(x, wp, taps, residual=None, alpha=1.0, beta=0.0):
+    """Y = alpha*conv(x, wp) + beta*residual.  wp: bf16 (taps, Cout, Cin)."""
+    B, H, W, Cin = _nhwc(x, "x")
+    _chk(wp, bf16, "wp")
+    if wp.dim() != 3 or wp.shape[0] != taps or wp.shape[2] != Cin:
+        raise ValueError(f"conv_igemm: packed weight {tuple(wp.shape)} does not match taps={taps}, Cin={Cin}")
+    Cout = wp.shape[1]
+    if residual is not None:
+        _chk(residual, bf16, "residual", (B, H, W, Cout))
+    y = torch.empty(B, H, W, Cout, device=x.device, dtype=bf16)
+    _lib.call("edm_conv_igemm", _p(x), _p(wp), _p(y), _p(residual), float(alpha), float(beta), B, H, W, Cin, Cout, taps,
+              _stream())
+    return y
+
+
+def conv_wgrad(x, dy, taps):
+    """fp32 split-K slabs (S, taps, Cout, Cin) of dW in packed order."""
+    B, H, W, Cin = _nhwc(x, "x")
+    Bd, Hd, Wd, Cout = _nhwc(dy, "dy")
+    if (Bd, Hd, Wd) != (B, H, W):
+        raise ValueError("conv_wgrad: x/dy spatial mismatch")
+    S = _lib.call("edm_conv_wgrad_nsplit", B, H, W, Cin, Cout, taps)
+    slabs = torch.empty(S, taps, Cout, Cin, device=x.device, dtype=f32)
+    _lib.call("edm_conv_wgrad", _p(x), _p(dy), _p(slabs), B, H, W, Cin, Cout, taps, S, _stream())
+    return slabs
+
+
+# ------------------------------------------------------------------ weights
+def weight_prep(w, taps, Ipad=None, want_fwd=True, want_dgrad=True, want_hat=False, perm=None, normalize_inplace=False):
+    """w: fp32 master (O, I, k, k) or (O, I).  Returns (wp_fwd, wp_dgrad, w_hat)."""
+    _chk(w, f32, "w")
+    O = w.shape[0]
+    I = w.shape[1]
+    if w.numel() != O * I * taps:
+        raise ValueError("weight_prep: taps does not match the weight shape")
+    Ipad = I if Ipad is None else Ipad
+    dev = w.device
+    wf = torch.empty(taps, O, Ipad, device=dev, dtype=bf16) if want_fwd else None
+    wd = torch.empty(taps, I, O, device=dev, dtype=bf16) if want_dgrad else None
+    wh = torch.empty(O, I * taps, device=dev, dtype=f32) if want_hat else None
+    if perm is not None:
+        _chk(perm, torch.int32, "perm", (O,))
+    _lib.call("edm_weight_prep", _p(w), O, I, taps, Ipad, _p(wf), _p(wd), _p(wh), _p(perm), int(normalize_inplace),
+              _stream())
+    return wf, wd, wh
+
+
+def wgrad_finish(slabs, w, taps, I, perm=None, scale=1.0, out=None):
+    """Reduce slabs (S, taps, O, Ipad) and project through the weight normalisation -> grad like w."""
+    _chk(slabs, f32, "slabs")
+    _chk(w, f32, "w")
+    S, t_, O, Ipad = slabs.shape
+    if t_ != taps or w.shape[0] != O or w.numel() != O * I * taps:
+        raise ValueError("wgrad_finish: shape mismatch")
+    accumulate = out is not None
+    if out is None:
+        out = torch.empty_like(w)
+    else:
+        _chk(out, f32, "out", w.shape)
+    _lib.call("edm_wgrad_finish", _p(slabs), S, _p(w), _p(out), _p(perm), O, I, Ipad, taps, float(scale), int(accumulate),
+              _stream())
+    return out
