@@ -1,0 +1,227 @@
+"""Headline benchmark: CIFAR-10 32x32 EDM2 U-Net (35.6 M params) bf16 training images/sec on N MI355X,
+plus 32-step Heun sampler images/sec, roofline of the dominant kernel and a CPU baseline.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = Diffuser -> Embedding -> Denoiser fwd -> sigma-weighted MSE -> backward -> bucketed gradient
+all-reduce over RCCL (overlapped with backward) -> fused Adam+EMA, on a synthetic device-resident batch
+(x = 0.5*randn(B,3,32,32), seed 42; conf/cifar10.yaml model, dropout 0.13, EMA 0.13, lr 0.02).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# work per unit, CIFAR-10 config (SURVEY.md 8(d) / BASELINE.md 3)
+TRAIN_GFLOP_PER_IMG = 81.0
+FWD_GFLOP_PER_IMG = 27.0
+MFMA_PEAK_TFLOPS = 2500.0      # bf16 dense, MI355X_MICROARCH.md chip table
+HBM_PEAK_GBS = 8000.0
+
+
+def build_model(device, conditional=False):
+    import tinyedm
+    from tinyedm.config import compose, instantiate
+    cfg = compose("cifar10_cond" if conditional else "cifar10", os.path.join(ROOT, "experiments", "conf"))
+    tinyedm.manual_seed(cfg.seed)
+    torch.manual_seed(cfg.seed)
+    model = instantiate(cfg.model).to(device)
+    return model, cfg
+
+
+def train_bench(args, rank, world, device):
+    import tinyedm
+    from tinyedm_amd import ops
+    from tinyedm_amd.ddp import GradReducer
+    from tinyedm_amd.ema import EMAOptimizer
+
+    model, cfg = build_model(device, args.conditional)
+    model.train()
+    opt_cfg = model.configure_optimizers()
+    base = opt_cfg["optimizer"]
+    gamma = tinyedm.sigma_rel_to_gamma(model.ema_length)
+    opt = EMAOptimizer(base, device=device, gamma=gamma, every_n_steps=model.every_n_steps)
+    reducer = GradReducer(base.arena)
+    reducer.broadcast_parameters()
+    B = args.batch
+    g = torch.Generator().manual_seed(42 + rank)
+    x = (0.5 * torch.randn(B, 3, 32, 32, generator=g)).to(device)
+    y = torch.randint(0, 10, (B,), generator=g).to(device)
+    batch = (x, y)
+
+    def step(i):
+        loss = model.training_step(batch, i)
+        loss.backward()
+        base.grad_scale = reducer.finish()
+        opt.step()
+        opt.zero_grad()
+        return loss
+
+    opt.zero_grad()
+    for i in range(args.warmup):
+        loss = step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    final_loss = float(loss)
+
+    # ---- roofline of the dominant kernel (3x3 implicit-GEMM conv): one extra, instrumented step AFTER the
+    # timed region: HIP events around every launch on the launch stream; algorithmic FLOPs from the shapes.
+    roof = None
+    if rank == 0:
+        ops.PROFILE = {}
+        step(args.warmup + args.steps)
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        roof = {}
+        for name, recs in prof.items():
+            ms = sum(s.elapsed_time(e) for s, e, _, _ in recs)
+            roof[name] = {"launches": len(recs), "ms": ms, "gflop": sum(f for _, _, f, _ in recs) / 1e9,
+                          "gbytes": sum(b for _, _, _, b in recs) / 1e9}
+    return model, B * world * args.steps / dt, dt / args.steps * 1e3, final_loss, roof
+
+
+def sampler_bench(args, model, device):
+    import tinyedm
+    model.eval()
+    solver = tinyedm.DeterministicSolver(num_steps=32)
+    B = args.sampler_batch
+    g = torch.Generator().manual_seed(7)
+    x0 = torch.randn(B, 3, 32, 32, generator=g).to(device)
+    solver.solve(model, x0, None, graph=True)          # capture + first replay
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.sampler_iters):
+        solver.solve(model, x0, None, graph=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.sampler_iters
+    return {"img_per_s": B / dt, "batch": B, "heun_steps": 32, "nfe": 63, "ms_per_solve": dt * 1e3,
+            "hipgraph": True, "state_dtype": "f32", "network_dtype": "bf16"}
+
+
+def cpu_baseline(args):
+    """Reference algorithm on the host cores: the CPU oracle's training step (fp32, plain torch CPU ops),
+    bounded to ~10-30 s of CPU work."""
+    from oracle import edm_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ecfg, dcfg = O.cifar10_cfg()
+    P = O.init_params(ecfg, dcfg, torch.Generator().manual_seed(1), gains_nonzero=True)
+    keys = O.trainable_keys(P)
+    for k in keys:
+        P[k].requires_grad_(True)
+    B = args.cpu_batch
+    g = torch.Generator().manual_seed(42)
+    clean = 0.5 * torch.randn(B, 3, 32, 32, generator=g)
+    m = {k: torch.zeros_like(P[k]) for k in keys}
+    v = {k: torch.zeros_like(P[k]) for k in keys}
+    ema = {k: P[k].detach().clone() for k in keys}
+    times = []
+    budget_t0 = time.perf_counter()
+    for it in range(1 + args.cpu_steps):
+        t0 = time.perf_counter()
+        eps, noise = torch.randn(B, generator=g), torch.randn(B, 3, 32, 32, generator=g)
+        loss = O.training_loss(P, ecfg, dcfg, clean, eps, noise, -1.2, 1.2)
+        grads = torch.autograd.grad(loss, [P[k] for k in keys])
+        with torch.no_grad():
+            for k, gr in zip(keys, grads):
+                O.adam_step(P[k], gr, m[k], v[k], it + 1, 0.02)
+                O.ema_step(ema[k], P[k], O.ema_beta(it, 4.6036))
+        if it > 0:
+            times.append(time.perf_counter() - t0)
+        if time.perf_counter() - budget_t0 > 40 and times:
+            break
+    sec = sum(times) / len(times)
+    return {"value": B / sec, "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} fp32 training steps of the CPU oracle (oracle/edm_oracle.py), batch {B}, "
+                      f"same CIFAR-10 model, dropout off, {sec:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (BASELINE.json configs[1]: 128)")
+    ap.add_argument("--conditional", action="store_true")
+    ap.add_argument("--sampler-batch", type=int, default=256)
+    ap.add_argument("--sampler-iters", type=int, default=2)
+    ap.add_argument("--no-sampler", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    model, ips, ms, final_loss, roof = train_bench(args, rank, world, device)
+    out = None
+    if rank == 0:
+        conv = roof.get("conv3x3_igemm", {"launches": 0, "ms": 0.0, "gflop": 0.0, "gbytes": 0.0})
+        achieved = conv["gflop"] / conv["ms"] if conv["ms"] > 0 else 0.0          # GFLOP/ms == TFLOP/s
+        out = {
+            "metric": "train imgs/sec CIFAR-10 32x32 bf16",
+            "value": round(ips, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "CIFAR-10 32x32 unconditional EDM2 U-Net (conf/cifar10.yaml, 35.6M params) "
+                                   "full training step: diffuse+embed+denoiser fwd/bwd+loss+grad all-reduce+Adam+EMA",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}", "conditional": bool(args.conditional), "final_loss": final_loss},
+            "roofline": {
+                "bound": "mfma", "kernel": "k_conv_igemm<9,...> (3x3 conv fwd + dgrad)",
+                "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": conv["launches"],
+                "avg_launch_ms": round(conv["ms"] / max(1, conv["launches"]), 4),
+                "algorithmic_gflop_per_step": round(conv["gflop"], 1),
+                "whole_step_mfma_frac": round(ips / world * TRAIN_GFLOP_PER_IMG / 1e3 / MFMA_PEAK_TFLOPS, 4),
+                "whole_step_hbm_frac": round(ips / world * 108.6e6 / 1e9 / HBM_PEAK_GBS, 4),
+                "per_kernel": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in roof.items()},
+            },
+        }
+        if not args.no_sampler:
+            out["sampler"] = sampler_bench(args, model, device)
+            out["sampler"]["mfma_frac"] = round(out["sampler"]["img_per_s"] * 63 * FWD_GFLOP_PER_IMG / 1e3 / MFMA_PEAK_TFLOPS, 4)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,130 @@
+/* tinyedm_hip.h -- C ABI of libtinyedm_hip.so, the MI355X (gfx950) kernels behind the tinyedm hot path.
+ *
+ * The reference (YichengDWu/tinyedm) has no native code: every entry point below replaces an ATen op
+ * call site of its Python hot path (cited as file:line relative to /root/reference/src/tinyedm) or the
+ * autograd backward of one.  Conventions:
+ *   - plain pointers + sizes only; every pointer is DEVICE memory owned by the caller; no allocation,
+ *     no host sync; work is enqueued on `stream` (graph-capturable).
+ *   - activations: NHWC bf16, i.e. a row-major [pixels = B*H*W][channels] matrix of 16-bit brain floats.
+ *   - per-(sample,channel) / parameter-side quantities: fp32.
+ *   - return 0 on success, <0 on error (edm_last_error() holds the message, thread-local).
+ */
+#ifndef TINYEDM_HIP_H
+#define TINYEDM_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* edm_stream_t; /* hipStream_t */
+
+int edm_version(void);
+const char* edm_last_error(void);
+
+/* ---------------------------------------------------------------- convolution (networks.py:35-37: F.conv2d) */
+/* Y[p,co] = alpha * sum_{tap,ci} X[p+off(tap),ci] * Wp[tap,co,ci] + beta * R[p,co].  taps in {1,9}; "same" padding.
+ * Forward conv with the forward pack; input-gradient (dgrad) with the flipped/transposed pack.  R may be NULL. */
+int edm_conv_igemm(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
+                   int W, int Cin, int Cout, int taps, edm_stream_t stream);
+/* weight gradient: slabs[s,tap,co,ci] (fp32, nsplit = edm_conv_wgrad_nsplit(...)) partial sums over pixels. */
+int edm_conv_wgrad_nsplit(int B, int H, int W, int Cin, int Cout, int taps);
+int edm_conv_wgrad(const void* X, const void* dY, float* slabs, int B, int H, int W, int Cin, int Cout, int taps,
+                   int nsplit, edm_stream_t stream);
+
+/* ---------------------------------------------------------------- weights (networks.py:17-19, 32-36, 55-59) */
+/* forced weight normalisation (in place when normalize_inplace) + effective weight w/(eps+|w|/sqrt(n))/sqrt(n),
+ * written as bf16 forward pack [taps,O,Ipad], bf16 dgrad pack [taps,I,O] (taps flipped) and/or fp32 [O,I*taps]. */
+int edm_weight_prep(float* w, int O, int I, int taps, int Ipad, void* wp_fwd, void* wp_dgrad, float* w_hat,
+                    const int* perm, int normalize_inplace, edm_stream_t stream);
+/* reduce split-K slabs and project through the normalisation -> gradient of the fp32 master weight [O,I,taps]. */
+int edm_wgrad_finish(const float* slabs, int S, const float* w, float* grad, const int* perm, int O, int I, int Ipad,
+                     int taps, float scale, int accumulate, edm_stream_t stream);
+
+/* ---------------------------------------------------------------- attention (networks.py:194-202) */
+/* qkv [B*N,3C] channel order [head][q|k|v][d]; q,k,v pixel-normalised over d; softmax(qk^T/sqrt(d)) v. d = 64, N<=256 */
+int edm_attention_fwd(const void* qkv, void* y, int B, int N, int C, int heads, edm_stream_t stream);
+int edm_attention_bwd(const void* qkv, const void* y, const void* gy, void* gqkv, int B, int N, int C, int heads,
+                      edm_stream_t stream);
+
+/* ---------------------------------------------------------------- per-pixel / elementwise */
+/* pixel_norm over C + mp_silu (networks.py:9-14, 83-84, 249-252); dsave[p] = eps + |x_p|/sqrt(C) */
+int edm_pixelnorm_silu_fwd(const void* x, void* xn, void* a, float* dsave, long P, int C, edm_stream_t stream);
+int edm_pixelnorm_silu_bwd(const void* xn, const float* dsave, const void* gxn, float gxn_scale, const void* ga,
+                           void* gx, long P, int C, edm_stream_t stream);
+/* mp_silu (networks.py:316) and its backward: gx = mp_silu'(x)*ga + extra_scale*gextra */
+int edm_silu_fwd(const void* x, void* a, long n, edm_stream_t stream);
+int edm_silu_bwd(const void* x, const void* ga, const void* gextra, float extra_scale, void* gx, long n,
+                 edm_stream_t stream);
+/* out = alpha*a + beta*b (mp_add, networks.py:87-88) */
+int edm_axpby(const void* a, float alpha, const void* b, float beta, void* out, long n, edm_stream_t stream);
+/* a = dropout(mp_silu(r * (lin*gain + 1)))  (networks.py:255-260 / 319-324); Philox mask from (seed, sub, step) */
+int edm_mod_silu_drop_fwd(const void* r, const float* lin, const float* gain, void* a, int B, int HW, int C,
+                          float pdrop, unsigned long long seed, unsigned sub, unsigned step, edm_stream_t stream);
+int edm_mod_silu_drop_bwd(const void* r, const float* lin, const float* gain, const void* ga, void* gr, float* gm,
+                          float* glin, float* ggain, int B, int HW, int C, float pdrop, unsigned long long seed,
+                          unsigned sub, unsigned step, edm_stream_t stream);
+int edm_dropout_mask(unsigned char* mask, long n, float pdrop, unsigned long long seed, unsigned sub, unsigned step,
+                     edm_stream_t stream);
+/* 2x2 average pool / nearest-exact x2 (networks.py:80, 72); H,W = OUTPUT dims; scale folds the backward factors */
+int edm_pool2(const void* x, void* y, int B, int Hout, int Wout, int C, float scale, edm_stream_t stream);
+int edm_up2(const void* x, void* y, int B, int Hout, int Wout, int C, float scale, edm_stream_t stream);
+/* out[b,c] += scale * sum_hw x[b,hw,c] (* y[b,hw,c])  -- ScaleLong mean (networks.py:116) and its gate gradient */
+int edm_reduce_hw(const void* x, long x_stride, const void* y, long y_stride, float* out, int B, int HW, int C,
+                  float scale, edm_stream_t stream);
+/* ScaleLong gate MLP (networks.py:112-118), fp32, per sample */
+int edm_scalelong_fwd(const float* mean, const float* W1h, const float* W2h, float* gate, float* z1save, int B, int C,
+                      int R, edm_stream_t stream);
+int edm_scalelong_bwd(const float* mean, const float* W1h, const float* W2h, const float* gate, const float* z1save,
+                      const float* ggate, float* gmean, float* gW1h, float* gW2h, int B, int C, int R,
+                      edm_stream_t stream);
+/* cat = [inp, skip*gate] (networks.py:311) and backward */
+int edm_concat_gate_fwd(const void* inp, const void* skip, const float* gate, void* cat, void* silu_out, int B, int HW,
+                        int Ci, int Cs, edm_stream_t stream);
+int edm_concat_gate_bwd(const void* gcat, const float* gate, const float* gmean, void* ginp, void* gskip, int B,
+                        int HW, int Ci, int Cs, edm_stream_t stream);
+
+/* ---------------------------------------------------------------- EDM preconditioning (networks.py:578-587, 602-603) */
+/* out[b,h,w,:] = [c_in(b)*noisy[b,:,h,w], 1, 0...] (bf16, CP channels); sigma_stride 0 = one scalar sigma */
+int edm_precond_in(const float* noisy, const float* sigma, int sigma_stride, float sigma_data, void* out, int B,
+                   int Cimg, int HW, int CP, edm_stream_t stream);
+/* D = conv_out(x)*gain_out*c_out + noisy*c_skip (fp32 NCHW); Fraw = conv_out(x) saved for the backward */
+int edm_conv_out_fwd(const void* x, const float* w_hat, const float* gain_out, const float* noisy, const float* sigma,
+                     int sigma_stride, float sigma_data, float* D, float* Fraw, int B, int HW, int C, int Co,
+                     edm_stream_t stream);
+int edm_conv_out_bwd(const void* x, const float* w_hat, const float* gain_out, const float* Fraw, const float* dD,
+                     const float* sigma, int sigma_stride, float sigma_data, void* gx, float* gw_hat, float* ggain,
+                     int B, int HW, int C, int Co, edm_stream_t stream);
+int edm_nchw_to_nhwc_bf16(const float* x, void* y, int B, int C, int HW, edm_stream_t stream);
+int edm_nhwc_bf16_to_nchw(const void* x, float* y, int B, int C, int HW, edm_stream_t stream);
+
+/* ---------------------------------------------------------------- fp32 linears + embedding (networks.py:58-60, 121-178) */
+int edm_linear_fwd(const float* X, const float* W, float* Y, int M, int N, int K, edm_stream_t stream);
+int edm_linear_dgrad(const float* dY, const float* W, float* dX, int M, int N, int K, int accumulate,
+                     edm_stream_t stream);
+int edm_linear_wgrad(const float* dY, const float* X, float* dW, int M, int N, int K, int accumulate,
+                     edm_stream_t stream);
+int edm_fourier_fwd(const float* sigma, int sigma_stride, const float* freqs, const float* phases, float* out, int B,
+                    int Fd, edm_stream_t stream);
+int edm_embed_combine_fwd(const float* emb_sigma, const float* wcls_hat, const long long* labels, float add_factor,
+                          int K, float* pre, float* out, int B, int E, edm_stream_t stream);
+int edm_embed_combine_bwd(const float* gout, const float* pre, const long long* labels, float add_factor, int K,
+                          float* gemb_sigma, float* gwcls_hat, int B, int E, edm_stream_t stream);
+
+/* ---------------------------------------------------------------- step level (edm.py:84-93, 212; metric.py:8-18; edm.py:251; ema.py:137-140; solvers.py:49-57) */
+int edm_diffuse(const float* clean, float* noisy, float* sigma, float P_mean, float P_std, int B, long CHW,
+                unsigned long long seed, unsigned step, edm_stream_t stream);
+int edm_diffuse_given(const float* clean, const float* eps, const float* noise, float* noisy, float* sigma,
+                      float P_mean, float P_std, int B, long CHW, edm_stream_t stream);
+int edm_weighted_mse(const float* D, const float* clean, const float* sigma, const float* weight_override,
+                     float sigma_data, float* loss, float* dD, int B, long CHW, edm_stream_t stream);
+int edm_adam_ema(float* theta, const float* grad, float* m, float* v, float* ema, long n, float lr, float b1,
+                 float b2, float eps, int step, float ema_beta, float grad_scale, edm_stream_t stream);
+int edm_heun_euler(const float* x, const float* D, float t0, float t1, float* dx, float* x1, long n,
+                   edm_stream_t stream);
+int edm_heun_correct(const float* x, const float* dx, const float* x1, const float* D1, float t0, float t1, float* out,
+                     long n, edm_stream_t stream);
+int edm_scale_f32(const float* x, float s, float* y, long n, edm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TINYEDM_HIP_H */

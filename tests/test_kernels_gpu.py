@@ -272,3 +272,131 @@ def test_precond_and_conv_out(ops):
     D0, _ = ops.conv_out_fwd(nhwc(x), whd, gain.to(DEV), noisy.to(DEV), s0.to(DEV), 0.5, want_fraw=False)
     cs0, co0, _ = O.precond_scalars(s0, 0.5)
     assert rel(D0.cpu(), (F.conv2d(x, what.detach()) * gain * co0 + noisy * cs0)) < 1e-5
+
+
+def _qkv_perm(C, heads):
+    """packed channel (head, which, dd) -> reference channel head*3d + dd*3 + which (networks.py:194)."""
+    d = C // heads
+    idx = torch.empty(3 * C, dtype=torch.long)
+    for h in range(heads):
+        for w in range(3):
+            for dd in range(d):
+                idx[h * 3 * d + w * d + dd] = h * 3 * d + dd * 3 + w
+    return idx
+
+
+@pytest.mark.parametrize("B,H,W,heads", [(2, 16, 16, 4), (3, 8, 8, 2), (2, 4, 4, 1), (1, 14, 14, 2), (2, 7, 7, 1)])
+def test_attention_fwd_bwd(ops, B, H, W, heads):
+    g = torch.Generator().manual_seed(B + H + heads)
+    C = 64 * heads
+    N = H * W
+    qkv_ref_layout = q(torch.randn(B, 3 * C, H, W, generator=g))          # reference channel order
+    gy = q(torch.randn(B, C, H, W, generator=g))
+    x = qkv_ref_layout.clone().requires_grad_(True)
+    t = x.view(B, heads, 64, 3, N)
+    t = O.q_bf16(O.rms_div(t, [2]))
+    qq, kk, vv = t.unbind(3)
+    s = torch.einsum("bhdi,bhdj->bhij", qq, kk) / 8.0
+    p = O.q_bf16(torch.softmax(s, dim=-1))
+    y_ref = torch.einsum("bhij,bhdj->bhdi", p, vv).reshape(B, C, H, W)
+    y_ref.backward(gy)
+    perm = _qkv_perm(C, heads)
+    qkv_packed = nhwc(qkv_ref_layout[:, perm])
+    y = ops.attention_fwd(qkv_packed, heads)
+    close_bf16(nchw(y), y_ref.detach(), l2=6e-3, mx=3e-2)
+    gqkv = ops.attention_bwd(qkv_packed, y, nhwc(gy), heads)
+    close_bf16(nchw(gqkv), x.grad[:, perm], l2=1.5e-2, mx=6e-2)
+
+
+def test_linear_and_embedding(ops):
+    g = torch.Generator().manual_seed(12)
+    B, Fd, E, K = 5, 64, 256, 10
+    X, Wt = torch.randn(B, Fd, generator=g), torch.randn(E, Fd, generator=g)
+    dY = torch.randn(B, E, generator=g)
+    assert rel(ops.linear_fwd(X.to(DEV), Wt.to(DEV)).cpu(), X @ Wt.t()) < 1e-5
+    assert rel(ops.linear_dgrad(dY.to(DEV), Wt.to(DEV)).cpu(), dY @ Wt) < 1e-5
+    assert rel(ops.linear_wgrad(dY.to(DEV), X.to(DEV)).cpu(), dY.t() @ X) < 1e-5
+    ecfg = O.EmbeddingCfg(Fd, E, K)
+    P = {"embedding.fourier_embed.freqs": 2 * math.pi * torch.randn(Fd, generator=g),
+         "embedding.fourier_embed.phases": 2 * math.pi * torch.rand(Fd, generator=g),
+         "embedding.sigma_embed.weight": torch.randn(E, Fd, generator=g),
+         "embedding.class_embed.linear.weight": torch.randn(E, K, generator=g)}
+    sigma = torch.randn(B, generator=g).exp()
+    labels = torch.randint(0, K, (B,), generator=g)
+    for k_ in ("embedding.sigma_embed.weight", "embedding.class_embed.linear.weight"):
+        P[k_].requires_grad_(True)
+    four_ref, out_ref = O.embedding_forward(P, ecfg, sigma, labels)
+    gout = torch.randn(B, E, generator=g)
+    out_ref.backward(gout)
+    four = ops.fourier_fwd(sigma.to(DEV), P["embedding.fourier_embed.freqs"].to(DEV),
+                           P["embedding.fourier_embed.phases"].to(DEV), B)
+    assert (four.cpu() - four_ref).abs().max() < 2e-4                    # fp32 cos of a large argument
+    wsh = O.effective_weight(P["embedding.sigma_embed.weight"].detach()).to(DEV)
+    wch = O.effective_weight(P["embedding.class_embed.linear.weight"].detach()).to(DEV)
+    es = ops.linear_fwd(four, wsh)
+    pre, out = ops.embed_combine_fwd(es, wch, labels.to(DEV), 0.5)
+    assert (out.cpu() - out_ref.detach()).abs().max() < 2e-4
+    ges, gwch = ops.embed_combine_bwd(gout.to(DEV), pre, labels.to(DEV), 0.5, wch.shape)
+    gwsh = ops.linear_wgrad(ges, four)
+    gws = ops.wgrad_finish(gwsh.view(1, 1, E, Fd), P["embedding.sigma_embed.weight"].detach().to(DEV), 1, Fd)
+    gwc = ops.wgrad_finish(gwch.view(1, 1, E, K), P["embedding.class_embed.linear.weight"].detach().to(DEV), 1, K)
+    assert rel(gws.cpu(), P["embedding.sigma_embed.weight"].grad) < 2e-3
+    assert rel(gwc.cpu(), P["embedding.class_embed.linear.weight"].grad) < 2e-3
+    # unconditional + scalar sigma
+    _, out_u = O.embedding_forward(P, ecfg, torch.tensor(1.7), None)
+    four_u = ops.fourier_fwd(torch.tensor([1.7], device=DEV), P["embedding.fourier_embed.freqs"].to(DEV),
+                             P["embedding.fourier_embed.phases"].to(DEV), 1)
+    _, o_u = ops.embed_combine_fwd(ops.linear_fwd(four_u, wsh), None, None, 0.5)
+    assert (o_u.cpu() - out_u.detach()).abs().max() < 2e-4
+
+
+def test_step_level_kernels(ops):
+    g = torch.Generator().manual_seed(13)
+    B = 6
+    clean = 0.5 * torch.randn(B, 3, 8, 8, generator=g)
+    eps, noise = torch.randn(B, generator=g), torch.randn(B, 3, 8, 8, generator=g)
+    noisy_ref, sigma_ref = O.diffuse(clean, eps, noise, -1.2, 1.2)
+    noisy, sigma = ops.diffuse_given(clean.to(DEV), eps.to(DEV), noise.to(DEV), -1.2, 1.2)
+    assert torch.allclose(noisy.cpu(), noisy_ref, rtol=1e-5, atol=1e-5) and torch.allclose(sigma.cpu(), sigma_ref, rtol=1e-5)
+    # Philox diffuser: distribution of ln(sigma) and of the unit noise (RNG parity is distributional)
+    big = torch.zeros(4096, 3, 8, 8, device=DEV)
+    nz, sg = ops.diffuse(big, -1.2, 1.2, 42, 3)
+    ls = sg.log()
+    assert abs(ls.mean().item() + 1.2) < 0.08 and abs(ls.std().item() - 1.2) < 0.08
+    unit = nz / sg.view(-1, 1, 1, 1)
+    assert abs(unit.mean().item()) < 0.01 and abs(unit.std().item() - 1) < 0.01
+    nz2, sg2 = ops.diffuse(big, -1.2, 1.2, 42, 3)
+    assert torch.equal(nz, nz2) and torch.equal(sg, sg2)                 # counter-based: replayable
+    nz3, _ = ops.diffuse(big, -1.2, 1.2, 42, 4)
+    assert not torch.equal(nz, nz3)
+    # loss (closed form of the reference's own test) + gradient
+    D = torch.randn(B, 3, 8, 8, generator=g).requires_grad_(True)
+    w = O.loss_weight(sigma_ref, 0.5)
+    ref = torch.mean(w.view(-1, 1, 1, 1) * (D - clean) ** 2)
+    ref.backward()
+    loss, dD = ops.weighted_mse(D.detach().to(DEV), clean.to(DEV), sigma_ref.to(DEV), 0.5)
+    assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    assert rel(dD.cpu(), D.grad) < 1e-5
+    # Adam + EMA against the oracle
+    n = 1003
+    th = torch.randn(n, generator=g)
+    m, v, ema = torch.zeros(n), torch.zeros(n), th.clone()
+    thd, md, vd, ed = th.clone().to(DEV), m.clone().to(DEV), v.clone().to(DEV), ema.clone().to(DEV)
+    gam = O.sigma_rel_to_gamma(0.13)
+    for step in range(1, 6):
+        gr = torch.randn(n, generator=g)
+        O.adam_step(th, gr, m, v, step, 0.02)
+        beta = O.ema_beta(step - 1, gam)
+        O.ema_step(ema, th, beta)
+        ops.adam_ema(thd, gr.to(DEV), md, vd, ed, 0.02, 0.9, 0.999, 1e-8, step, beta)
+        assert torch.allclose(thd.cpu(), th, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(ed.cpu(), ema, rtol=1e-5, atol=1e-6)
+    # Heun updates
+    x, Dn, D1 = torch.randn(4, 3, 8, 8, generator=g), torch.randn(4, 3, 8, 8, generator=g), torch.randn(4, 3, 8, 8, generator=g)
+    t0, t1 = 3.0, 1.7
+    dx_ref = (x - Dn) / t0
+    x1_ref = x + (t1 - t0) * dx_ref
+    dx, x1 = ops.heun_euler(x.to(DEV), Dn.to(DEV), t0, t1)
+    assert torch.allclose(dx.cpu(), dx_ref, atol=1e-6) and torch.allclose(x1.cpu(), x1_ref, atol=1e-6)
+    out = ops.heun_correct(x.to(DEV), dx, x1, D1.to(DEV), t0, t1)
+    assert torch.allclose(out.cpu(), x + (t1 - t0) * (0.5 * dx_ref + 0.5 * (x1_ref - D1) / t1), atol=1e-5)

@@ -1,0 +1,169 @@
+"""Network-level parity on the GPU: tinyedm_amd modules (HIP path) vs the golden vectors produced
+by the reference itself and vs the CPU oracle on the same seeded parameters/inputs.
+
+Tolerances ('bf16 parity target'): the HIP path computes in bf16 with fp32 accumulation.
+ * vs the oracle run with the same bf16 rounding points: rel L2 <= 1e-2 on D-x (tight: only
+   summation order and a few fused-epilogue roundings differ);
+ * vs the reference's fp32 golden output: no worse than 2x the reference's OWN bf16-autocast deviation
+   from its fp32 output (stored in the fixture), floor 5e-3.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import edm_oracle as O
+from oracle.make_golden import tiny_cfgs, grad_digest
+
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def build(ecfg, dcfg, P, device=DEV):
+    import tinyedm_amd as T
+    emb = T.Embedding(ecfg.fourier_dim, ecfg.embedding_dim, ecfg.num_classes, ecfg.add_factor)
+    den = T.Denoiser(dcfg.in_channels, dcfg.out_channels, tuple(dcfg.encoder_block_types),
+                     tuple(dcfg.decoder_block_types), tuple(dcfg.encoder_out_channels),
+                     tuple(dcfg.decoder_out_channels), tuple(dcfg.skip_connections), dcfg.dropout_rate,
+                     dcfg.sigma_data, dcfg.encoder_add_factor, dcfg.decoder_add_factor, dcfg.embedding_dim,
+                     dcfg.num_heads)
+    emb.load_state_dict({k[len("embedding."):]: v for k, v in P.items() if k.startswith("embedding.")}, strict=True)
+    den.load_state_dict({k[len("denoiser."):]: v for k, v in P.items() if k.startswith("denoiser.")}, strict=True)
+    return emb.to(device), den.to(device)
+
+
+@pytest.fixture(scope="module")
+def tiny(golden_dir):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    g = np.load(os.path.join(golden_dir, "tiny_net.npz"))
+    ecfg, dcfg = tiny_cfgs()
+    P = O.init_params(ecfg, dcfg, torch.Generator().manual_seed(7))
+    return g, ecfg, dcfg, P
+
+
+def T_(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_state_dict_keys_match_reference_layout(tiny):
+    g, ecfg, dcfg, P = tiny
+    emb, den = build(ecfg, dcfg, P)
+    keys = sorted(["embedding." + k for k in emb.state_dict()] + ["denoiser." + k for k in den.state_dict()])
+    assert keys == sorted(P)
+    for k, v in den.state_dict().items():
+        assert v.shape == P["denoiser." + k].shape and v.dtype == torch.float32
+
+
+def test_eval_forward_matches_golden_and_oracle(tiny):
+    g, ecfg, dcfg, P = tiny
+    emb, den = build(ecfg, dcfg, P)
+    emb.eval(); den.eval()
+    noisy, sigma, labels = T_(g["noisy"]), T_(g["sigma"]), T_(g["labels"])
+    with torch.no_grad():
+        four, e = emb(sigma.to(DEV), labels.to(DEV))
+        D = den(noisy.to(DEV), sigma.to(DEV), e)
+    assert (four.cpu() - T_(g["eval_fourier"])).abs().max() < 5e-4
+    assert (e.cpu() - T_(g["eval_emb"])).abs().max() < 5e-4
+    assert D.dtype == torch.float32 and D.shape == noisy.shape
+    ref32, refbf = T_(g["eval_D"]), T_(g["eval_D_autocast_bf16"])
+    D_or = O.edm_forward(P, ecfg, dcfg, noisy, sigma, labels, bf16=True)
+    # network part F*c_out (D - c_skip*x): compare on the residual so c_skip*x cannot hide errors
+    c_skip, _, _ = O.precond_scalars(sigma, dcfg.sigma_data)
+    base = c_skip * noisy
+    assert rel(D.cpu() - base, D_or - base) <= 1e-2, rel(D.cpu() - base, D_or - base)
+    assert rel(D.cpu() - base, ref32 - base) <= max(2.0 * rel(refbf - base, ref32 - base), 5e-3)
+    # unconditional and scalar-sigma call patterns (solvers.py:48)
+    with torch.no_grad():
+        _, eu = emb(sigma.to(DEV), None)
+        Du = den(noisy.to(DEV), sigma.to(DEV), eu)
+        s0 = torch.tensor(1.7, device=DEV)
+        _, e0 = emb(s0, labels.view(-1, 1).to(DEV))
+        D0 = den(noisy.to(DEV), s0, e0)
+    assert rel(Du.cpu() - base, T_(g["eval_D_uncond"]) - base) <= 3e-2
+    cs0, _, _ = O.precond_scalars(torch.tensor([1.7]), dcfg.sigma_data)
+    assert rel(D0.cpu() - cs0 * noisy, T_(g["eval_D_scalar_sigma"]) - cs0 * noisy) <= 3e-2
+
+
+def test_training_step_grads_match_golden_and_oracle(tiny):
+    g, ecfg, dcfg, P = tiny
+    emb, den = build(ecfg, dcfg, P)
+    emb.train(); den.train()
+    clean, labels = T_(g["clean"]).to(DEV), T_(g["labels"]).to(DEV)
+    noisy, sigma = T_(g["noisy"]).to(DEV), T_(g["sigma"]).to(DEV)
+    _, e = emb(sigma, labels)
+    D = den(noisy, sigma, e)
+    from tinyedm_amd import metric
+    w = (sigma ** 2 + 0.25) / (sigma * 0.5) ** 2
+    loss = metric.weighted_mse_loss(w, D, clean)
+    loss.backward()
+    assert abs(loss.item() - float(g["train_loss"])) <= 3e-2 * abs(float(g["train_loss"]))
+    # oracle with the same bf16 rounding points
+    Pb = {k: v.clone() for k, v in P.items()}
+    for k in O.trainable_keys(Pb):
+        Pb[k].requires_grad_(True)
+    lo = O.training_loss(Pb, ecfg, dcfg, T_(g["clean"]), T_(g["eps"]), T_(g["noise"]), -1.2, 1.2, T_(g["labels"]), bf16=True)
+    lo.backward()
+    named = {("embedding." + k): v for k, v in emb.named_parameters()}
+    named.update({("denoiser." + k): v for k, v in den.named_parameters()})
+    keys = [str(k) for k in g["grad_keys"]]
+    assert sorted(named) == keys
+    worst = 0.0
+    scal = [Pb[k].grad.abs().item() for k in keys if Pb[k].numel() == 1]
+    scal_rms = float(np.sqrt(np.mean(np.square(scal))))
+    for i, k in enumerate(keys):
+        gr = named[k].grad
+        assert gr is not None and torch.isfinite(gr).all(), k
+        # forced weight normalisation happened in place (networks.py:32-34)
+        np.testing.assert_allclose(grad_digest(named[k].detach().cpu()), g["post_param_digest"][i], rtol=1e-4, atol=1e-5,
+                                   err_msg=k)
+        if gr.numel() == 1:
+            # scalar gains: a sum with heavy cancellation -> judge against the scale of the scalar grads
+            err = abs(gr.item() - Pb[k].grad.item())
+            assert err <= 5e-2 * max(abs(Pb[k].grad.item()), scal_rms), f"{k}: {gr.item()} vs {Pb[k].grad.item()}"
+            continue
+        r_or = rel(gr, Pb[k].grad)
+        worst = max(worst, r_or)
+        assert r_or <= 6e-2, f"{k}: rel vs bf16 oracle {r_or:.3e}"
+        # golden (reference fp32 autograd): norm of the gradient within 5 %
+        gn = float(g["grad_digest"][i][1])
+        assert abs(gr.double().norm().item() - gn) <= 5e-2 * gn + 1e-6, f"{k}: |g| {gr.norm().item()} vs {gn}"
+    print("worst per-tensor grad rel err vs bf16 oracle:", worst)
+
+
+def test_blocks_match_golden(golden_dir):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import tinyedm_amd as T
+    g = np.load(os.path.join(golden_dir, "blocks.npz"))
+    emb = T_(g["emb"]).to(DEV)
+    # fixtures use 16/32-channel blocks; the HIP convs need C % 32 == 0 -> only the 32-channel ones run here
+    spec = {"enc_plain": (False, False), "enc_down": (True, False)}
+    for tag, (down, attn) in spec.items():
+        m = T.networks.EncoderBlock(32, 32, 64, down, attn, num_heads=2)
+        sd = {k.split("::p::")[1]: T_(g[k]) for k in g.files if k.startswith(tag + "::p::")}
+        m.load_state_dict(sd, strict=True)
+        m = m.to(DEV).eval()
+        with torch.no_grad():
+            y = m(T_(g[tag + "::x"]).to(DEV), emb)
+        assert rel(y, T_(g[tag + "::y"])) <= 2e-2, (tag, rel(y, T_(g[tag + "::y"])))
+    spec = {"dec_plain": (False, 0), "dec_up": (True, 0), "dec_skip": (False, 32)}
+    for tag, (up, sc) in spec.items():
+        cout = 16 if tag == "dec_skip" else 32
+        if cout % 32:
+            continue
+        m = T.networks.DecoderBlock(32, cout, 64, up, False, num_heads=2, skip_channels=sc)
+        sd = {k.split("::p::")[1]: T_(g[k]) for k in g.files if k.startswith(tag + "::p::")}
+        m.load_state_dict(sd, strict=True)
+        m = m.to(DEV).eval()
+        skip = T_(g[tag + "::skip"]).to(DEV) if sc else None
+        with torch.no_grad():
+            y = m(T_(g[tag + "::x"]).to(DEV), emb, skip)
+        assert rel(y, T_(g[tag + "::y"])) <= 2e-2, (tag, rel(y, T_(g[tag + "::y"])))

@@ -1,0 +1,91 @@
+"""Data-parallel gradient exchange: one process per GPU, bucketed all-reduce of the FLAT gradient
+arena over RCCL (backend "nccl" on ROCm; "gloo" on CPU for tests), launched from autograd hooks as
+each bucket's gradients become final so the collective overlaps the rest of the backward pass.
+
+This replaces the implicit Lightning ``DDPStrategy`` -> torch DDP reducer -> NCCL of the reference
+(experiments/conf/*.yaml ``devices: -1, strategy: auto``; train.py:26).  Differences by design:
+gradients already live contiguously in one arena, so buckets are zero-copy slices of it (no
+bucket flatten/unflatten), buckets are sized for xGMI rings (default 32 MiB), and the mean over
+ranks is folded into the fused optimizer kernel's ``grad_scale`` instead of a divide pass.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, arena, bucket_bytes: int = 32 << 20, process_group=None):
+        self.arena = arena
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.enabled = True                      # False during non-final gradient-accumulation micro-batches
+        self.is_cuda = arena.grad.is_cuda
+        self.comm_stream = torch.cuda.Stream() if self.is_cuda else None
+        # buckets = contiguous arena ranges, built in REVERSE parameter order (backward order)
+        per_bucket = max(1, bucket_bytes // 4)
+        self.buckets: List[dict] = []
+        cur = None
+        n = len(arena.params)
+        for idx in reversed(range(n)):
+            p, off = arena.params[idx], arena.offsets[idx]
+            end = arena.offsets[idx + 1] if idx + 1 < n else arena.numel
+            if cur is None or cur["hi"] - off > per_bucket:
+                cur = {"lo": off, "hi": end, "params": [], "pending": 0, "work": None}
+                self.buckets.append(cur)
+            cur["lo"] = off
+            cur["params"].append(idx)
+        self._bucket_of = {}
+        for b in self.buckets:
+            for idx in b["params"]:
+                self._bucket_of[idx] = b
+        self._hooks = []
+        if self.world > 1:
+            for idx, p in enumerate(arena.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(idx)))
+        self.reset()
+
+    def reset(self):
+        for b in self.buckets:
+            b["pending"] = len(b["params"])
+            b["work"] = None
+
+    def _make_hook(self, idx):
+        def hook(_param):
+            if not self.enabled:
+                return
+            b = self._bucket_of[idx]
+            b["pending"] -= 1
+            if b["pending"] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        view = self.arena.grad[b["lo"]:b["hi"]]
+        if self.is_cuda:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                b["work"] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            b["work"] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self) -> float:
+        """Wait for every bucket (launching any whose hooks never fired, e.g. unused parameters) and
+        return the scale (1/world) the optimizer must apply to the summed gradients."""
+        if self.world > 1:
+            for b in self.buckets:
+                if b["work"] is None:
+                    self._launch(b)
+            for b in self.buckets:
+                b["work"].wait()
+            if self.is_cuda:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.reset()
+        return 1.0 / self.world
+
+    def broadcast_parameters(self, src: int = 0):
+        """DDP's initial parameter broadcast: one collective over the parameter arena."""
+        if self.world > 1:
+            dist.broadcast(self.arena.theta, src=src, group=self.group)

@@ -1,0 +1,207 @@
+"""EDM training module and Diffuser with the reference's surface (reference edm.py:64-334), running
+the step on the HIP path.  ``EDM`` mirrors the LightningModule the reference defines: same keyword-only
+constructor, ``training_step`` / ``validation_step`` / ``forward`` / ``predict_step`` /
+``configure_optimizers`` / ``configure_callbacks`` / ``load_from_checkpoint`` / ``swap_ema_weights``."""
+from __future__ import annotations
+
+import contextlib
+from typing import Any
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+from torch.optim.lr_scheduler import LambdaLR
+
+from . import networks, ops
+from .config import instantiate
+from .ema import EMA, EMAOptimizer, FusedAdam
+from .metric import WeightedMeanSquaredError
+from .networks import UncertaintyNet
+from .trainer import LightningModule
+from .utils import deinstantiate, swap_tensors
+
+
+class Diffuser(nn.Module):
+    """ln(sigma) ~ N(P_mean, P_std); returns (clean + sigma*n, sigma)  (reference edm.py:64-96).
+    Both normal draws come from a counter-based Philox stream keyed by (seed, step), generated inside
+    the noising kernel (no separate randn launches)."""
+
+    def __init__(self, P_mean: float, P_std: float) -> None:
+        super().__init__()
+        self.P_mean = P_mean
+        self.P_std = P_std
+
+    @torch.no_grad()
+    def forward(self, clean_image: Tensor) -> tuple[Tensor, Tensor]:
+        if not clean_image.is_cuda:
+            raise RuntimeError("tinyedm_amd.Diffuser: input must be a GPU tensor (there is no CPU path)")
+        x = clean_image.float().contiguous()
+        noisy, sigma = ops.diffuse(x, self.P_mean, self.P_std, networks.rng.seed ^ 0xD1FF05E5, networks.rng.step)
+        return noisy.to(clean_image.dtype), sigma.to(clean_image.dtype)
+
+    def extra_repr(self) -> str:
+        return f"P_mean={self.P_mean}, P_std={self.P_std}"
+
+
+class EDM(LightningModule):
+    def __init__(
+        self,
+        *,
+        diffuser,
+        embedding,
+        denoiser,
+        use_ema: bool,
+        use_uncertainty: bool,
+        steady_steps: int,
+        rampup_steps: int,
+        scheduler_interval: str,
+        sigma_data: float | None = None,
+        lr: float = 1e-4,
+        betas: tuple[float, float] = (0.9, 0.999),
+        ema_length: float | None = None,
+        validate_original_weights: bool = False,
+        every_n_steps: int = 1,
+        cpu_offload: bool = False,
+    ) -> None:
+        super().__init__()
+        assert hasattr(embedding, "fourier_dim") and embedding.fourier_dim is not None, \
+            "Embedding must have an fourier_dim attribute."
+        if use_ema and ema_length is None:
+            raise ValueError("ema_length must be specified when use_ema is True.")
+        self.diffuser = diffuser
+        self.embedding = embedding
+        self.denoiser = denoiser
+        self.use_ema = use_ema
+        self.use_uncertainty = use_uncertainty
+        self.steady_steps = steady_steps
+        self.rampup_steps = rampup_steps
+        self.scheduler_interval = scheduler_interval
+        self.betas = tuple(betas)
+        self.ema_length = ema_length
+        self.validate_original_weights = validate_original_weights
+        self.every_n_steps = every_n_steps
+        self.cpu_offload = cpu_offload
+        self.u = UncertaintyNet(embedding.fourier_dim, embedding.fourier_dim) if use_uncertainty else None
+        self.sigma_data = sigma_data if sigma_data is not None else denoiser.sigma_data
+        self.lr = lr
+        self.train_mse = WeightedMeanSquaredError()
+        self.val_mse = WeightedMeanSquaredError()
+        self.save_config()
+
+    def save_config(self):
+        self.hparams.update(deinstantiate(self))
+
+    # ------------------------------------------------------------------ checkpoints (edm.py:159-203)
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, *, map_location=None, load_ema: bool = False, **kwargs: Any):
+        checkpoint = torch.load(checkpoint_path, map_location=map_location, weights_only=False, **kwargs)
+        model = instantiate(checkpoint["hyper_parameters"])
+        assert isinstance(model, LightningModule)
+        state_dict = checkpoint.get("state_dict") or {}
+        if state_dict:
+            model.load_state_dict(state_dict, strict=False)
+        if load_ema:
+            ema_params = cls.find_ema_weights(checkpoint)
+            for param, ema_param in zip(model.parameters(), ema_params):
+                swap_tensors(param.data, ema_param.to(param.device))
+            print("EMA weights loaded.")
+        ref = next((t for t in state_dict.values() if isinstance(t, torch.Tensor)), None)
+        if ref is not None:
+            model.to(ref.device)
+        return model
+
+    @staticmethod
+    def find_ema_weights(checkpoint: dict):
+        try:
+            return checkpoint["optimizer_states"][0]["ema"]
+        except KeyError:
+            raise ValueError("EMA weights not found in the checkpoint.")
+
+    # ------------------------------------------------------------------ steps (edm.py:205-248)
+    def _loss(self, batch, metric, training: bool):
+        clean_image, class_label = batch
+        class_label = class_label if self.conditional else None
+        noisy_image, sigma = self.diffuser(clean_image)
+        fourier_embedding, embedding = self.embedding(sigma, class_label)
+        denoised_image = self.denoiser(noisy_image, sigma, embedding)
+        weight = (sigma ** 2 + self.sigma_data ** 2) / (sigma * self.sigma_data) ** 2
+        if training and self.u is not None:
+            uncertainty = self.u(fourier_embedding).flatten()
+            uncertainty_mean = uncertainty.mean()
+            loss = metric(weight / uncertainty.exp(), denoised_image, clean_image) + uncertainty_mean
+            self.log("uncertainty", uncertainty_mean)
+        else:
+            loss = metric(weight, denoised_image, clean_image)
+        return loss
+
+    def training_step(self, batch, batch_idx):
+        loss = self._loss(batch, self.train_mse, True)
+        self.log("train_loss", self.train_mse, prog_bar=True)
+        sch = self.lr_schedulers()
+        if sch is not None:
+            self.log("learning_rate", sch.get_last_lr()[0])
+        if not self.denoiser.training:      # the Denoiser advances the Philox step itself in training mode
+            networks.rng.step += 1
+        return loss
+
+    def validation_step(self, batch, batch_idx):
+        loss = self._loss(batch, self.val_mse, False)
+        networks.rng.step += 1
+        self.log("val_loss", self.val_mse)
+        return loss
+
+    # ------------------------------------------------------------------ optimisation (edm.py:250-278, 305-320)
+    def configure_optimizers(self):
+        optimizer = FusedAdam(self.parameters(), lr=self.lr, betas=self.betas)
+        lr_scheduler = self.get_lr_scheduler(optimizer, self.rampup_steps, self.steady_steps)
+        return {"optimizer": optimizer,
+                "lr_scheduler": {"scheduler": lr_scheduler, "interval": self.scheduler_interval, "frequency": 1}}
+
+    def configure_callbacks(self):
+        callbacks = []
+        if self.use_ema:
+            callbacks.append(EMA(ema_length=self.ema_length, validate_original_weights=self.validate_original_weights,
+                                 cpu_offload=self.cpu_offload, every_n_steps=self.every_n_steps))
+        return callbacks
+
+    @staticmethod
+    def lr_lambda(current_step, rampup_steps, steady_steps):
+        if current_step < rampup_steps:
+            return 1e-8 + (1.0 - 1e-8) * current_step / rampup_steps
+        if current_step < rampup_steps + steady_steps:
+            return 1.0
+        return 1 / np.sqrt(1 + (current_step - rampup_steps - steady_steps) / steady_steps)
+
+    @staticmethod
+    def get_lr_scheduler(optimizer, rampup_steps, steady_steps):
+        return LambdaLR(optimizer, lambda s: EDM.lr_lambda(s, rampup_steps, steady_steps))
+
+    # ------------------------------------------------------------------ inference (edm.py:280-303)
+    def forward(self, noisy_image: Tensor, sigma: Tensor, class_label: Tensor | None = None) -> Tensor:
+        class_label = class_label if self.conditional else None
+        _, embedding = self.embedding(sigma, class_label)
+        return self.denoiser(noisy_image, sigma, embedding)
+
+    def predict_step(self, batch: Any, batch_idx: int, dataloader_idx: int | None = None):
+        x0, class_label = batch
+        class_label = class_label if self.conditional else None
+        return self.solver.solve(self, x0, class_label)
+
+    @property
+    def num_classes(self) -> int | None:
+        return self.embedding.num_classes
+
+    @property
+    def conditional(self) -> bool:
+        return self.num_classes is not None
+
+    @contextlib.contextmanager
+    def swap_ema_weights(self, trainer):
+        optimizer = trainer.optimizers[0]
+        if not (self.use_ema and isinstance(optimizer, EMAOptimizer)):
+            raise ValueError("EMA is not used or the optimizer is not an EMAOptimizer.")
+        optimizer.switch_main_parameter_weights()
+        try:
+            yield
+        finally:
+            optimizer.switch_main_parameter_weights()

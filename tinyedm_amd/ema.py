@@ -1,0 +1,226 @@
+"""Optimizer side of the step: fused Adam + power-function EMA over flat HBM arenas.
+
+Replaces ``optim.Adam(fused=True)`` (reference edm.py:251-253) and the NeMo-derived
+``EMAOptimizer`` / ``EMA`` callback (reference ema.py): parameters, gradients, Adam moments and the
+EMA copy each live in ONE contiguous fp32 arena (35.6 M floats for the CIFAR net), parameters and
+their ``.grad`` are views into them, and a step is a single HIP launch that reads theta,g,m,v,ema and
+writes theta,m,v,ema once -- instead of the multi-tensor Adam launch plus two foreach passes on a
+side stream.  The flat gradient arena is also what the data-parallel reducer all-reduces.
+"""
+from __future__ import annotations
+
+import contextlib
+from typing import Iterable, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .utils import swap_tensors
+
+
+def sigma_rel_to_gamma(sigma_rel):
+    """reference ema.py:29-32."""
+    t = sigma_rel ** -2
+    return np.roots([1, 7, 16 - t, 12 - t]).real.max()
+
+
+class MisconfigurationException(Exception):
+    pass
+
+
+def _align(n: int, a: int = 64) -> int:
+    return (n + a - 1) // a * a
+
+
+class FlatArena:
+    """Re-homes a parameter list into one contiguous fp32 buffer (views keep names/shapes/strides)."""
+
+    def __init__(self, params: List[torch.nn.Parameter]):
+        self.params = [p for p in params if p.requires_grad]
+        dev = self.params[0].device
+        self.offsets, off = [], 0
+        for p in self.params:
+            if p.dtype != torch.float32:
+                raise TypeError("FlatArena expects fp32 master parameters")
+            self.offsets.append(off)
+            off += _align(p.numel())
+        self.numel = off
+        self.theta = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(off, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                view = self.theta[o:o + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+    def rebind_grads(self):
+        for p, o in zip(self.params, self.offsets):
+            g = self.grad[o:o + p.numel()].view_as(p)
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+
+    def zero_grad(self):
+        self.grad.zero_()
+        self.rebind_grads()
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """Adam (no weight decay / amsgrad) with torch.optim.Adam semantics, one launch over the arena."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        params = list(params)
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
+        self.arena = FlatArena(params)
+        self.m = torch.zeros_like(self.arena.theta)
+        self.v = torch.zeros_like(self.arena.theta)
+        self.step_count = 0
+        self.grad_scale = 1.0
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.arena.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None, ema: Optional[torch.Tensor] = None, ema_beta: float = 0.0):
+        loss = closure() if closure is not None else None
+        g = self.param_groups[0]
+        self.arena.rebind_grads()
+        self.step_count += 1
+        ops.adam_ema(self.arena.theta, self.arena.grad, self.m, self.v, ema, g["lr"], g["betas"][0], g["betas"][1],
+                     g["eps"], self.step_count, ema_beta, self.grad_scale)
+        from .networks import bump_weight_epoch
+        bump_weight_epoch()
+        return loss
+
+    def state_dict(self):
+        return {"m": self.m, "v": self.v, "step": self.step_count,
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        self.step_count = sd["step"]
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update(s)
+
+
+class EMAOptimizer:
+    """Same surface as the reference's EMAOptimizer (ema.py:160-348): wraps an optimizer, keeps an EMA
+    copy updated with beta_t = (1 - 1/(t+1))^(gamma+1) after every ``every_n_steps`` optimizer steps,
+    in-place weight swapping, and a state dict {opt, ema, current_step, gamma, every_n_steps}.
+    With ``FusedAdam`` the EMA update is fused into the optimizer kernel."""
+
+    def __init__(self, optimizer: FusedAdam, device=None, gamma: float = 0.0, every_n_steps: int = 1,
+                 current_step: int = 0):
+        if not isinstance(optimizer, FusedAdam):
+            raise TypeError("tinyedm_amd.EMAOptimizer wraps tinyedm_amd.FusedAdam")
+        self.optimizer = optimizer
+        self.gamma = gamma
+        self.device = device
+        self.current_step = current_step
+        self.every_n_steps = every_n_steps
+        self.ema_arena = optimizer.arena.theta.clone()
+
+    @property
+    def ema_params(self):
+        a = self.optimizer.arena
+        return tuple(self.ema_arena[o:o + p.numel()].view_as(p) for p, o in zip(a.params, a.offsets))
+
+    @property
+    def param_groups(self):
+        return self.optimizer.param_groups
+
+    def all_parameters(self):
+        return (p for g in self.param_groups for p in g["params"])
+
+    def _should_update_at_step(self) -> bool:
+        return self.current_step % self.every_n_steps == 0
+
+    def step(self, closure=None, **kwargs):
+        if self._should_update_at_step():
+            decay = (1 - 1 / (self.current_step + 1)) ** (self.gamma + 1)
+            loss = self.optimizer.step(closure, ema=self.ema_arena, ema_beta=float(decay))
+        else:
+            loss = self.optimizer.step(closure)
+        self.current_step += 1
+        return loss
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.optimizer.zero_grad()
+
+    def switch_main_parameter_weights(self):
+        swap_tensors(self.optimizer.arena.theta, self.ema_arena)
+        from .networks import bump_weight_epoch
+        bump_weight_epoch()
+
+    @contextlib.contextmanager
+    def swap_ema_weights(self, enabled: bool = True):
+        if enabled:
+            self.switch_main_parameter_weights()
+        try:
+            yield
+        finally:
+            if enabled:
+                self.switch_main_parameter_weights()
+
+    def __getattr__(self, name):
+        return getattr(self.__dict__["optimizer"], name)
+
+    def synchronize(self):
+        pass
+
+    def state_dict(self):
+        return {"opt": self.optimizer.state_dict(), "ema": tuple(t.clone() for t in self.ema_params),
+                "current_step": self.current_step, "gamma": self.gamma, "every_n_steps": self.every_n_steps}
+
+    def load_state_dict(self, sd):
+        self.optimizer.load_state_dict(sd["opt"])
+        for dst, src in zip(self.ema_params, sd["ema"]):
+            dst.copy_(src)
+        self.current_step = sd["current_step"]
+        self.gamma = sd["gamma"]
+        self.every_n_steps = sd["every_n_steps"]
+
+
+class EMA:
+    """Callback with the reference's hooks (ema.py:35-123): wraps the trainer's optimizers at fit start,
+    swaps EMA weights in for validation/test unless ``validate_original_weights``."""
+
+    def __init__(self, ema_length: float, validate_original_weights: bool = False, every_n_steps: int = 1,
+                 cpu_offload: bool = False):
+        if not (0 <= ema_length <= 0.2886):
+            raise MisconfigurationException("EMA length value must be between 0 and 0.2886")
+        if cpu_offload:
+            raise MisconfigurationException("cpu_offload is not supported: the EMA lives in HBM next to the weights")
+        self.ema_length = ema_length
+        self.gamma = sigma_rel_to_gamma(ema_length)
+        self.validate_original_weights = validate_original_weights
+        self.every_n_steps = every_n_steps
+        self.cpu_offload = cpu_offload
+
+    def on_fit_start(self, trainer, pl_module) -> None:
+        trainer.optimizers = [
+            o if isinstance(o, EMAOptimizer) else EMAOptimizer(o, device=pl_module.device, gamma=self.gamma,
+                                                               every_n_steps=self.every_n_steps,
+                                                               current_step=trainer.global_step)
+            for o in trainer.optimizers]
+
+    def _should_validate_ema_weights(self, trainer) -> bool:
+        return not self.validate_original_weights and any(isinstance(o, EMAOptimizer) for o in trainer.optimizers)
+
+    def swap_model_weights(self, trainer):
+        for o in trainer.optimizers:
+            assert isinstance(o, EMAOptimizer)
+            o.switch_main_parameter_weights()
+
+    def on_validation_start(self, trainer, pl_module) -> None:
+        if self._should_validate_ema_weights(trainer):
+            self.swap_model_weights(trainer)
+
+    def on_validation_end(self, trainer, pl_module) -> None:
+        if self._should_validate_ema_weights(trainer):
+            self.swap_model_weights(trainer)
+
+    on_test_start = on_validation_start
+    on_test_end = on_validation_end

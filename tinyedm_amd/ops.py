@@ -13,6 +13,28 @@ from . import _lib
 
 bf16, f32 = torch.bfloat16, torch.float32
 
+# When set to a dict, the MFMA kernels below record (start_event, end_event, algorithmic FLOPs, algorithmic
+# HBM bytes) per launch on the launch stream (bench.py's roofline leg).  None = no instrumentation.
+PROFILE = None
+
+
+class _prof:
+    def __init__(self, name, flops, nbytes):
+        self.name, self.flops, self.nbytes = name, flops, nbytes
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        if PROFILE is not None:
+            self.e.record()
+            PROFILE.setdefault(self.name, []).append((self.s, self.e, self.flops, self.nbytes))
+        return False
+
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -270,8 +292,11 @@ def conv_igemm(x, wp, taps, residual=None, alpha=1.0, beta=0.0):
     if residual is not None:
         _chk(residual, bf16, "residual", (B, H, W, Cout))
     y = torch.empty(B, H, W, Cout, device=x.device, dtype=bf16)
-    _lib.call("edm_conv_igemm", _p(x), _p(wp), _p(y), _p(residual), float(alpha), float(beta), B, H, W, Cin, Cout, taps,
-              _stream())
+    npix = B * H * W
+    with _prof("conv3x3_igemm" if taps == 9 else "conv1x1_igemm", 2.0 * npix * Cin * Cout * taps,
+               2.0 * (npix * (Cin + Cout * (2 if residual is not None else 1)) + wp.numel())):
+        _lib.call("edm_conv_igemm", _p(x), _p(wp), _p(y), _p(residual), float(alpha), float(beta), B, H, W, Cin, Cout,
+                  taps, _stream())
     return y
 
 
@@ -283,7 +308,10 @@ def conv_wgrad(x, dy, taps):
         raise ValueError("conv_wgrad: x/dy spatial mismatch")
     S = _lib.call("edm_conv_wgrad_nsplit", B, H, W, Cin, Cout, taps)
     slabs = torch.empty(S, taps, Cout, Cin, device=x.device, dtype=f32)
-    _lib.call("edm_conv_wgrad", _p(x), _p(dy), _p(slabs), B, H, W, Cin, Cout, taps, S, _stream())
+    npix = B * H * W
+    with _prof("conv3x3_wgrad" if taps == 9 else "conv1x1_wgrad", 2.0 * npix * Cin * Cout * taps,
+               2.0 * npix * (Cin + Cout) + 4.0 * slabs.numel()):
+        _lib.call("edm_conv_wgrad", _p(x), _p(dy), _p(slabs), B, H, W, Cin, Cout, taps, S, _stream())
     return slabs
 
 
@@ -322,3 +350,180 @@ def wgrad_finish(slabs, w, taps, I, perm=None, scale=1.0, out=None):
     _lib.call("edm_wgrad_finish", _p(slabs), S, _p(w), _p(out), _p(perm), O, I, Ipad, taps, float(scale), int(accumulate),
               _stream())
     return out
+
+
+# ------------------------------------------------------------------ attention
+def attention_fwd(qkv, heads):
+    """qkv (B,H,W,3C) bf16 with per-token channel order [head][q|k|v][d] -> y (B,H,W,C)."""
+    B, H, W, C3 = _nhwc(qkv, "qkv")
+    C = C3 // 3
+    y = torch.empty(B, H, W, C, device=qkv.device, dtype=bf16)
+    N = H * W
+    with _prof("attention_fwd", 4.0 * B * N * N * C, 2.0 * B * N * 4 * C):
+        _lib.call("edm_attention_fwd", _p(qkv), _p(y), B, N, C, heads, _stream())
+    return y
+
+
+def attention_bwd(qkv, y, gy, heads):
+    B, H, W, C3 = _nhwc(qkv, "qkv")
+    C = C3 // 3
+    _chk(y, bf16, "y", (B, H, W, C))
+    _chk(gy, bf16, "gy", (B, H, W, C))
+    gqkv = torch.empty_like(qkv)
+    N = H * W
+    with _prof("attention_bwd", 14.0 * B * N * N * C, 2.0 * B * N * 8 * C):
+        _lib.call("edm_attention_bwd", _p(qkv), _p(y), _p(gy), _p(gqkv), B, N, C, heads, _stream())
+    return gqkv
+
+
+# ------------------------------------------------------------------ fp32 linears / embedding
+def linear_fwd(x, w):
+    _chk(x, f32, "x")
+    _chk(w, f32, "w")
+    M, K = x.shape
+    N = w.shape[0]
+    if w.shape != (N, K):
+        raise ValueError("linear_fwd: shape mismatch")
+    y = torch.empty(M, N, device=x.device, dtype=f32)
+    _lib.call("edm_linear_fwd", _p(x), _p(w), _p(y), M, N, K, _stream())
+    return y
+
+
+def linear_dgrad(dy, w):
+    _chk(dy, f32, "dy")
+    _chk(w, f32, "w")
+    M, N = dy.shape
+    K = w.shape[1]
+    if w.shape[0] != N:
+        raise ValueError("linear_dgrad: shape mismatch")
+    dx = torch.empty(M, K, device=dy.device, dtype=f32)
+    _lib.call("edm_linear_dgrad", _p(dy), _p(w), _p(dx), M, N, K, 0, _stream())
+    return dx
+
+
+def linear_wgrad(dy, x):
+    _chk(dy, f32, "dy")
+    _chk(x, f32, "x")
+    M, N = dy.shape
+    K = x.shape[1]
+    if x.shape[0] != M:
+        raise ValueError("linear_wgrad: shape mismatch")
+    dw = torch.empty(N, K, device=dy.device, dtype=f32)
+    _lib.call("edm_linear_wgrad", _p(dy), _p(x), _p(dw), M, N, K, 0, _stream())
+    return dw
+
+
+def fourier_fwd(sigma, freqs, phases, B):
+    ss = _sigma_arg(sigma, B)
+    _chk(freqs, f32, "freqs")
+    _chk(phases, f32, "phases", freqs.shape)
+    out = torch.empty(B, freqs.numel(), device=freqs.device, dtype=f32)
+    _lib.call("edm_fourier_fwd", _p(sigma), ss, _p(freqs), _p(phases), _p(out), B, freqs.numel(), _stream())
+    return out
+
+
+def _labels_arg(labels, B):
+    if labels is None:
+        return None
+    if not labels.is_cuda:
+        raise RuntimeError("labels must be a CUDA/HIP tensor")
+    labels = labels.flatten().to(torch.int64).contiguous()
+    if labels.numel() != B:
+        raise ValueError(f"labels must have {B} elements")
+    return labels
+
+
+def embed_combine_fwd(emb_sigma, wcls_hat, labels, add_factor):
+    _chk(emb_sigma, f32, "emb_sigma")
+    B, E = emb_sigma.shape
+    K = 0
+    if labels is not None:
+        _chk(wcls_hat, f32, "wcls_hat")
+        K = wcls_hat.shape[1]
+    pre, out = torch.empty_like(emb_sigma), torch.empty_like(emb_sigma)
+    _lib.call("edm_embed_combine_fwd", _p(emb_sigma), _p(wcls_hat), _p(labels), float(add_factor), K, _p(pre), _p(out), B,
+              E, _stream())
+    return pre, out
+
+
+def embed_combine_bwd(gout, pre, labels, add_factor, wcls_shape):
+    _chk(gout, f32, "gout", pre.shape)
+    B, E = pre.shape
+    ges = torch.empty_like(pre)
+    gw, K = None, 0
+    if labels is not None:
+        gw = torch.zeros(wcls_shape, device=pre.device, dtype=f32)
+        K = wcls_shape[1]
+    _lib.call("edm_embed_combine_bwd", _p(gout), _p(pre), _p(labels), float(add_factor), K, _p(ges), _p(gw), B, E, _stream())
+    return ges, gw
+
+
+# ------------------------------------------------------------------ step-level kernels
+def diffuse(clean, P_mean, P_std, seed, step):
+    _chk(clean, f32, "clean")
+    B = clean.shape[0]
+    noisy = torch.empty_like(clean)
+    sigma = torch.empty(B, device=clean.device, dtype=f32)
+    _lib.call("edm_diffuse", _p(clean), _p(noisy), _p(sigma), float(P_mean), float(P_std), B, clean.numel() // B, int(seed),
+              int(step), _stream())
+    return noisy, sigma
+
+
+def diffuse_given(clean, eps, noise, P_mean, P_std):
+    _chk(clean, f32, "clean")
+    B = clean.shape[0]
+    _chk(eps, f32, "eps", (B,))
+    _chk(noise, f32, "noise", clean.shape)
+    noisy = torch.empty_like(clean)
+    sigma = torch.empty(B, device=clean.device, dtype=f32)
+    _lib.call("edm_diffuse_given", _p(clean), _p(eps), _p(noise), _p(noisy), _p(sigma), float(P_mean), float(P_std), B,
+              clean.numel() // B, _stream())
+    return noisy, sigma
+
+
+def weighted_mse(D, clean, sigma, sigma_data, weight=None, want_grad=True):
+    _chk(D, f32, "D")
+    _chk(clean, f32, "clean", D.shape)
+    B = D.shape[0]
+    if weight is not None:
+        _chk(weight, f32, "weight", (B,))
+    else:
+        _chk(sigma, f32, "sigma", (B,))
+    loss = torch.zeros((), device=D.device, dtype=f32)
+    dD = torch.empty_like(D) if want_grad else None
+    _lib.call("edm_weighted_mse", _p(D), _p(clean), _p(sigma), _p(weight), float(sigma_data), _p(loss), _p(dD), B,
+              D.numel() // B, _stream())
+    return loss, dD
+
+
+def adam_ema(theta, grad, m, v, ema, lr, b1, b2, eps, step, ema_beta, grad_scale=1.0):
+    for t, nme in ((theta, "theta"), (grad, "grad"), (m, "m"), (v, "v")):
+        _chk(t, f32, nme)
+        if t.numel() != theta.numel():
+            raise ValueError("adam_ema: arena size mismatch")
+    if ema is not None:
+        _chk(ema, f32, "ema")
+    _lib.call("edm_adam_ema", _p(theta), _p(grad), _p(m), _p(v), _p(ema), theta.numel(), float(lr), float(b1), float(b2),
+              float(eps), int(step), float(ema_beta), float(grad_scale), _stream())
+
+
+def heun_euler(x, D, t0, t1):
+    _chk(x, f32, "x")
+    _chk(D, f32, "D", x.shape)
+    dx, x1 = torch.empty_like(x), torch.empty_like(x)
+    _lib.call("edm_heun_euler", _p(x), _p(D), float(t0), float(t1), _p(dx), _p(x1), x.numel(), _stream())
+    return dx, x1
+
+
+def heun_correct(x, dx, x1, D1, t0, t1):
+    _chk(x, f32, "x")
+    out = torch.empty_like(x)
+    _lib.call("edm_heun_correct", _p(x), _p(dx), _p(x1), _p(D1), float(t0), float(t1), _p(out), x.numel(), _stream())
+    return out
+
+
+def scale_f32(x, s):
+    _chk(x, f32, "x")
+    y = torch.empty_like(x)
+    _lib.call("edm_scale_f32", _p(x), float(s), _p(y), x.numel(), _stream())
+    return y
