@@ -22,6 +22,19 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def note(msg):
+    """progress line on stderr (the JSON result line is the only thing on stdout)."""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("EDM_CPU_THREADS", "16"))))
+
 # work per unit, CIFAR-10 config (SURVEY.md 8(d) / BASELINE.md 3)
 TRAIN_GFLOP_PER_IMG = 81.0
 FWD_GFLOP_PER_IMG = 27.0
@@ -68,8 +81,11 @@ def train_bench(args, rank, world, device):
         return loss
 
     opt.zero_grad()
+    note(f"model built, warmup {args.warmup} steps")
     for i in range(args.warmup):
         loss = step(i)
+    torch.cuda.synchronize()
+    note(f"warmup done, timing {args.steps} steps")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -84,7 +100,8 @@ def train_bench(args, rank, world, device):
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
+    note(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
 
     # ---- roofline of the dominant kernel (3x3 implicit-GEMM conv): one extra, instrumented step AFTER the
     # timed region: HIP events around every launch on the launch stream; algorithmic FLOPs from the shapes.
@@ -109,8 +126,10 @@ def sampler_bench(args, model, device):
     B = args.sampler_batch
     g = torch.Generator().manual_seed(7)
     x0 = torch.randn(B, 3, 32, 32, generator=g).to(device)
+    note("sampler: warm-up + hipGraph capture")
     solver.solve(model, x0, None, graph=True)          # capture + first replay
     torch.cuda.synchronize()
+    note("sampler: captured, timing replays")
     t0 = time.perf_counter()
     for _ in range(args.sampler_iters):
         solver.solve(model, x0, None, graph=True)
@@ -124,8 +143,9 @@ def cpu_baseline(args):
     """Reference algorithm on the host cores: the CPU oracle's training step (fp32, plain torch CPU ops),
     bounded to ~10-30 s of CPU work."""
     from oracle import edm_oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    note(f"cpu baseline on {cores} host threads")
     ecfg, dcfg = O.cifar10_cfg()
     P = O.init_params(ecfg, dcfg, torch.Generator().manual_seed(1), gains_nonzero=True)
     keys = O.trainable_keys(P)
