@@ -25,6 +25,10 @@ const char* edm_last_error(void);
  * Forward conv with the forward pack; input-gradient (dgrad) with the flipped/transposed pack.  R may be NULL. */
 int edm_conv_igemm(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
                    int W, int Cin, int Cout, int taps, edm_stream_t stream);
+/* second-generation kernel, same contract (LDS-DMA staging, 3-deep weight ring, 256x128 tile); returns -3 for shapes
+ * it does not cover. */
+int edm_conv_igemm_v2(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
+                      int W, int Cin, int Cout, int taps, edm_stream_t stream);
 /* weight gradient: slabs[s,tap,co,ci] (fp32, nsplit = edm_conv_wgrad_nsplit(...)) partial sums over pixels. */
 int edm_conv_wgrad_nsplit(int B, int H, int W, int Cin, int Cout, int taps);
 int edm_conv_wgrad(const void* X, const void* dY, float* slabs, int B, int H, int W, int Cin, int Cout, int taps,

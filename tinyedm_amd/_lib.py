@@ -39,6 +39,7 @@ SIGNATURES = {
     "edm_nhwc_bf16_to_nchw": [P, P, I, I, I, P],
     # conv_igemm.hip / conv_wgrad.hip
     "edm_conv_igemm": [P, P, P, P, F, F, I, I, I, I, I, I, P],
+    "edm_conv_igemm_v2": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_wgrad_nsplit": [I, I, I, I, I, I],
     "edm_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, P],
     # attention.hip

@@ -741,14 +741,17 @@ __global__ void k_conv_out_bwd_x(const float* __restrict__ dD, const float* __re
   }
 }
 //   gwh[o,c] += sum_p dF[p,o]*x[p,c] ;  ggain += sum dD*c_out*F
-// block = 64 threads (one chunk each), grid = (ceil(CL/64), ceil(npix/PIXW))
+// block = CL*PS threads (thread -> fixed 8-channel chunk c8, pixel phase ps), grid = ceil(npix/PIXW);
+// partial sums are reduced across the PS phases in LDS, then ONE atomic per (o,c) per workgroup.
 __global__ void k_conv_out_bwd_w(const bf16* __restrict__ x, const float* __restrict__ dD,
                                  const float* __restrict__ Fraw, const float* __restrict__ gain_out,
                                  const float* __restrict__ sigma, int sstride, float sd, float* __restrict__ gwh,
                                  float* __restrict__ ggain, int HW, int C, int Co, long npix, int PIXW) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [PS][Co*C]
   const int CL = C >> 3;
-  const int c8 = blockIdx.x * 64 + threadIdx.x;
-  const long p0 = (long)blockIdx.y * PIXW, p1 = min(npix, p0 + PIXW);
+  const int PS = blockDim.x / CL;
+  const int c8 = threadIdx.x % CL, ps = threadIdx.x / CL;
+  const long p0 = (long)blockIdx.x * PIXW, p1 = min(npix, p0 + PIXW);
   const float go = *gain_out;
   float acc[8][8];
 #pragma unroll
@@ -756,36 +759,38 @@ __global__ void k_conv_out_bwd_w(const bf16* __restrict__ x, const float* __rest
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[o][j] = 0.f;
   float gg = 0.f;
-  for (long p = p0; p < p1; ++p) {
-    long b = p / HW;
-    int hw = (int)(p % HW);
-    float s = sigma[b * sstride];
-    float cout = s * sd * rsqrtf(s * s + sd * sd);
+  for (long p = p0 + ps; p < p1; p += PS) {
+    const long b = p / HW;
+    const int hw = (int)(p % HW);
+    const float s = sigma[b * sstride];
+    const float cout = s * sd * rsqrtf(s * s + sd * sd);
     float v[8];
-    if (c8 < CL) load8(x + p * C + c8 * 8, v);
+    load8(x + p * C + c8 * 8, v);
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
       if (o < Co) {
-        long idx = (b * Co + o) * HW + hw;
+        const long idx = (b * Co + o) * HW + hw;
         float d = dD[idx] * cout;
-        if (blockIdx.x == 0 && threadIdx.x == 0) gg += d * Fraw[idx];
+        if (c8 == 0) gg += d * Fraw[idx];
         d *= go;
-        if (c8 < CL) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[o][j] += d * v[j];
-        }
+        for (int j = 0; j < 8; ++j) acc[o][j] += d * v[j];
       }
     }
   }
-  if (c8 < CL) {
 #pragma unroll
-    for (int o = 0; o < 8; ++o)
-      if (o < Co) {
+  for (int o = 0; o < 8; ++o)
+    if (o < Co) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(gwh + (long)o * C + c8 * 8 + j, acc[o][j]);
-      }
+      for (int j = 0; j < 8; ++j) red[(ps * Co + o) * C + c8 * 8 + j] = acc[o][j];
+    }
+  __syncthreads();
+  for (int e = threadIdx.x; e < Co * C; e += blockDim.x) {
+    float sacc = 0.f;
+    for (int q = 0; q < PS; ++q) sacc += red[q * Co * C + e];
+    atomicAdd(gwh + e, sacc);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ggain, gg);
+  if (c8 == 0) atomicAdd(ggain, gg);
 }
 // gw_hat [Co,C] and ggain are accumulated (+=): caller zero-fills.
 extern "C" int edm_conv_out_bwd(const void* x, const float* w_hat, const float* gain_out, const float* Fraw,
@@ -797,9 +802,16 @@ extern "C" int edm_conv_out_bwd(const void* x, const float* w_hat, const float* 
   hipLaunchKernelGGL(k_conv_out_bwd_x, dim3(grid_for(n8, 256)), dim3(256), 0, st, dD, w_hat, gain_out, sigma,
                      sigma_stride, sigma_data, (bf16*)gx, HW, C, Co, n8);
   EDM_CHECK_LAUNCH("conv_out_bwd_x");
-  const int PIXW = 256;
-  hipLaunchKernelGGL(k_conv_out_bwd_w, dim3(cdiv(C / 8, 64), cdiv(npix, PIXW)), dim3(64), 0, st, (const bf16*)x, dD,
-                     Fraw, gain_out, sigma, sigma_stride, sigma_data, gw_hat, ggain, HW, C, Co, npix, PIXW);
+  {
+    const int CL = C / 8;
+    EDM_REQUIRE(CL <= 256, "conv_out_bwd: C=%d too large", C);
+    int block = (256 / CL) * CL, PS = block / CL;
+    while (PS > 1 && (size_t)PS * Co * C * sizeof(float) > 48 * 1024) { --PS; block = PS * CL; }
+    const int PIXW = 1024;
+    hipLaunchKernelGGL(k_conv_out_bwd_w, dim3(cdiv(npix, PIXW)), dim3(block), (size_t)PS * Co * C * sizeof(float), st,
+                       (const bf16*)x, dD, Fraw, gain_out, sigma, sigma_stride, sigma_data, gw_hat, ggain, HW, C, Co,
+                       npix, PIXW);
+  }
   EDM_CHECK_LAUNCH("conv_out_bwd_w");
   return EDM_OK;
 }

@@ -11,16 +11,17 @@ __global__ __launch_bounds__(256) void k_sgemm(const float* __restrict__ A, long
                                                  const float* __restrict__ Bm, long bsk, long bsn,
                                                  float* __restrict__ C, long csm, long csn, int M, int N, int K,
                                                  float alpha, int accumulate) {
-  constexpr int TM = 64, TN = 64, TK = 16;
+  constexpr int TM = 32, TN = 32, TK = 32;
   __shared__ float As[TK][TM + 1];
   __shared__ float Bs[TK][TN + 1];
+  // 256 threads: 16x16 threads x (2x2 outputs) = 32x32 tile (small tiles: these GEMMs are tiny, parallelism first)
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-  float acc[4][4];
+  float acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int j = 0; j < 2; ++j) acc[i][j] = 0.f;
   for (int k0 = 0; k0 < K; k0 += TK) {
     for (int e = threadIdx.x; e < TM * TK; e += 256) {
       const int kk = e % TK, mm = e / TK;
@@ -35,23 +36,68 @@ __global__ __launch_bounds__(256) void k_sgemm(const float* __restrict__ A, long
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < TK; ++kk) {
-      float a[4], b[4];
+      float a[2], b[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+      for (int i = 0; i < 2; ++i) a[i] = As[kk][ty * 2 + i];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
+      for (int j = 0; j < 2; ++j) b[j] = Bs[kk][tx * 2 + j];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+        for (int j = 0; j < 2; ++j) acc[i][j] += a[i] * b[j];
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + ty * 2 + i, n = n0 + tx * 2 + j;
+      if (m < M && n < N) {
+        float* c = C + m * csm + n * csn;
+        *c = accumulate ? *c + alpha * acc[i][j] : alpha * acc[i][j];
+      }
+    }
+}
+
+// Fast path for K <= 256: the whole K extent of a 32x32 output tile is staged at once (one barrier, no K loop),
+// because these GEMMs are latency-bound (a 128x256x256 problem is 17 MFLOP).
+__global__ __launch_bounds__(256) void k_sgemm_smallk(const float* __restrict__ A, long asm_, long ask,
+                                                        const float* __restrict__ Bm, long bsk, long bsn,
+                                                        float* __restrict__ C, long csm, long csn, int M, int N, int K,
+                                                        float alpha, int accumulate) {
+  constexpr int TM = 32, TN = 32, LD = 33;
+  extern __shared__ __attribute__((aligned(16))) float sm_[];
+  float (*As)[LD] = reinterpret_cast<float (*)[LD]>(sm_);
+  float (*Bs)[LD] = reinterpret_cast<float (*)[LD]>(sm_ + (size_t)K * LD);
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+  // pick the thread->element map so that the unit-stride dimension of each operand is the fast one
+  for (int e = threadIdx.x; e < TM * K; e += 256) {
+    int kk, mm;
+    if (ask == 1) { kk = e % K; mm = e / K; } else { mm = e % TM; kk = e / TM; }
+    const int m = m0 + mm;
+    As[kk][mm] = (m < M) ? A[m * asm_ + kk * ask] : 0.f;
+  }
+  for (int e = threadIdx.x; e < TN * K; e += 256) {
+    int kk, nn;
+    if (bsk == 1) { kk = e % K; nn = e / K; } else { nn = e % TN; kk = e / TN; }
+    const int n = n0 + nn;
+    Bs[kk][nn] = (n < N) ? Bm[kk * bsk + n * bsn] : 0.f;
+  }
+  __syncthreads();
+  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll 8
+  for (int kk = 0; kk < K; ++kk) {
+    const float a0 = As[kk][ty * 2], a1 = As[kk][ty * 2 + 1];
+    const float b0 = Bs[kk][tx * 2], b1 = Bs[kk][tx * 2 + 1];
+    acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + ty * 2 + i, n = n0 + tx * 2 + j;
       if (m < M && n < N) {
         float* c = C + m * csm + n * csn;
         *c = accumulate ? *c + alpha * acc[i][j] : alpha * acc[i][j];
@@ -61,7 +107,18 @@ __global__ __launch_bounds__(256) void k_sgemm(const float* __restrict__ A, long
 
 int sgemm(const float* A, long asm_, long ask, const float* B, long bsk, long bsn, float* C, long csm, long csn, int M,
           int N, int K, float alpha, int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL(k_sgemm, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, A, asm_, ask, B, bsk, bsn, C, csm,
+  if (K <= 512) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sgemm_smallk),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k_sgemm_smallk, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), (size_t)2 * K * 33 * sizeof(float),
+                       st, A, asm_, ask, B, bsk, bsn, C, csm, csn, M, N, K, alpha, accumulate);
+    return 0;
+  }
+  hipLaunchKernelGGL(k_sgemm, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, st, A, asm_, ask, B, bsk, bsn, C, csm,
                      csn, M, N, K, alpha, accumulate);
   return 0;
 }

@@ -83,7 +83,15 @@ __global__ __launch_bounds__(256) void k_wgrad_finish(const float* __restrict__ 
     const int t = e / I, i = e - t * I;
     const float* sp = slabs + ((long)t * O + r) * Ipad + i;
     float a = 0.f;
-    for (int s = 0; s < S; ++s) a += sp[s * slab_stride];
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {  // 8 independent loads in flight per lane
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = sp[(s + u) * slab_stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; s < S; ++s) a += sp[s * slab_stride];
     a *= scale;
     const float wv = row[i * taps + t];
     g[i * taps + t] = a;

@@ -44,7 +44,10 @@ class GradReducer:
         self._hooks = []
         if self.world > 1:
             for idx, p in enumerate(arena.params):
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(idx)))
+                hook = self._make_hook(idx)
+                self._hooks.append(p.register_post_accumulate_grad_hook(hook))
+                if hasattr(p, "_edm_hooks"):      # gradients written directly by the HIP finish kernel
+                    p._edm_hooks.append(hook)
         self.reset()
 
     def reset(self):

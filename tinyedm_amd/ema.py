@@ -54,6 +54,8 @@ class FlatArena:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
+                p._edm_direct = True          # weight-gradient kernels may accumulate into p.grad directly
+                p._edm_hooks = []
 
     def rebind_grads(self):
         for p, o in zip(self.params, self.offsets):

@@ -99,6 +99,13 @@ class _WNBase(nn.Module):
         """slabs (S, taps, O, Ipad) fp32 in packed order -> gradient w.r.t. the master weight."""
         w = self.weight
         I = w.shape[1]
+        if w.grad is not None and getattr(w, "_edm_direct", False):
+            # flat-arena mode: accumulate straight into the gradient arena (no autograd AccumulateGrad pass,
+            # no temporary) and tell the data-parallel reducer this gradient is final.
+            ops.wgrad_finish(slabs, w.data, self._taps(), I, perm=self._perm, scale=scale, out=w.grad)
+            for hook in getattr(w, "_edm_hooks", ()):
+                hook(w)
+            return None
         g = ops.wgrad_finish(slabs, w.data, self._taps(), I, perm=self._perm, scale=scale)
         return g.view_as(w)
 

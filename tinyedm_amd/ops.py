@@ -5,6 +5,7 @@ Layout conventions: activations are NHWC bf16 tensors of shape (B, H, W, C) (con
 "rows" means B*H*W.  Per-(sample,channel) quantities are fp32 (B, C).
 """
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -282,6 +283,22 @@ def nhwc_bf16_to_nchw(x):
 
 
 # ------------------------------------------------------------------ convolution
+# 0 = pick per shape (default), 1 = register-staged 128x128 kernel, 2 = LDS-DMA 256x128 kernel
+IGEMM_VERSION = int(os.environ.get("EDM_IGEMM", "0"))
+
+
+def _igemm_entry(npix, W, Cout, taps):
+    if taps == 9 and W > 64:
+        return "edm_conv_igemm"
+    if IGEMM_VERSION == 1:
+        return "edm_conv_igemm"
+    if IGEMM_VERSION == 2:
+        return "edm_conv_igemm_v2"
+    # the 256x128-tile kernel needs >= 2 workgroups per CU to pay off (measured: r01 microbench)
+    tiles = ((npix + 255) // 256) * ((Cout + 127) // 128)
+    return "edm_conv_igemm_v2" if tiles >= 512 else "edm_conv_igemm"
+
+
 def conv_igemm(x, wp, taps, residual=None, alpha=1.0, beta=0.0):
     """Y = alpha*conv(x, wp) + beta*residual.  wp: bf16 (taps, Cout, Cin)."""
     B, H, W, Cin = _nhwc(x, "x")
@@ -295,8 +312,7 @@ def conv_igemm(x, wp, taps, residual=None, alpha=1.0, beta=0.0):
     npix = B * H * W
     with _prof("conv3x3_igemm" if taps == 9 else "conv1x1_igemm", 2.0 * npix * Cin * Cout * taps,
                2.0 * (npix * (Cin + Cout * (2 if residual is not None else 1)) + wp.numel())):
-        _lib.call("edm_conv_igemm", _p(x), _p(wp), _p(y), _p(residual), float(alpha), float(beta), B, H, W, Cin, Cout,
-                  taps, _stream())
+        _lib.call(_igemm_entry(npix, W, Cout, taps), _p(x), _p(wp), _p(y), _p(residual), float(alpha), float(beta), B, H, W, Cin, Cout, taps, _stream())
     return y
 
 
