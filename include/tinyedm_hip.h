@@ -29,6 +29,18 @@ int edm_conv_igemm(const void* X, const void* Wp, void* Y, const void* R, float 
  * it does not cover. */
 int edm_conv_igemm_v2(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
                       int W, int Cin, int Cout, int taps, edm_stream_t stream);
+/* third-generation kernel, same contract (512x128 "tall" tile, 128x64 per wave); -3 for shapes it does not cover */
+int edm_conv_igemm_v3(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
+                      int W, int Cin, int Cout, int taps, edm_stream_t stream);
+/* diagnostic (tools/ only): in-kernel shader clock of the v3 kernel (dbg[0] cycles, dbg[1] 100 MHz ticks, dbg[2] WGs) */
+int edm_conv_igemm_v3_clock(const void* X, const void* Wp, void* Y, int B, int H, int W, int Cin, int Cout,
+                            unsigned long long* dbg, edm_stream_t stream);
+/* diagnostic (tools/ only): s_memtime stamps per loop segment of the v2 kernel, summed over waves into dbg[0..5] */
+int edm_conv_igemm_v2_stamp(const void* X, const void* Wp, void* Y, int B, int H, int W, int Cin, int Cout,
+                            unsigned long long* dbg, edm_stream_t stream);
+/* diagnostic (tools/ only): timing-only ablations of the v2 kernel (bit0 no MFMA, bit1 no DMA, bit2 no reads, bit3 no barrier) */
+int edm_conv_igemm_v2_ablate(const void* X, const void* Wp, void* Y, int B, int H, int W, int Cin, int Cout, int mode,
+                             edm_stream_t stream);
 /* weight gradient: slabs[s,tap,co,ci] (fp32, nsplit = edm_conv_wgrad_nsplit(...)) partial sums over pixels. */
 int edm_conv_wgrad_nsplit(int B, int H, int W, int Cin, int Cout, int taps);
 int edm_conv_wgrad(const void* X, const void* dY, float* slabs, int B, int H, int W, int Cin, int Cout, int taps,

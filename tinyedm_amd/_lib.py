@@ -40,6 +40,10 @@ SIGNATURES = {
     # conv_igemm.hip / conv_wgrad.hip
     "edm_conv_igemm": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_v2": [P, P, P, P, F, F, I, I, I, I, I, I, P],
+    "edm_conv_igemm_v3": [P, P, P, P, F, F, I, I, I, I, I, I, P],
+    "edm_conv_igemm_v3_clock": [P, P, P, I, I, I, I, I, P, P],
+    "edm_conv_igemm_v2_stamp": [P, P, P, I, I, I, I, I, P, P],
+    "edm_conv_igemm_v2_ablate": [P, P, P, I, I, I, I, I, I, P],
     "edm_conv_wgrad_nsplit": [I, I, I, I, I, I],
     "edm_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, P],
     # attention.hip

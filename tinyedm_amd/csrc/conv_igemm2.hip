@@ -35,12 +35,21 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int TAPS, int NX>
+// diagnostic stamps (STAMP=true builds only; never used by the product path): cycles per loop segment
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+
+template <int TAPS, int NX, bool STAMP = false, int ABL = 0>
 __global__ __launch_bounds__(512, 4) void k_conv_igemm2(const bf16* __restrict__ X, const bf16* __restrict__ Wp,
                                                           bf16* __restrict__ Y, const bf16* __restrict__ R,
                                                           const bf16* __restrict__ zeros, float alpha, float beta,
                                                           int Npix, int H, int W, int Cin, int Cout, int tiles_m,
-                                                          int tiles_n) {
+                                                          int tiles_n, unsigned long long* dbg = nullptr) {
   constexpr int XBUFS = (TAPS == 9) ? 2 : 3;
   constexpr int XROWS = NX * 8 * 16;  // LDS rows per slab buffer (every DMA slot is backed by LDS)
   constexpr int XBYTES = XROWS * ROWB;
@@ -135,10 +144,13 @@ __global__ __launch_bounds__(512, 4) void k_conv_igemm2(const bf16* __restrict__
     }
   }
 
+  unsigned long long seg[5] = {0, 0, 0, 0, 0}, tprev = 0;
+  if (STAMP) tprev = stamp();
   int chunk = 0, tap = 0;
   for (int t = 0; t < T; ++t) {
     // ---- retire tile t (counted: the younger tile(s) stay in flight across the barrier)
-    if (t + 1 >= T) {
+    if (ABL & 2) {
+    } else if (t + 1 >= T) {
       wait_vmcnt<0>();
     } else if (TAPS == 9) {
       if ((tap == 1 || tap == 2) && chunk + 1 < nchunks) wait_vmcnt<NX + 1>();
@@ -146,9 +158,12 @@ __global__ __launch_bounds__(512, 4) void k_conv_igemm2(const bf16* __restrict__
     } else {
       wait_vmcnt<NX + 1>();
     }
-    __builtin_amdgcn_s_barrier();
+    if (STAMP) { unsigned long long n = stamp(); seg[0] += n - tprev; tprev = n; }
+    if (!(ABL & 8)) __builtin_amdgcn_s_barrier();
+    if (STAMP) { unsigned long long n = stamp(); seg[1] += n - tprev; tprev = n; }
     // ---- issue tile t+2 (its ring slot was last read at iteration t-1: every wave is past that barrier)
-    if (TAPS == 9) {
+    if (ABL & 2) {
+    } else if (TAPS == 9) {
       if (t + 2 < T) {
         int tp2 = tap + 2, ch2 = chunk;
         if (tp2 >= TAPS) { tp2 -= TAPS; ++ch2; }
@@ -161,6 +176,7 @@ __global__ __launch_bounds__(512, 4) void k_conv_igemm2(const bf16* __restrict__
         issue_x(t + 2, (t + 2) % XBUFS);
       }
     }
+    if (STAMP) { unsigned long long n = stamp(); seg[2] += n - tprev; tprev = n; }
     // ---- MFMA over this (chunk, tap)
     const int toff = (TAPS == 9) ? ((tap / 3 - 1) * W + (tap % 3 - 1)) : 0;
     const char* wt = Wb + (t % WRING) * WTILE;
@@ -168,7 +184,7 @@ __global__ __launch_bounds__(512, 4) void k_conv_igemm2(const bf16* __restrict__
     const int r0 = brow[0] + toff, r1 = brow[1] + toff;
     const int s0 = (r0 >> 2) & 3, s1 = (r1 >> 2) & 3;
     const bool v0 = (mask[0] >> tap) & 1, v1 = (mask[1] >> tap) & 1;
-    {
+    if (!(ABL & 4)) {
       bf16x8 a0 = *reinterpret_cast<const bf16x8*>(wt + a_off0);
       bf16x8 a1 = *reinterpret_cast<const bf16x8*>(wt + 32 * ROWB + a_off0);
       bf16x8 b0 = *reinterpret_cast<const bf16x8*>(xs + r0 * ROWB + (((0 + lhi) ^ s0) << 4));
@@ -181,6 +197,15 @@ __global__ __launch_bounds__(512, 4) void k_conv_igemm2(const bf16* __restrict__
       b1 = v1 ? b1 : zero8;
       b2 = v0 ? b2 : zero8;
       b3 = v1 ? b3 : zero8;
+      if (STAMP) {
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+        unsigned long long n = stamp(); seg[3] += n - tprev; tprev = n;
+      }
+      if (ABL & 1) {
+        asm volatile("" ::"v"(a0), "v"(a1), "v"(a2), "v"(a3));
+        asm volatile("" ::"v"(b0), "v"(b1), "v"(b2), "v"(b3));
+      } else {
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
@@ -189,8 +214,15 @@ __global__ __launch_bounds__(512, 4) void k_conv_igemm2(const bf16* __restrict__
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b3, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b2, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b3, acc[1][1], 0, 0, 0);
+      }
     }
+    if (STAMP) { unsigned long long n = stamp(); seg[4] += n - tprev; tprev = n; }
     if (++tap == TAPS) { tap = 0; ++chunk; }
+  }
+  if (STAMP && dbg && lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) atomicAdd(dbg + q, seg[q]);
+    atomicAdd(dbg + 5, 1ull);
   }
 
   // ---- epilogue: lane holds, per (i,j), pixel = col(l31) and 4x4 consecutive output channels
@@ -238,10 +270,58 @@ void launch2(const void* X, const void* Wp, void* Y, const void* R, float alpha,
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const bf16*)X, (const bf16*)Wp, (bf16*)Y, (const bf16*)R,
-                     (const bf16*)g_zero_page, alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n);
+                     (const bf16*)g_zero_page, alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n,
+                     (unsigned long long*)nullptr);
 }
 
 }  // namespace
+
+// Diagnostic build (tools only): 3x3 shape, accumulates per-wave segment cycles into dbg[0..4], wave count in dbg[5].
+// Segments: 0 vmcnt wait, 1 barrier, 2 DMA issue, 3 fragment reads landed, 4 MFMA issue.
+extern "C" int edm_conv_igemm_v2_stamp(const void* X, const void* Wp, void* Y, int B, int H, int W, int Cin, int Cout,
+                                       unsigned long long* dbg, hipStream_t st) {
+  EDM_REQUIRE(X && Wp && Y && dbg && g_zero_page && W <= 32, "conv_igemm_v2_stamp: bad args (run the product kernel once first)");
+  const int Npix = B * H * W;
+  const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + BN - 1) / BN;
+  const size_t lds = (size_t)2 * 3 * 8 * 16 * ROWB + WRING * WTILE;
+  auto kern = k_conv_igemm2<9, 3, true>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(kern, dim3(((tiles_m + 7) / 8) * 8 * tiles_n), dim3(512), lds, st, (const bf16*)X, (const bf16*)Wp,
+                     (bf16*)Y, (const bf16*)nullptr, (const bf16*)g_zero_page, 1.f, 0.f, Npix, H, W, Cin, Cout, tiles_m,
+                     tiles_n, dbg);
+  EDM_CHECK_LAUNCH("conv_igemm_v2_stamp");
+  return EDM_OK;
+}
+
+// Diagnostic (tools only): timing-only ablations of the 3x3 v2 kernel (outputs are wrong by construction).
+// mode bit0 no MFMA, bit1 no DMA/waits, bit2 no fragment reads + MFMA, bit3 no barrier.
+template <int ABL>
+static void launch_abl(const void* X, const void* Wp, void* Y, int Npix, int H, int W, int Cin, int Cout, hipStream_t st) {
+  const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + BN - 1) / BN;
+  const size_t lds = (size_t)2 * 3 * 8 * 16 * ROWB + WRING * WTILE;
+  auto kern = k_conv_igemm2<9, 3, false, ABL>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(kern, dim3(((tiles_m + 7) / 8) * 8 * tiles_n), dim3(512), lds, st, (const bf16*)X, (const bf16*)Wp,
+                     (bf16*)Y, (const bf16*)nullptr, (const bf16*)g_zero_page, 1.f, 0.f, Npix, H, W, Cin, Cout, tiles_m,
+                     tiles_n, (unsigned long long*)nullptr);
+}
+extern "C" int edm_conv_igemm_v2_ablate(const void* X, const void* Wp, void* Y, int B, int H, int W, int Cin, int Cout,
+                                        int mode, hipStream_t st) {
+  EDM_REQUIRE(X && Wp && Y && g_zero_page && W <= 32, "conv_igemm_v2_ablate: bad args");
+  const int Npix = B * H * W;
+  switch (mode) {
+    case 0: launch_abl<0>(X, Wp, Y, Npix, H, W, Cin, Cout, st); break;
+    case 1: launch_abl<1>(X, Wp, Y, Npix, H, W, Cin, Cout, st); break;
+    case 2: launch_abl<2>(X, Wp, Y, Npix, H, W, Cin, Cout, st); break;
+    case 4: launch_abl<4>(X, Wp, Y, Npix, H, W, Cin, Cout, st); break;
+    case 6: launch_abl<6>(X, Wp, Y, Npix, H, W, Cin, Cout, st); break;
+    case 8: launch_abl<8>(X, Wp, Y, Npix, H, W, Cin, Cout, st); break;
+    case 10: launch_abl<10>(X, Wp, Y, Npix, H, W, Cin, Cout, st); break;
+    default: edm_set_error("conv_igemm_v2_ablate: unknown mode %d", mode); return EDM_ERR_ARG;
+  }
+  EDM_CHECK_LAUNCH("conv_igemm_v2_ablate");
+  return EDM_OK;
+}
 
 // Same contract as edm_conv_igemm (conv_igemm.hip); returns EDM_ERR_UNSUPPORTED for shapes it does not cover so the
 // dispatcher can fall back to generation 1.

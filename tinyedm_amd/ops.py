@@ -294,9 +294,15 @@ def _igemm_entry(npix, W, Cout, taps):
         return "edm_conv_igemm"
     if IGEMM_VERSION == 2:
         return "edm_conv_igemm_v2"
-    # the 256x128-tile kernel needs >= 2 workgroups per CU to pay off (measured: r01 microbench)
-    tiles = ((npix + 255) // 256) * ((Cout + 127) // 128)
-    return "edm_conv_igemm_v2" if tiles >= 512 else "edm_conv_igemm"
+    if IGEMM_VERSION == 3:
+        return "edm_conv_igemm_v3"
+    # per-shape choice from the r01 microbenchmarks (tools/microbench_conv.py): the LDS-DMA tall-tile kernels only pay
+    # off when they still give every CU >= 2 tiles; small feature maps keep the 128x128 register-staged kernel.
+    if taps == 9:
+        tiles3 = ((npix + 511) // 512) * ((Cout + 127) // 128)
+        return "edm_conv_igemm_v3" if tiles3 >= 512 else "edm_conv_igemm"
+    tiles2 = ((npix + 255) // 256) * ((Cout + 127) // 128)
+    return "edm_conv_igemm_v2" if tiles2 >= 1024 else "edm_conv_igemm"
 
 
 def conv_igemm(x, wp, taps, residual=None, alpha=1.0, beta=0.0):
