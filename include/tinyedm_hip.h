@@ -51,6 +51,11 @@ int edm_conv_wgrad(const void* X, const void* dY, float* slabs, int B, int H, in
  * written as bf16 forward pack [taps,O,Ipad], bf16 dgrad pack [taps,I,O] (taps flipped) and/or fp32 [O,I*taps]. */
 int edm_weight_prep(float* w, int O, int I, int taps, int Ipad, void* wp_fwd, void* wp_dgrad, float* w_hat,
                     const int* perm, int normalize_inplace, edm_stream_t stream);
+/* multi-tensor form: one launch for every weight of a network.  descs = device array of 64-byte records
+ * {float* w; bf16* fwd; bf16* dgrad; float* hat; const int* perm; int O, I, taps, Ipad, row0, pad;}, row2desc = device
+ * int32 [total_rows] mapping each packed output row to its record (row0 = first global row of the record). */
+int edm_weight_prep_multi(const void* descs, const int* row2desc, int total_rows, int normalize_inplace,
+                          edm_stream_t stream);
 /* reduce split-K slabs and project through the normalisation -> gradient of the fp32 master weight [O,I,taps]. */
 int edm_wgrad_finish(const float* slabs, int S, const float* w, float* grad, const int* perm, int O, int I, int Ipad,
                      int taps, float scale, int accumulate, edm_stream_t stream);
@@ -73,11 +78,11 @@ int edm_silu_bwd(const void* x, const void* ga, const void* gextra, float extra_
 /* out = alpha*a + beta*b (mp_add, networks.py:87-88) */
 int edm_axpby(const void* a, float alpha, const void* b, float beta, void* out, long n, edm_stream_t stream);
 /* a = dropout(mp_silu(r * (lin*gain + 1)))  (networks.py:255-260 / 319-324); Philox mask from (seed, sub, step) */
-int edm_mod_silu_drop_fwd(const void* r, const float* lin, const float* gain, void* a, int B, int HW, int C,
-                          float pdrop, unsigned long long seed, unsigned sub, unsigned step, edm_stream_t stream);
-int edm_mod_silu_drop_bwd(const void* r, const float* lin, const float* gain, const void* ga, void* gr, float* gm,
-                          float* glin, float* ggain, int B, int HW, int C, float pdrop, unsigned long long seed,
-                          unsigned sub, unsigned step, edm_stream_t stream);
+int edm_mod_silu_drop_fwd(const void* r, const float* lin, long lin_stride, const float* gain, void* a, int B, int HW,
+                          int C, float pdrop, unsigned long long seed, unsigned sub, unsigned step, edm_stream_t stream);
+int edm_mod_silu_drop_bwd(const void* r, const float* lin, long lin_stride, const float* gain, const void* ga, void* gr,
+                          float* gm, float* glin, long glin_stride, float* ggain, int B, int HW, int C, float pdrop,
+                          unsigned long long seed, unsigned sub, unsigned step, edm_stream_t stream);
 int edm_dropout_mask(unsigned char* mask, long n, float pdrop, unsigned long long seed, unsigned sub, unsigned step,
                      edm_stream_t stream);
 /* 2x2 average pool / nearest-exact x2 (networks.py:80, 72); H,W = OUTPUT dims; scale folds the backward factors */

@@ -22,8 +22,8 @@ SIGNATURES = {
     "edm_silu_fwd": [P, P, L, P],
     "edm_silu_bwd": [P, P, P, F, P, L, P],
     "edm_axpby": [P, F, P, F, P, L, P],
-    "edm_mod_silu_drop_fwd": [P, P, P, P, I, I, I, F, U64, U, U, P],
-    "edm_mod_silu_drop_bwd": [P, P, P, P, P, P, P, P, I, I, I, F, U64, U, U, P],
+    "edm_mod_silu_drop_fwd": [P, P, L, P, P, I, I, I, F, U64, U, U, P],
+    "edm_mod_silu_drop_bwd": [P, P, L, P, P, P, P, P, L, P, I, I, I, F, U64, U, U, P],
     "edm_dropout_mask": [P, L, F, U64, U, U, P],
     "edm_pool2": [P, P, I, I, I, I, F, P],
     "edm_up2": [P, P, I, I, I, I, F, P],
@@ -66,6 +66,7 @@ SIGNATURES = {
     "edm_scale_f32": [P, F, P, L, P],
     # weights.hip
     "edm_weight_prep": [P, I, I, I, I, P, P, P, P, I, P],
+    "edm_weight_prep_multi": [P, P, I, I, P],
     "edm_wgrad_finish": [P, I, P, P, P, I, I, I, I, F, I, P],
 }
 _RET = {"edm_last_error": ctypes.c_char_p}

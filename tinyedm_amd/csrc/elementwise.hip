@@ -226,7 +226,7 @@ __device__ __forceinline__ bool keep_elem(uint32_t r, float p) { return u32_to_u
 
 __global__ void k_mod_silu_drop_fwd(const bf16* __restrict__ r, const float* __restrict__ lin,
                                     const float* __restrict__ gain, bf16* __restrict__ a, int HW, int C, long n8,
-                                    float pdrop, uint32_t seed_lo, uint32_t seed_hi, uint32_t sub, uint32_t step) {
+                                    long lin_stride, float pdrop, uint32_t seed_lo, uint32_t seed_hi, uint32_t sub, uint32_t step) {
   const int CL = C >> 3;
   const float g = *gain;
   const float keep_scale = pdrop > 0.f ? 1.0f / (1.0f - pdrop) : 1.0f;
@@ -236,7 +236,7 @@ __global__ void k_mod_silu_drop_fwd(const bf16* __restrict__ r, const float* __r
     const int b = (int)(pix / HW);
     float v[8];
     load8(r + i * 8, v);
-    const float* lp = lin + (long)b * C + c8 * 8;
+    const float* lp = lin + (long)b * lin_stride + c8 * 8;
     Philox4 r0, r1;
     if (pdrop > 0.f) {
       r0 = philox4x32_10((uint32_t)(2 * i), (uint32_t)((2 * i) >> 32), sub, step, seed_lo, seed_hi);
@@ -259,7 +259,7 @@ __global__ void k_mod_silu_drop_fwd(const bf16* __restrict__ r, const float* __r
 __global__ void k_mod_silu_drop_bwd(const bf16* __restrict__ r, const float* __restrict__ lin,
                                     const float* __restrict__ gain, const bf16* __restrict__ ga,
                                     bf16* __restrict__ gr, float* __restrict__ gm, int HW, int C, int PIXW,
-                                    float pdrop, uint32_t seed_lo, uint32_t seed_hi, uint32_t sub, uint32_t step) {
+                                    long lin_stride, float pdrop, uint32_t seed_lo, uint32_t seed_hi, uint32_t sub, uint32_t step) {
   extern __shared__ __attribute__((aligned(16))) float red[];
   const int CL = C >> 3;
   const int PS = blockDim.x / CL;
@@ -272,7 +272,7 @@ __global__ void k_mod_silu_drop_bwd(const bf16* __restrict__ r, const float* __r
   float m[8], acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    m[j] = lin[(long)b * C + c8 * 8 + j] * g + 1.0f;
+    m[j] = lin[(long)b * lin_stride + c8 * 8 + j] * g + 1.0f;
     acc[j] = 0.f;
   }
   for (int p = p_begin + ps; p < p_end; p += PS) {
@@ -308,13 +308,15 @@ __global__ void k_mod_silu_drop_bwd(const bf16* __restrict__ r, const float* __r
 // glin = gm*gain ; ggain += sum gm*lin
 __global__ void k_mod_finish(const float* __restrict__ gm, const float* __restrict__ lin,
                              const float* __restrict__ gain, float* __restrict__ glin, float* __restrict__ ggain,
-                             long n) {
+                             long n, int C, long lin_stride, long glin_stride) {
   const float g = *gain;
   float part = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / C;
+    const int c = (int)(i - b * C);
     float v = gm[i];
-    glin[i] = v * g;
-    part += v * lin[i];
+    glin[b * glin_stride + c] = v * g;
+    part += v * lin[b * lin_stride + c];
   }
   part = wave_sum(part);
   if ((threadIdx.x & 63) == 0) atomicAdd(ggain, part);
@@ -322,30 +324,34 @@ __global__ void k_mod_finish(const float* __restrict__ gm, const float* __restri
 
 static int block_for_chunks(int CL) { return (256 / CL) * CL; }
 
-extern "C" int edm_mod_silu_drop_fwd(const void* r, const float* lin, const float* gain, void* a, int B, int HW,
-                                     int C, float pdrop, unsigned long long seed, unsigned sub, unsigned step,
+// lin: row b starts at lin + b*lin_stride (lin_stride >= C: a column slice of the batched embed-linear output)
+extern "C" int edm_mod_silu_drop_fwd(const void* r, const float* lin, long lin_stride, const float* gain, void* a, int B,
+                                     int HW, int C, float pdrop, unsigned long long seed, unsigned sub, unsigned step,
                                      hipStream_t st) {
-  EDM_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && C > 0 && pdrop >= 0.f && pdrop < 1.f, "mod_silu_drop_fwd: bad args");
+  EDM_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && C > 0 && pdrop >= 0.f && pdrop < 1.f && lin_stride >= C,
+              "mod_silu_drop_fwd: bad args");
   long n8 = (long)B * HW * C / 8;
   hipLaunchKernelGGL(k_mod_silu_drop_fwd, dim3(grid_for(n8, 256)), dim3(256), 0, st, (const bf16*)r, lin, gain,
-                     (bf16*)a, HW, C, n8, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), sub, step);
+                     (bf16*)a, HW, C, n8, lin_stride, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), sub, step);
   EDM_CHECK_LAUNCH("mod_silu_drop_fwd");
   return EDM_OK;
 }
 
-// gm must be zero-filled [B,C] fp32 scratch; glin [B,C]; ggain device scalar accumulated (+=).
-extern "C" int edm_mod_silu_drop_bwd(const void* r, const float* lin, const float* gain, const void* ga, void* gr,
-                                     float* gm, float* glin, float* ggain, int B, int HW, int C, float pdrop,
-                                     unsigned long long seed, unsigned sub, unsigned step, hipStream_t st) {
-  EDM_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && C > 0 && C <= 1024, "mod_silu_drop_bwd: bad args");
+// gm must be zero-filled [B,C] fp32 scratch; glin rows at glin + b*glin_stride; ggain device scalar accumulated (+=).
+extern "C" int edm_mod_silu_drop_bwd(const void* r, const float* lin, long lin_stride, const float* gain,
+                                     const void* ga, void* gr, float* gm, float* glin, long glin_stride, float* ggain,
+                                     int B, int HW, int C, float pdrop, unsigned long long seed, unsigned sub,
+                                     unsigned step, hipStream_t st) {
+  EDM_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && C > 0 && C <= 1024 && lin_stride >= C && glin_stride >= C,
+              "mod_silu_drop_bwd: bad args");
   int CL = C / 8, block = block_for_chunks(CL), PS = block / CL;
   int PIXW = HW >= 256 ? 128 : HW;
   hipLaunchKernelGGL(k_mod_silu_drop_bwd, dim3(B, cdiv(HW, PIXW)), dim3(block), PS * C * sizeof(float), st,
-                     (const bf16*)r, lin, gain, (const bf16*)ga, (bf16*)gr, gm, HW, C, PIXW, pdrop, (uint32_t)seed,
-                     (uint32_t)(seed >> 32), sub, step);
+                     (const bf16*)r, lin, gain, (const bf16*)ga, (bf16*)gr, gm, HW, C, PIXW, lin_stride, pdrop,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), sub, step);
   EDM_CHECK_LAUNCH("mod_silu_drop_bwd");
   hipLaunchKernelGGL(k_mod_finish, dim3(grid_for((long)B * C, 256, 64)), dim3(256), 0, st, gm, lin, gain, glin,
-                     ggain, (long)B * C);
+                     ggain, (long)B * C, C, lin_stride, glin_stride);
   EDM_CHECK_LAUNCH("mod_finish");
   return EDM_OK;
 }

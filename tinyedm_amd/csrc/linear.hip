@@ -22,7 +22,12 @@ __global__ __launch_bounds__(256) void k_sgemm(const float* __restrict__ A, long
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = 0.f;
-  for (int k0 = 0; k0 < K; k0 += TK) {
+  // split-K over gridDim.z (partial sums are combined with float atomics; C pre-zeroed by the launcher)
+  const int kper = ((K + gridDim.z - 1) / gridDim.z + TK - 1) / TK * TK;
+  const int kbeg = blockIdx.z * kper;
+  const int kend = min(K, kbeg + kper);
+  K = kend;
+  for (int k0 = kbeg; k0 < K; k0 += TK) {
     for (int e = threadIdx.x; e < TM * TK; e += 256) {
       const int kk = e % TK, mm = e / TK;
       const int m = m0 + mm, k = k0 + kk;
@@ -55,7 +60,8 @@ __global__ __launch_bounds__(256) void k_sgemm(const float* __restrict__ A, long
       const int m = m0 + ty * 2 + i, n = n0 + tx * 2 + j;
       if (m < M && n < N) {
         float* c = C + m * csm + n * csn;
-        *c = accumulate ? *c + alpha * acc[i][j] : alpha * acc[i][j];
+        if (gridDim.z > 1) atomicAdd(c, alpha * acc[i][j]);
+        else *c = accumulate ? *c + alpha * acc[i][j] : alpha * acc[i][j];
       }
     }
 }
@@ -118,8 +124,17 @@ int sgemm(const float* A, long asm_, long ask, const float* B, long bsk, long bs
                        st, A, asm_, ask, B, bsk, bsn, C, csm, csn, M, N, K, alpha, accumulate);
     return 0;
   }
-  hipLaunchKernelGGL(k_sgemm, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, st, A, asm_, ask, B, bsk, bsn, C, csm,
-                     csn, M, N, K, alpha, accumulate);
+  int splits = 1;
+  const long tiles = (long)((N + 31) / 32) * ((M + 31) / 32);
+  if (K >= 1024 && tiles < 512 && csn == 1 && csm == N) {  // long-K, few tiles: split K to fill the chip
+    long sp = K / 256, cap = (1024 + tiles - 1) / tiles;
+    if (sp > cap) sp = cap;
+    if (sp > 32) sp = 32;
+    splits = (int)(sp < 1 ? 1 : sp);
+    if (splits > 1 && !accumulate) (void)hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), st);
+  }
+  hipLaunchKernelGGL(k_sgemm, dim3((N + 31) / 32, (M + 31) / 32, splits), dim3(256), 0, st, A, asm_, ask, B, bsk, bsn, C,
+                     csm, csn, M, N, K, alpha, accumulate);
   return 0;
 }
 

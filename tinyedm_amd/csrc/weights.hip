@@ -21,12 +21,10 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 }
 
 // one workgroup per packed output row r (master row mo = perm ? perm[r] : r)
-__global__ __launch_bounds__(256) void k_weight_prep(float* __restrict__ w, int O, int I, int taps, int Ipad,
-                                                       bf16* __restrict__ wp_fwd, bf16* __restrict__ wp_dgrad,
-                                                       float* __restrict__ w_hat, const int* __restrict__ perm,
-                                                       int normalize_inplace) {
-  __shared__ float red[8];
-  const int r = blockIdx.x;
+__device__ __forceinline__ void prep_row(float* __restrict__ w, int O, int I, int taps, int Ipad,
+                                         bf16* __restrict__ wp_fwd, bf16* __restrict__ wp_dgrad,
+                                         float* __restrict__ w_hat, const int* __restrict__ perm,
+                                         int normalize_inplace, int r, float* red) {
   const int mo = perm ? perm[r] : r;
   const int n = I * taps;
   float* row = w + (long)mo * n;
@@ -66,6 +64,30 @@ __global__ __launch_bounds__(256) void k_weight_prep(float* __restrict__ w, int 
   }
 }
 
+__global__ __launch_bounds__(256) void k_weight_prep(float* __restrict__ w, int O, int I, int taps, int Ipad,
+                                                       bf16* __restrict__ wp_fwd, bf16* __restrict__ wp_dgrad,
+                                                       float* __restrict__ w_hat, const int* __restrict__ perm,
+                                                       int normalize_inplace) {
+  __shared__ float red[8];
+  prep_row(w, O, I, taps, Ipad, wp_fwd, wp_dgrad, w_hat, perm, normalize_inplace, blockIdx.x, red);
+}
+
+// multi-tensor form: ONE launch prepares every weight of the network (136 tensors for the CIFAR-10 U-Net)
+struct PrepDesc {  // mirrored by tinyedm_amd/networks.py (64 bytes)
+  float* w;
+  bf16* fwd;
+  bf16* dgrad;
+  float* hat;
+  const int* perm;
+  int O, I, taps, Ipad, row0, pad_;
+};
+__global__ __launch_bounds__(256) void k_weight_prep_multi(const PrepDesc* __restrict__ descs,
+                                                             const int* __restrict__ row2desc, int normalize_inplace) {
+  __shared__ float red[8];
+  const PrepDesc d = descs[row2desc[blockIdx.x]];
+  prep_row(d.w, d.O, d.I, d.taps, d.Ipad, d.fwd, d.dgrad, d.hat, d.perm, normalize_inplace, blockIdx.x - d.row0, red);
+}
+
 // grad[mo, i, t] (=|+=) projection( scale * sum_s slabs[s, t, r, i] ) through w_hat = w/(d*sqrt(n))
 __global__ __launch_bounds__(256) void k_wgrad_finish(const float* __restrict__ slabs, int S, const float* __restrict__ w,
                                                         float* __restrict__ grad, const int* __restrict__ perm, int O,
@@ -78,7 +100,33 @@ __global__ __launch_bounds__(256) void k_wgrad_finish(const float* __restrict__ 
   const float* row = w + (long)mo * n;
   const long slab_stride = (long)taps * O * Ipad;
   float dot = 0.f, ss = 0.f;
-  // iterate in packed order (t major, i minor) for coalesced slab reads
+  // iterate in packed order (t major, i minor) for coalesced slab reads; 16-byte loads, 4 slabs in flight per lane
+  // (the pass is a pure HBM stream of S*n floats per row: bytes in flight per CU set its rate)
+  if ((I & 3) == 0 && (Ipad & 3) == 0) {
+    const int I4 = I >> 2;
+    for (int e4 = threadIdx.x; e4 < taps * I4; e4 += blockDim.x) {
+      const int t = e4 / I4, i = (e4 - t * I4) * 4;
+      const float* sp = slabs + ((long)t * O + r) * Ipad + i;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      int s = 0;
+      for (; s + 4 <= S; s += 4) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(sp + (s + u) * slab_stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a += v[u];
+      }
+      for (; s < S; ++s) a += *reinterpret_cast<const f32x4*>(sp + s * slab_stride);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float av = a[q] * scale;
+        const float wv = row[(i + q) * taps + t];
+        g[(i + q) * taps + t] = av;
+        dot += av * wv;
+        ss += wv * wv;
+      }
+    }
+  } else
   for (int e = threadIdx.x; e < n; e += blockDim.x) {
     const int t = e / I, i = e - t * I;
     const float* sp = slabs + ((long)t * O + r) * Ipad + i;
@@ -126,6 +174,18 @@ extern "C" int edm_weight_prep(float* w, int O, int I, int taps, int Ipad, void*
   hipLaunchKernelGGL(k_weight_prep, dim3(O), dim3(256), 0, st, w, O, I, taps, Ipad, (bf16*)wp_fwd, (bf16*)wp_dgrad,
                      w_hat, perm, normalize_inplace);
   EDM_CHECK_LAUNCH("weight_prep");
+  return EDM_OK;
+}
+
+// descs: device array of 64-byte records {w, fwd, dgrad, hat, perm (pointers), O, I, taps, Ipad, row0, pad (int32)};
+// row2desc: device int32 [total_rows], the record index of every packed output row (row0 = first row of the record).
+extern "C" int edm_weight_prep_multi(const void* descs, const int* row2desc, int total_rows, int normalize_inplace,
+                                     hipStream_t st) {
+  EDM_REQUIRE(descs && row2desc && total_rows > 0, "weight_prep_multi: bad args");
+  static_assert(sizeof(PrepDesc) == 64, "PrepDesc layout");
+  hipLaunchKernelGGL(k_weight_prep_multi, dim3(total_rows), dim3(256), 0, st, (const PrepDesc*)descs, row2desc,
+                     normalize_inplace);
+  EDM_CHECK_LAUNCH("weight_prep_multi");
   return EDM_OK;
 }
 

@@ -82,6 +82,9 @@ class _WNBase(nn.Module):
         w = self.weight
         if not w.is_cuda:
             raise RuntimeError("tinyedm_amd: parameters must live on the GPU (there is no CPU path)")
+        if self.training and getattr(self, "_fresh", False):  # prepared by this forward's multi-tensor launch
+            self._fresh = False
+            return self._cache
         key = (w.data_ptr(), w._version, _WEIGHT_EPOCH)
         if self.training or self._cache is None or self._cache_key != key:
             perm = self._perm
@@ -108,6 +111,55 @@ class _WNBase(nn.Module):
             return None
         g = ops.wgrad_finish(slabs, w.data, self._taps(), I, perm=self._perm, scale=scale)
         return g.view_as(w)
+
+
+class _PrepPlan:
+    """Multi-tensor weight preparation: ONE launch normalises and packs every weight of a network
+    (edm_weight_prep_multi) into persistent kernel-layout buffers, instead of one launch per layer."""
+
+    def __init__(self, mods):
+        self.mods = mods
+        dev = mods[0].weight.device
+        self.ptr_key = tuple(m.weight.data_ptr() for m in mods)
+        desc = np.zeros(len(mods), dtype=np.dtype([
+            ("w", "<u8"), ("fwd", "<u8"), ("dgrad", "<u8"), ("hat", "<u8"), ("perm", "<u8"),
+            ("O", "<i4"), ("I", "<i4"), ("taps", "<i4"), ("Ipad", "<i4"), ("row0", "<i4"), ("pad", "<i4")]))
+        assert desc.dtype.itemsize == 64
+        rows, row0 = [], 0
+        self.caches = []
+        for k, m in enumerate(mods):
+            w = m.weight
+            O, I, taps = w.shape[0], w.shape[1], m._taps()
+            ipad = I if m._ipad is None else m._ipad
+            wf = torch.empty(taps, O, ipad, device=dev, dtype=bf16) if "fwd" in m._want else None
+            wd = torch.empty(taps, I, O, device=dev, dtype=bf16) if "dgrad" in m._want else None
+            wh = torch.empty(O, I * taps, device=dev, dtype=f32) if "hat" in m._want else None
+            if m._perm is not None and m._perm.device != dev:
+                m._perm = m._perm.to(dev)
+            desc[k] = (w.data_ptr(), wf.data_ptr() if wf is not None else 0, wd.data_ptr() if wd is not None else 0,
+                       wh.data_ptr() if wh is not None else 0, m._perm.data_ptr() if m._perm is not None else 0,
+                       O, I, taps, ipad, row0, 0)
+            rows.append(np.full(O, k, dtype=np.int32))
+            row0 += O
+            self.caches.append((wf, wd, wh))
+        self.total_rows = row0
+        self.desc = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
+        self.row2desc = torch.from_numpy(np.concatenate(rows)).to(dev)
+        self.eval_key = None
+
+    def valid_for(self, mods):
+        return tuple(m.weight.data_ptr() for m in mods) == self.ptr_key
+
+    def run(self, training: bool):
+        key = (tuple(m.weight._version for m in self.mods), _WEIGHT_EPOCH)
+        if training or key != self.eval_key:
+            ops.weight_prep_multi(self.desc, self.row2desc, self.total_rows, training)
+            # the in-place normalisation does not go through torch: remember what the packs correspond to
+            self.eval_key = None if training else key
+        for m, c in zip(self.mods, self.caches):
+            m._cache = c
+            m._cache_key = (m.weight.data_ptr(), m.weight._version, _WEIGHT_EPOCH)
+            m._fresh = training
 
 
 class Conv2d(_WNBase):
@@ -447,13 +499,14 @@ class _ResBlockFn(torch.autograd.Function):
     -> conv3x3 -> mp_add with the skip path (networks.py:246-263 encoder / 312-327 decoder)."""
 
     @staticmethod
-    def forward(ctx, u, emb, w1x1, w1, w2, wemb, gain, blk):
+    def forward(ctx, u, emb, w1x1, w1, w2, wemb, gain, blk, lin_view, glin_view, token):
         enc = blk.is_encoder
         has1 = w1x1 is not None
         taps = 9
         wf1, wd1, _ = blk.conv_3x3_1.packs()
         wf2, wd2, _ = blk.conv_3x3_2.packs()
-        weh = blk.embed.packs()[2]
+        batched = lin_view is not None          # embed Linear evaluated for all blocks at once (_EmbedAllFn)
+        weh = None if batched else blk.embed.packs()[2]
         wd11 = None
         if enc:
             x = u
@@ -469,7 +522,7 @@ class _ResBlockFn(torch.autograd.Function):
             s = ops.silu_fwd(u)
             dsave = None
         r1 = ops.conv_igemm(s, wf1, taps)
-        lin = ops.linear_fwd(emb, weh)
+        lin = lin_view if batched else ops.linear_fwd(emb, weh)
         pdrop = blk.dropout_rate if blk.training else 0.0
         seed, sub, step = rng.seed, blk.rng_sub, rng.step
         a2 = ops.mod_silu_drop_fwd(r1, lin, gain, pdrop, seed, sub, step)
@@ -477,7 +530,9 @@ class _ResBlockFn(torch.autograd.Function):
         out = ops.conv_igemm(a2, wf2, taps, residual=xres, alpha=b, beta=a)
         ctx.blk, ctx.enc, ctx.has1 = blk, enc, has1
         ctx.drop = (pdrop, seed, sub, step)
-        ctx.save_for_backward(u, xres if enc else None, dsave, s, r1, lin, a2, emb, gain, wd1, wd2, wd11, weh)
+        ctx.batched, ctx.glin_view = batched, glin_view
+        ctx.save_for_backward(u, xres if enc else None, dsave, s, r1, lin, a2, None if batched else emb, gain, wd1, wd2,
+                              wd11, weh)
         return out
 
     @staticmethod
@@ -489,10 +544,17 @@ class _ResBlockFn(torch.autograd.Function):
         a, b = _mp_coeffs(blk.add_factor)
         ga2 = ops.conv_igemm(gout, wd2, 9, alpha=b)
         gw2 = blk.conv_3x3_2.finish_grad(ops.conv_wgrad(a2, gout, 9), scale=b)
-        gr1, glin, ggain = ops.mod_silu_drop_bwd(r1, lin, gain, ga2, pdrop, seed, sub, step)
-        dweh = ops.linear_wgrad(glin, emb)
-        gwemb = blk.embed.finish_grad(dweh.view(1, 1, *dweh.shape))
-        gemb = ops.linear_dgrad(glin, weh) if ctx.needs_input_grad[1] else None
+        gwemb = gemb = gtoken = None
+        if ctx.batched:
+            # d loss / d lin goes into this block's column slice of the shared buffer; _EmbedAllFn.backward turns
+            # the whole buffer into the embed-weight and embedding gradients with two GEMMs
+            gr1, _, ggain = ops.mod_silu_drop_bwd(r1, lin, gain, ga2, pdrop, seed, sub, step, glin_out=ctx.glin_view)
+            gtoken = torch.zeros(1, device=gout.device, dtype=f32)
+        else:
+            gr1, glin, ggain = ops.mod_silu_drop_bwd(r1, lin, gain, ga2, pdrop, seed, sub, step)
+            dweh = ops.linear_wgrad(glin, emb)
+            gwemb = blk.embed.finish_grad(dweh.view(1, 1, *dweh.shape))
+            gemb = ops.linear_dgrad(glin, weh) if ctx.needs_input_grad[1] else None
         gs = ops.conv_igemm(gr1, wd1, 9)
         gw1 = blk.conv_3x3_1.finish_grad(ops.conv_wgrad(s, gr1, 9))
         gw11 = None
@@ -510,7 +572,7 @@ class _ResBlockFn(torch.autograd.Function):
                 gw11 = blk.conv_1x1.finish_grad(ops.conv_wgrad(u, gout, 1), scale=a)
             else:
                 gu = ops.silu_bwd(u, gs, gout, a)
-        return gu, gemb, gw11, gw1, gw2, gwemb, ggain, None
+        return gu, gemb, gw11, gw1, gw2, gwemb, ggain, None, None, None, gtoken
 
 
 _rng_sub_counter = [0]
@@ -528,10 +590,15 @@ class _BlockBase(nn.Module):
         _rng_sub_counter[0] += 1
         self.rng_sub = _rng_sub_counter[0]
 
-    def _res(self, u: Tensor, embedding: Tensor) -> Tensor:
+    def _res(self, u: Tensor, embedding: Tensor, lin=None) -> Tensor:
         w11 = self.conv_1x1.weight if isinstance(self.conv_1x1, Conv2d) else None
-        out = _ResBlockFn.apply(u, embedding, w11, self.conv_3x3_1.weight, self.conv_3x3_2.weight, self.embed.weight,
-                                self.gain, self)
+        if lin is None:
+            out = _ResBlockFn.apply(u, embedding, w11, self.conv_3x3_1.weight, self.conv_3x3_2.weight,
+                                    self.embed.weight, self.gain, self, None, None, None)
+        else:
+            lin_view, glin_view, token = lin
+            out = _ResBlockFn.apply(u, None, w11, self.conv_3x3_1.weight, self.conv_3x3_2.weight, None, self.gain,
+                                    self, lin_view, glin_view, token)
         if isinstance(self.attention, CosineAttention):
             out = self.attention.forward_nhwc(out)
         return out
@@ -563,11 +630,11 @@ class EncoderBlock(_BlockBase):
         self.conv_3x3_1 = Conv2d(out_channels, out_channels, 3)
         self._common(out_channels, embedding_dim, attention, num_heads, dropout_rate)
 
-    def forward(self, input: Tensor, embedding: Tensor) -> Tensor:
+    def forward(self, input: Tensor, embedding: Tensor, _lin=None) -> Tensor:
         x, conv = _as_nhwc(input)
         if isinstance(self.resample, DownSample):
             x = _ResampleFn.apply(x, False)
-        out = self._res(x, _emb32(embedding, x.shape[0]))
+        out = self._res(x, None if _lin is not None else _emb32(embedding, x.shape[0]), _lin)
         return ops.nhwc_bf16_to_nchw(out).to(input.dtype) if conv else _tag(out)
 
 
@@ -587,7 +654,7 @@ class DecoderBlock(_BlockBase):
         self.conv_3x3_1 = Conv2d(total, out_channels, 3)
         self._common(out_channels, embedding_dim, attention, num_heads, dropout_rate)
 
-    def forward(self, input: Tensor, embedding: Tensor, skip: Tensor | None = None) -> Tensor:
+    def forward(self, input: Tensor, embedding: Tensor, skip: Tensor | None = None, _lin=None) -> Tensor:
         x, conv = _as_nhwc(input)
         if skip is not None:
             assert self.cat_factor is not None
@@ -595,7 +662,7 @@ class DecoderBlock(_BlockBase):
             x = _ConcatGateFn.apply(x, sk, self.cat_factor.layer1.weight, self.cat_factor.layer2.weight, self.cat_factor)
         if isinstance(self.resample, UpSample):
             x = _ResampleFn.apply(x, True)
-        out = self._res(x, _emb32(embedding, x.shape[0]))
+        out = self._res(x, None if _lin is not None else _emb32(embedding, x.shape[0]), _lin)
         return ops.nhwc_bf16_to_nchw(out).to(input.dtype) if conv else _tag(out)
 
 
@@ -663,6 +730,39 @@ def build_decoder_blocks(block_types, out_channels, skip_channels, **kwargs):
 # --------------------------------------------------------------------------------------
 # Denoiser (networks.py:490-605)
 # --------------------------------------------------------------------------------------
+class _EmbedAllFn(torch.autograd.Function):
+    """The per-block embed Linears (networks.py:256, 320) of ALL blocks as one fp32 GEMM: emb (B,E) x Wcat^T
+    (E, sum C) -> lin_all (B, sum C).  Blocks read/write column slices; their d loss / d lin lands in a shared
+    buffer, and this node's backward (which autograd runs after every block, via the scalar `token` edge) turns
+    it into all embed-weight gradients and d loss / d emb with two more GEMMs."""
+
+    @staticmethod
+    def forward(ctx, emb, den, *weights):
+        blocks = den._res_blocks()
+        whs = [b.embed.packs()[2] for b in blocks]
+        wcat = torch.cat(whs, 0)
+        lin_all = ops.linear_fwd(emb, wcat)
+        glin_all = torch.zeros_like(lin_all)
+        ctx.den, ctx.glin_all = den, glin_all
+        ctx.save_for_backward(emb, wcat)
+        token = torch.zeros(1, device=emb.device, dtype=f32)
+        ctx.mark_non_differentiable(lin_all, glin_all)
+        return lin_all, glin_all, token
+
+    @staticmethod
+    def backward(ctx, _g1, _g2, _gtoken):
+        emb, wcat = ctx.saved_tensors
+        glin_all = ctx.glin_all
+        dw = ops.linear_wgrad(glin_all, emb)                    # (sum C, E)
+        gemb = ops.linear_dgrad(glin_all, wcat) if ctx.needs_input_grad[0] else None
+        gws, off = [], 0
+        for b in ctx.den._res_blocks():
+            C = b.embed.weight.shape[0]
+            gws.append(b.embed.finish_grad(dw[off:off + C].view(1, 1, C, -1)))
+            off += C
+        return (gemb, None, *gws)
+
+
 class _ConvInFn(torch.autograd.Function):
     """c_in * noisy, ones channel, conv_in 3x3 (networks.py:584-587); input padded to 32 channels."""
 
@@ -760,21 +860,42 @@ class Denoiser(nn.Module):
         self.embedding_dim = embedding_dim
         self.num_heads = num_heads
 
+    def _res_blocks(self):
+        return list(self.encoder_blocks) + list(self.decoder_blocks)
+
+    def _prep_all(self):
+        """One multi-tensor launch for every weight of the U-Net (forced normalisation in training + packs)."""
+        mods = [m for m in self.modules() if isinstance(m, _WNBase)]
+        plan = getattr(self, "_plan", None)
+        if plan is None or not plan.valid_for(mods):
+            plan = self._plan = _PrepPlan(mods)
+        plan.run(self.training)
+
     def forward(self, noisy_image: Tensor, sigma: Tensor, embedding: Tensor):
         if not noisy_image.is_cuda:
             raise RuntimeError("tinyedm_amd.Denoiser: inputs must be GPU tensors (there is no CPU path)")
+        with torch.no_grad():
+            self._prep_all()
         noisy = noisy_image.float().contiguous()
         B = noisy.shape[0]
         sig = sigma.detach().float().flatten().contiguous()
         emb = _emb32(embedding, B)
 
+        blocks = self._res_blocks()
+        lin_all, glin_all, token = _EmbedAllFn.apply(emb, self, *[b.embed.weight for b in blocks])
+        lins, off = {}, 0
+        for b in blocks:
+            C = b.embed.weight.shape[0]
+            lins[b] = (lin_all[:, off:off + C], glin_all[:, off:off + C], token)
+            off += C
+
         x = _ConvInFn.apply(noisy, sig, self.conv_in.weight, self)
         skips = [x]
         for block in self.encoder_blocks:
-            x = block(_tag(x), emb)
+            x = block(_tag(x), None, _lin=lins[block])
             skips.append(x)
         for block, has_skip in zip(self.decoder_blocks, self.skip_connections):
-            x = block(_tag(x), emb, _tag(skips.pop())) if has_skip else block(_tag(x), emb)
+            x = block(_tag(x), None, _tag(skips.pop()) if has_skip else None, _lin=lins[block])
         D = _ConvOutFn.apply(x, self.conv_out.weight, self.gain_out, noisy, sig, self)
         if self.training:
             rng.step += 1

@@ -111,26 +111,37 @@ def axpby(a, alpha, b=None, beta=0.0):
     return out
 
 
+def _lin_view(lin, B, C, name):
+    """(B, C) fp32 view whose rows may be strided (a column slice of the batched embed-linear output)."""
+    if not lin.is_cuda or lin.dtype != f32 or lin.dim() != 2 or tuple(lin.shape) != (B, C) or lin.stride(1) != 1:
+        raise ValueError(f"{name}: expected a (B={B}, C={C}) fp32 GPU tensor with unit column stride")
+    if lin.stride(0) < C:
+        raise ValueError(f"{name}: row stride {lin.stride(0)} < C={C}")
+    return lin.stride(0)
+
+
 def mod_silu_drop_fwd(r, lin, gain, pdrop, seed, sub, step):
     B, H, W, C = _nhwc(r, "r")
-    _chk(lin, f32, "lin", (B, C))
+    ls = _lin_view(lin, B, C, "lin")
     _chk(gain, f32, "gain")
     a = torch.empty_like(r)
-    _lib.call("edm_mod_silu_drop_fwd", _p(r), _p(lin), _p(gain), _p(a), B, H * W, C, float(pdrop), int(seed), int(sub),
+    _lib.call("edm_mod_silu_drop_fwd", _p(r), _p(lin), ls, _p(gain), _p(a), B, H * W, C, float(pdrop), int(seed), int(sub),
               int(step), _stream())
     return a
 
 
-def mod_silu_drop_bwd(r, lin, gain, ga, pdrop, seed, sub, step):
+def mod_silu_drop_bwd(r, lin, gain, ga, pdrop, seed, sub, step, glin_out=None):
+    """glin_out: optional (B, C) strided fp32 view to receive d loss / d lin (else a fresh tensor)."""
     B, H, W, C = _nhwc(r, "r")
-    _chk(lin, f32, "lin", (B, C))
+    ls = _lin_view(lin, B, C, "lin")
     _chk(ga, bf16, "ga", r.shape)
     gr = torch.empty_like(r)
     gm = torch.zeros(B, C, device=r.device, dtype=f32)
-    glin = torch.empty(B, C, device=r.device, dtype=f32)
+    glin = torch.empty(B, C, device=r.device, dtype=f32) if glin_out is None else glin_out
+    gs = _lin_view(glin, B, C, "glin")
     ggain = torch.zeros((), device=r.device, dtype=f32)
-    _lib.call("edm_mod_silu_drop_bwd", _p(r), _p(lin), _p(gain), _p(ga), _p(gr), _p(gm), _p(glin), _p(ggain), B, H * W, C,
-              float(pdrop), int(seed), int(sub), int(step), _stream())
+    _lib.call("edm_mod_silu_drop_bwd", _p(r), _p(lin), ls, _p(gain), _p(ga), _p(gr), _p(gm), _p(glin), gs, _p(ggain), B,
+              H * W, C, float(pdrop), int(seed), int(sub), int(step), _stream())
     return gr, glin, ggain
 
 
@@ -355,6 +366,15 @@ def weight_prep(w, taps, Ipad=None, want_fwd=True, want_dgrad=True, want_hat=Fal
     _lib.call("edm_weight_prep", _p(w), O, I, taps, Ipad, _p(wf), _p(wd), _p(wh), _p(perm), int(normalize_inplace),
               _stream())
     return wf, wd, wh
+
+
+def weight_prep_multi(desc, row2desc, total_rows, normalize_inplace):
+    """desc: uint8 tensor of 64-byte PrepDesc records (see csrc/weights.hip), row2desc: int32 [total_rows]."""
+    _chk(desc, torch.uint8, "desc")
+    _chk(row2desc, torch.int32, "row2desc", (total_rows,))
+    if desc.numel() % 64:
+        raise ValueError("weight_prep_multi: descriptor table must be a multiple of 64 bytes")
+    _lib.call("edm_weight_prep_multi", _p(desc), _p(row2desc), int(total_rows), int(bool(normalize_inplace)), _stream())
 
 
 def wgrad_finish(slabs, w, taps, I, perm=None, scale=1.0, out=None):
