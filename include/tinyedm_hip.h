@@ -45,6 +45,9 @@ int edm_conv_igemm_v2_ablate(const void* X, const void* Wp, void* Y, int B, int 
 int edm_conv_wgrad_nsplit(int B, int H, int W, int Cin, int Cout, int taps);
 int edm_conv_wgrad(const void* X, const void* dY, float* slabs, int B, int H, int W, int Cin, int Cout, int taps,
                    int nsplit, edm_stream_t stream);
+/* second-generation weight-gradient kernel, same contract (LDS-DMA staging, rolling X window); -3 = not covered */
+int edm_conv_wgrad_v2(const void* X, const void* dY, float* slabs, int B, int H, int W, int Cin, int Cout, int taps,
+                      int nsplit, edm_stream_t stream);
 
 /* ---------------------------------------------------------------- weights (networks.py:17-19, 32-36, 55-59) */
 /* forced weight normalisation (in place when normalize_inplace) + effective weight w/(eps+|w|/sqrt(n))/sqrt(n),

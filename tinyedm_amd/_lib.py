@@ -46,6 +46,7 @@ SIGNATURES = {
     "edm_conv_igemm_v2_ablate": [P, P, P, I, I, I, I, I, I, P],
     "edm_conv_wgrad_nsplit": [I, I, I, I, I, I],
     "edm_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, P],
+    "edm_conv_wgrad_v2": [P, P, P, I, I, I, I, I, I, I, P],
     # attention.hip
     "edm_attention_fwd": [P, P, I, I, I, I, P],
     "edm_attention_bwd": [P, P, P, P, I, I, I, I, P],

@@ -28,12 +28,12 @@ struct Cfg {
   static constexpr int CPR = KC / 8;        // 16-B chunks per row
 };
 
-template <int TAPS, int KC, int XL>
+template <int TAPS, int KC, int XL, int NJ = 2>  // NJ = 32-pixel blocks per wave: tile = (64*NJ) pixels x 128 channels
 __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ X, const bf16* __restrict__ Wp,
                                                          bf16* __restrict__ Y, const bf16* __restrict__ R,
                                                          float alpha, float beta, int Npix, int H, int W, int Cin,
                                                          int Cout, int tiles_m, int tiles_n) {
-  constexpr int BM = 128, BN = 128;
+  constexpr int BM = 64 * NJ, BN = 128;
   constexpr int ROWB = Cfg<KC>::ROWB, CPR = Cfg<KC>::CPR;
   constexpr int WL = BN * CPR / 256;  // W loads per thread
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -55,11 +55,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ 
   const int l31 = lane & 31, lhi = lane >> 5;
 
   // ---- per-lane tap masks for the two pixel blocks this wave multiplies
-  unsigned mask[2];
-  int brow[2];
+  unsigned mask[NJ];
+  int brow[NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int ml = wn * 64 + j * 32 + l31;
+  for (int j = 0; j < NJ; ++j) {
+    const int ml = wn * (32 * NJ) + j * 32 + l31;
     const int m = m0 + ml;
     brow[j] = ml + HALO;
     unsigned mk = 0;
@@ -76,11 +76,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ 
     mask[j] = mk;
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -151,21 +151,24 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ 
     // ---- MFMA over this tap's KC-deep slice
     const int toff = (TAPS == 9) ? ((tap / 3 - 1) * W + (tap % 3 - 1)) : 0;
     const char* wbase = Ws + (t & 1) * (BN * ROWB) + (wm * 64 + l31) * ROWB + lhi * 16;
-    const char* xb0 = Xs + (brow[0] + toff) * ROWB + lhi * 16;
-    const char* xb1 = Xs + (brow[1] + toff) * ROWB + lhi * 16;
-    const bool v0 = (mask[0] >> tap) & 1, v1 = (mask[1] >> tap) & 1;
+    const char* xb[NJ];
+    bool vv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      xb[j] = Xs + (brow[j] + toff) * ROWB + lhi * 16;
+      vv[j] = (mask[j] >> tap) & 1;
+    }
 #pragma unroll
     for (int ks = 0; ks < KC / 16; ++ks) {
       bf16x8 a0 = *reinterpret_cast<const bf16x8*>(wbase + ks * 32);
       bf16x8 a1 = *reinterpret_cast<const bf16x8*>(wbase + 32 * ROWB + ks * 32);
-      bf16x8 b0 = *reinterpret_cast<const bf16x8*>(xb0 + ks * 32);
-      bf16x8 b1 = *reinterpret_cast<const bf16x8*>(xb1 + ks * 32);
-      b0 = v0 ? b0 : zero8;
-      b1 = v1 ? b1 : zero8;
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        bf16x8 b = *reinterpret_cast<const bf16x8*>(xb[j] + ks * 32);
+        b = vv[j] ? b : zero8;
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[1][j], 0, 0, 0);
+      }
     }
     tap = ntap;
     chunk = nchunk;
@@ -173,8 +176,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ 
 
   // ---- epilogue: lane holds, per (i,j), pixel = col(l31) and 4x4 consecutive output channels
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const long m = (long)m0 + wn * 64 + j * 32 + l31;
+  for (int j = 0; j < NJ; ++j) {
+    const long m = (long)m0 + wn * (32 * NJ) + j * 32 + l31;
     if (m >= Npix) continue;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -200,16 +203,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ 
   }
 }
 
-template <int TAPS, int KC, int XL>
+template <int TAPS, int KC, int XL, int NJ = 2>
 int launch(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int Npix, int H, int W,
            int Cin, int Cout, hipStream_t st) {
-  constexpr int BM = 128, BN = 128;
+  constexpr int BM = 64 * NJ, BN = 128;
   const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + BN - 1) / BN;
   const int HALO = (TAPS == 9) ? (W + 1) : 0;
   const int xrows = BM + 2 * HALO;
   const size_t lds = ((xrows * Cfg<KC>::ROWB + 15) & ~15) + 2 * BN * Cfg<KC>::ROWB;
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
-  auto kern = k_conv_igemm<TAPS, KC, XL>;
+  auto kern = k_conv_igemm<TAPS, KC, XL, NJ>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -232,6 +235,14 @@ extern "C" int edm_conv_igemm(const void* X, const void* Wp, void* Y, const void
   EDM_REQUIRE(Cout > 0 && Cout % 8 == 0, "conv_igemm: Cout=%d must be a multiple of 8", Cout);
   EDM_REQUIRE(W <= 64 || taps == 1, "conv_igemm: W=%d > 64 unsupported for 3x3", W);
   const int Npix = B * H * W;
+  // small feature maps (fewer than ~1.5 tiles per CU at 128 pixels): halve the pixel tile to fill the chip
+  const long tiles128 = (long)((Npix + 127) / 128) * ((Cout + 127) / 128);
+  if (Cin % 64 == 0 && tiles128 < 384 && W <= 30) {
+    if (taps == 1) launch<1, 64, 2, 1>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st);
+    else launch<9, 64, 4, 1>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st);   // (64 + 2*(W+1)) * 8 <= 1024 chunks
+    EDM_CHECK_LAUNCH("conv_igemm");
+    return EDM_OK;
+  }
   const int xrows = 128 + (taps == 9 ? 2 * (W + 1) : 0);
   if (Cin % 64 == 0) {
     const int need = (xrows * 8 + 255) / 256;

@@ -1,0 +1,274 @@
+// Weight-gradient convolution, second generation: same math and slab interface as conv_wgrad.hip
+// ("zero-padded flat K" + transposing LDS reads), rebuilt around the CDNA4 async global->LDS path.
+//
+//   dWp[tap, co, ci] = sum_p dY[p, co] * X[p + off(tap), ci]          (fp32, split-K slabs)
+//
+// What changed against generation 1 (0.51 PFLOP/s; 40 % of wave time parked on vmcnt/barrier, every
+// 64-row stage re-staged its 2x34-row halo, staging went HBM -> VGPR -> ds_write with per-row decode):
+//  * both operands are staged by `global_load_lds_dwordx4` (LDS-DMA), 16 rows x 64 B per wave-instruction,
+//    straight into the [rows][32 ch] images the transposing reads want; pad rows read a zero page;
+//  * X lives in a rolling LDS window (4 stage slots + 2 mirror slots so every 3x3 window is contiguous):
+//    each 64-row stage loads only its 64 NEW rows (was 132): -52 % X traffic, -35 % total;
+//  * dY stage t+2 and X stage t+3 are issued while stage t computes; counted `s_waitcnt vmcnt(2)` + raw
+//    `s_barrier` keep the younger stage in flight across the barrier;
+//  * one padded-row decode per lane per stage serves BOTH operands (dY stage t+2 and X stage t+3 are the
+//    same padded rows).
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short short4v;
+typedef __attribute__((ext_vector_type(8))) short short8v;
+typedef short4v __attribute__((address_space(3))) * lds_s4p;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int KP = 64;                 // padded rows per stage
+constexpr int SUBB = KP * 64;          // bytes of one [64 rows][32 ch] sub-image stage
+constexpr int DYRING = 3, XSLOTS = 6;  // dY stages in flight; X: 4 ring slots + 2 mirrors
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
+  short4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(p0));
+  short4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(p1));
+  short8v c = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, c);
+}
+__device__ __forceinline__ void dma16(const void* src, char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_dst, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+struct Geo {  // padded flat-K geometry (host-computed)
+  int PW, PH, lead_rows, kmult;
+  long kbeg0, kend;
+};
+
+template <int TAPS>
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad2(const bf16* __restrict__ X, const bf16* __restrict__ dY,
+                                                          float* __restrict__ slabs, const bf16* __restrict__ zeros,
+                                                          int B, int H, int W, int Cin, int Cout, int tiles_ci, long L,
+                                                          Geo g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* dYb = smem;                          // [DYRING][2 sub][64 rows][64 B]
+  char* Xb = smem + DYRING * 2 * SUBB;       // [2 sub][XSLOTS][64 rows][64 B]
+  const int PW = g.PW, PH = g.PH;
+  const int HALOX = (TAPS == 9) ? PW + 1 : 0;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tco = blockIdx.x / tiles_ci, tci = blockIdx.x % tiles_ci;
+  const int s = blockIdx.y;
+  const int co0 = tco * 64, ci0 = tci * 64;
+  const int cb = wave & 1, ib = wave >> 1;  // this wave's 32x32 (co, ci) block
+  const long ks0 = g.kbeg0 + (long)s * L;
+  const long ks1 = (ks0 + L < g.kend) ? ks0 + L : g.kend;
+  const int nst = (ks1 > ks0) ? (int)((ks1 - ks0 + KP - 1) / KP) : 0;
+  const long Npix = (long)B * H * W;
+
+  // ---- per-lane decode state of the padded row this lane stages: row = base + 16*wave + (lane>>2)
+  const int drow = lane >> 2, dp = lane & 3;
+  long kp = ks0 - KP + wave * 16 + drow;  // rows of X stage 0 (one stage of lead-in before the split)
+  int sw, sh, sn;                         // (w, h, n) of kp  [TAPS==9]
+  if (TAPS == 9) {
+    const long R = kp / PW;
+    sw = (int)(kp - R * PW);
+    const long r2 = R - g.lead_rows + (long)g.kmult * PH;
+    sn = (int)(r2 / PH) - g.kmult;
+    sh = (int)(r2 % PH);
+  } else {
+    sw = sh = sn = 0;
+  }
+  const int adv_w = KP % PW, adv_h = KP / PW;
+  auto advance = [&]() {
+    kp += KP;
+    if (TAPS == 9) {
+      sw += adv_w;
+      sh += adv_h;
+      if (sw >= PW) { sw -= PW; sh += 1; }
+      while (sh >= PH) { sh -= PH; sn += 1; }
+    }
+  };
+  auto pixel = [&](bool& valid) -> long {
+    if (TAPS == 9) {
+      valid = sn >= 0 && sn < B && sh < H && sw < W;
+      return ((long)sn * H + sh) * W + sw;
+    } else {
+      const long p = kp - KP;
+      valid = p >= 0 && p < Npix;
+      return p;
+    }
+  };
+  // stage X stage j (and its mirror) / dY stage t from the CURRENT decode state
+  auto issue_x = [&](int j) {
+    bool valid;
+    const long pix = pixel(valid);
+    const int slot = j & 3;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int ci = ci0 + sub * 32;
+      const bf16* src = (valid && ci < Cin) ? X + pix * Cin + ci + dp * 8 : zeros;
+      dma16(src, Xb + sub * (XSLOTS * SUBB) + slot * SUBB + wave * 1024);
+      if (TAPS == 9 && slot < 2) dma16(src, Xb + sub * (XSLOTS * SUBB) + (4 + slot) * SUBB + wave * 1024);
+    }
+  };
+  auto issue_dy = [&](int t) {
+    bool valid;
+    const long pix = pixel(valid);
+    valid = valid && kp < ks1;
+    const int buf = t % DYRING;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int co = co0 + sub * 32;
+      const bf16* src = (valid && co < Cout) ? dY + pix * Cout + co + dp * 8 : zeros;
+      dma16(src, dYb + buf * (2 * SUBB) + sub * SUBB + wave * 1024);
+    }
+  };
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int krow_l = 8 * (lane >> 5) + ((lane & 15) >> 2);
+  const int chan_b = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  const bool wave_active = (co0 + cb * 32 < Cout) && (ci0 + ib * 32 < Cin);
+
+  if (nst > 0) {
+    // ---- prologue, issue order X(0) X(1) X(2) dY(0) dY(1): dY stage t shares its rows with X stage t+1
+    issue_x(0);
+    advance();
+    issue_x(1);
+    // remember the state of stage-1 rows for dY(0): re-derive by issuing dY(0) before advancing further is not
+    // possible (order!), so keep a copy of the decode state
+    const long kp1 = kp;
+    const int w1 = sw, h1 = sh, n1 = sn;
+    advance();
+    issue_x(2);
+    const long kp2 = kp;
+    const int w2 = sw, h2 = sh, n2 = sn;
+    kp = kp1; sw = w1; sh = h1; sn = n1;
+    issue_dy(0);
+    kp = kp2; sw = w2; sh = h2; sn = n2;
+    if (nst > 1) issue_dy(1);
+  }
+
+  for (int t = 0; t < nst; ++t) {
+    // ---- retire dY(t) and X(t+2); dY(t+1) (2 DMAs per wave, issued last) may stay in flight
+    if (t + 1 < nst) wait_vmcnt<2>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    // ---- issue X(t+3) then dY(t+2): the same padded rows
+    if (t + 3 <= nst + 1) {
+      advance();
+      issue_x(t + 3);
+      if (t + 2 < nst) issue_dy(t + 2);
+    }
+    // ---- 36 (or 4) MFMAs over this stage
+    if (wave_active) {
+      const int slot = (t + 1) & 3;
+      const int base_row = ((TAPS == 9 && slot == 0) ? 4 : slot) * KP;
+      const char* abase = dYb + (t % DYRING) * (2 * SUBB) + cb * SUBB + krow_l * 64 + chan_b;
+      const char* bbase = Xb + ib * (XSLOTS * SUBB) + (base_row + krow_l) * 64 + chan_b;
+#pragma unroll 1
+      for (int ks = 0; ks < KP / 16; ++ks) {
+        bf16x8 a = tr_frag(abase + ks * 16 * 64, abase + ks * 16 * 64 + 4 * 64);
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) {
+          const int off = (TAPS == 9) ? ((tp / 3 - 1) * PW + (tp % 3 - 1)) : 0;
+          const char* bp = bbase + (ks * 16 + off) * 64;
+          bf16x8 b = tr_frag(bp, bp + 4 * 64);
+          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[tp], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- store the wave's 9 (or 1) 32x32 fp32 blocks into this split's slab
+  if (wave_active) {
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int ci = ci0 + ib * 32 + l31;
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) {
+      float* base = slabs + (((long)s * TAPS + tp) * Cout) * Cin;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        base[(long)co * Cin + ci] = acc[tp][r];
+      }
+    }
+  }
+  (void)HALOX;
+}
+
+bf16* g_zero_page_w = nullptr;
+
+Geo make_geo(int B, int H, int W, int taps) {
+  Geo g;
+  if (taps == 9) {
+    g.PW = W + 1;
+    g.PH = H + 1;
+    g.lead_rows = 2 + (KP + g.PW - 1) / g.PW;
+    g.kmult = (g.lead_rows + g.PH - 1) / g.PH;
+    g.kbeg0 = (long)(g.lead_rows - 1) * g.PW + 1;
+    g.kend = ((long)g.lead_rows + (long)B * g.PH) * g.PW;
+  } else {
+    g.PW = W;
+    g.PH = H;
+    g.lead_rows = 0;
+    g.kmult = 0;
+    g.kbeg0 = KP;
+    g.kend = KP + (long)B * H * W;
+  }
+  return g;
+}
+
+}  // namespace
+
+// Same contract as edm_conv_wgrad (the same edm_conv_wgrad_nsplit value sizes the slab workspace); returns -3 for
+// shapes outside its coverage (3x3 with W > 62).
+extern "C" int edm_conv_wgrad_nsplit(int B, int H, int W, int Cin, int Cout, int taps);
+extern "C" int edm_conv_wgrad_v2(const void* X, const void* dY, float* slabs, int B, int H, int W, int Cin, int Cout,
+                                 int taps, int nsplit, hipStream_t st) {
+  EDM_REQUIRE(X && dY && slabs, "conv_wgrad_v2: null pointer");
+  EDM_REQUIRE(taps == 1 || taps == 9, "conv_wgrad_v2: taps must be 1 or 9");
+  EDM_REQUIRE(B > 0 && H > 0 && W > 0 && (long)B * (H + 1) * (W + 1) < (1L << 30), "conv_wgrad_v2: bad B/H/W");
+  EDM_REQUIRE(Cin > 0 && Cin % 32 == 0 && Cout > 0 && Cout % 32 == 0, "conv_wgrad_v2: Cin, Cout must be multiples of 32");
+  EDM_REQUIRE(nsplit == edm_conv_wgrad_nsplit(B, H, W, Cin, Cout, taps), "conv_wgrad_v2: nsplit mismatch");
+  if (taps == 9 && W + 2 > KP) return EDM_ERR_UNSUPPORTED;
+  if (!g_zero_page_w) {
+    if (hipMalloc((void**)&g_zero_page_w, 256) != hipSuccess || hipMemset(g_zero_page_w, 0, 256) != hipSuccess) {
+      edm_set_error("conv_wgrad_v2: cannot allocate the zero page");
+      return EDM_ERR_LAUNCH;
+    }
+  }
+  const Geo g = make_geo(B, H, W, taps);
+  long L = (g.kend - g.kbeg0 + nsplit - 1) / nsplit;
+  L = (L + KP - 1) / KP * KP;
+  const int tiles_co = (Cout + 63) / 64, tiles_ci = (Cin + 63) / 64;
+  const size_t lds = (size_t)DYRING * 2 * SUBB + (size_t)2 * XSLOTS * SUBB;
+  if (taps == 9) {
+    auto kern = k_conv_wgrad2<9>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles_co * tiles_ci, nsplit), dim3(256), lds, st, (const bf16*)X, (const bf16*)dY,
+                       slabs, (const bf16*)g_zero_page_w, B, H, W, Cin, Cout, tiles_ci, L, g);
+  } else {
+    auto kern = k_conv_wgrad2<1>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles_co * tiles_ci, nsplit), dim3(256), lds, st, (const bf16*)X, (const bf16*)dY,
+                       slabs, (const bf16*)g_zero_page_w, B, H, W, Cin, Cout, tiles_ci, L, g);
+  }
+  EDM_CHECK_LAUNCH("conv_wgrad_v2");
+  return EDM_OK;
+}

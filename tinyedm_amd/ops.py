@@ -333,6 +333,9 @@ def conv_igemm(x, wp, taps, residual=None, alpha=1.0, beta=0.0):
     return y
 
 
+WGRAD_VERSION = int(os.environ.get("EDM_WGRAD", "2"))   # 1 = register-staged kernel, 2 = LDS-DMA rolling-window kernel
+
+
 def conv_wgrad(x, dy, taps):
     """fp32 split-K slabs (S, taps, Cout, Cin) of dW in packed order."""
     B, H, W, Cin = _nhwc(x, "x")
@@ -344,7 +347,9 @@ def conv_wgrad(x, dy, taps):
     npix = B * H * W
     with _prof("conv3x3_wgrad" if taps == 9 else "conv1x1_wgrad", 2.0 * npix * Cin * Cout * taps,
                2.0 * npix * (Cin + Cout) + 4.0 * slabs.numel()):
-        _lib.call("edm_conv_wgrad", _p(x), _p(dy), _p(slabs), B, H, W, Cin, Cout, taps, S, _stream())
+        # 3x3: LDS-DMA rolling-window kernel; 1x1: the register-staged kernel is (slightly) faster (r01 microbench)
+        fn = "edm_conv_wgrad_v2" if (WGRAD_VERSION == 2 and taps == 9 and W <= 62) else "edm_conv_wgrad"
+        _lib.call(fn, _p(x), _p(dy), _p(slabs), B, H, W, Cin, Cout, taps, S, _stream())
     return slabs
 
 
