@@ -66,9 +66,27 @@ CONV_SHAPES = [
 ]
 
 
+@pytest.fixture(params=[0, 1, 2, 3], ids=["igemm-auto", "igemm-v1", "igemm-v2", "igemm-v3"])
+def igemm_version(request, ops):
+    """Every generation of the implicit-GEMM kernel must pass the same parity tests (the per-shape dispatcher
+    picks v2/v3 only for full-size layers, so they are forced here on the small test shapes)."""
+    old = ops.IGEMM_VERSION
+    ops.IGEMM_VERSION = request.param
+    yield request.param
+    ops.IGEMM_VERSION = old
+
+
+@pytest.fixture(params=[1, 2], ids=["wgrad-v1", "wgrad-v2"])
+def wgrad_version(request, ops):
+    old = ops.WGRAD_VERSION
+    ops.WGRAD_VERSION = request.param
+    yield request.param
+    ops.WGRAD_VERSION = old
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", CONV_SHAPES)
 @pytest.mark.parametrize("k", [3, 1])
-def test_conv_igemm_forward(ops, B, H, W, Cin, Cout, k):
+def test_conv_igemm_forward(ops, igemm_version, B, H, W, Cin, Cout, k):
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cin + k)
     x = q(torch.randn(B, Cin, H, W, generator=g))
     w = q(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k))
@@ -77,7 +95,44 @@ def test_conv_igemm_forward(ops, B, H, W, Cin, Cout, k):
     close_bf16(nchw(y), ref)
 
 
-def test_conv_igemm_residual_epilogue(ops):
+def test_conv_full_size_layer_properties(ops):
+    """BASELINE-size layer (B=128, 32x32, 256->256): too big for an fp64 CPU reference in a test, so check
+    size-independent properties of the kernels the dispatcher picks there: linearity of conv in its input,
+    agreement between kernel generations, and <dY, conv(X)> == <wgrad(X,dY), W> (adjoint identity)."""
+    g = torch.Generator().manual_seed(77)
+    B, H, W, C = 128, 32, 32, 256
+    x1 = torch.randn(B, H, W, C, generator=g).to(torch.bfloat16).to(DEV)
+    x2 = torch.randn(B, H, W, C, generator=g).to(torch.bfloat16).to(DEV)
+    wp = (torch.randn(9, C, C, generator=g) / 48).to(torch.bfloat16).to(DEV)
+    old = ops.IGEMM_VERSION
+    try:
+        ys = {}
+        for v in (1, 2, 3):
+            ops.IGEMM_VERSION = v
+            ys[v] = ops.conv_igemm(x1, wp, 9).float()
+        ops.IGEMM_VERSION = 0
+        y_auto = ops.conv_igemm(x1, wp, 9).float()
+    finally:
+        ops.IGEMM_VERSION = old
+    for v in (2, 3):
+        assert rel(ys[v], ys[1]) < 3e-3, (v, rel(ys[v], ys[1]))
+    assert torch.equal(y_auto, ys[3])                      # the dispatcher picks the tall-tile kernel here
+    y2 = ops.conv_igemm(x2, wp, 9).float()
+    y12 = ops.conv_igemm((x1.float() + x2.float()).to(torch.bfloat16), wp, 9).float()
+    assert rel(y12, ys[3] + y2) < 1e-2                     # linearity (bf16 rounding of the summed input)
+    dy = torch.randn(B, H, W, C, generator=g).to(torch.bfloat16).to(DEV)
+    lhs = (dy.float() * ys[3]).sum().item()
+    for wv in (1, 2):
+        oldw, ops.WGRAD_VERSION = ops.WGRAD_VERSION, wv
+        try:
+            slabs = ops.conv_wgrad(x1, dy, 9)
+        finally:
+            ops.WGRAD_VERSION = oldw
+        rhs = (slabs.sum(0) * wp.float()).sum().item()
+        assert abs(lhs - rhs) <= 2e-2 * abs(lhs) + 50.0, (wv, lhs, rhs)
+
+
+def test_conv_igemm_residual_epilogue(ops, igemm_version):
     g = torch.Generator().manual_seed(5)
     B, H, W, Cin, Cout = 2, 16, 16, 128, 128
     x = q(torch.randn(B, Cin, H, W, generator=g))
@@ -90,7 +145,7 @@ def test_conv_igemm_residual_epilogue(ops):
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", CONV_SHAPES[:6])
 @pytest.mark.parametrize("k", [3, 1])
-def test_weight_prep_dgrad_and_wgrad(ops, B, H, W, Cin, Cout, k):
+def test_weight_prep_dgrad_and_wgrad(ops, wgrad_version, B, H, W, Cin, Cout, k):
     """weight_prep packs + in-place normalisation, conv dgrad through the flipped pack, and
     wgrad slabs + finish (projection through the weight normalisation) vs oracle autograd."""
     g = torch.Generator().manual_seed(B * 77 + H + Cin + k)
