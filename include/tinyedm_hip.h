@@ -32,6 +32,10 @@ int edm_conv_igemm_v2(const void* X, const void* Wp, void* Y, const void* R, flo
 /* third-generation kernel, same contract (512x128 "tall" tile, 128x64 per wave); -3 for shapes it does not cover */
 int edm_conv_igemm_v3(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
                       int W, int Cin, int Cout, int taps, edm_stream_t stream);
+/* fourth generation, 3x3 only: v3 geometry with a fully static schedule (18x unrolled, precomputed fragment addresses,
+ * masks folded into addresses, incremental DMA pointers); -3 for shapes it does not cover (taps != 9, Cin % 64 != 0) */
+int edm_conv_igemm_v4(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
+                      int W, int Cin, int Cout, int taps, edm_stream_t stream);
 /* diagnostic (tools/ only): in-kernel shader clock of the v3 kernel (dbg[0] cycles, dbg[1] 100 MHz ticks, dbg[2] WGs) */
 int edm_conv_igemm_v3_clock(const void* X, const void* Wp, void* Y, int B, int H, int W, int Cin, int Cout,
                             unsigned long long* dbg, edm_stream_t stream);

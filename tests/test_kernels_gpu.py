@@ -66,7 +66,7 @@ CONV_SHAPES = [
 ]
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=["igemm-auto", "igemm-v1", "igemm-v2", "igemm-v3"])
+@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["igemm-auto", "igemm-v1", "igemm-v2", "igemm-v3", "igemm-v4"])
 def igemm_version(request, ops):
     """Every generation of the implicit-GEMM kernel must pass the same parity tests (the per-shape dispatcher
     picks v2/v3 only for full-size layers, so they are forced here on the small test shapes)."""
@@ -107,16 +107,16 @@ def test_conv_full_size_layer_properties(ops):
     old = ops.IGEMM_VERSION
     try:
         ys = {}
-        for v in (1, 2, 3):
+        for v in (1, 2, 3, 4):
             ops.IGEMM_VERSION = v
             ys[v] = ops.conv_igemm(x1, wp, 9).float()
         ops.IGEMM_VERSION = 0
         y_auto = ops.conv_igemm(x1, wp, 9).float()
     finally:
         ops.IGEMM_VERSION = old
-    for v in (2, 3):
+    for v in (2, 3, 4):
         assert rel(ys[v], ys[1]) < 3e-3, (v, rel(ys[v], ys[1]))
-    assert torch.equal(y_auto, ys[3])                      # the dispatcher picks the tall-tile kernel here
+    assert torch.equal(y_auto, ys[3]) or torch.equal(y_auto, ys[4])   # the dispatcher picks a tall-tile kernel here
     y2 = ops.conv_igemm(x2, wp, 9).float()
     y12 = ops.conv_igemm((x1.float() + x2.float()).to(torch.bfloat16), wp, 9).float()
     assert rel(y12, ys[3] + y2) < 1e-2                     # linearity (bf16 rounding of the summed input)

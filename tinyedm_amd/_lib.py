@@ -41,6 +41,7 @@ SIGNATURES = {
     "edm_conv_igemm": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_v2": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_v3": [P, P, P, P, F, F, I, I, I, I, I, I, P],
+    "edm_conv_igemm_v4": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_v3_clock": [P, P, P, I, I, I, I, I, P, P],
     "edm_conv_igemm_v2_stamp": [P, P, P, I, I, I, I, I, P, P],
     "edm_conv_igemm_v2_ablate": [P, P, P, I, I, I, I, I, I, P],

@@ -22,7 +22,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr int BM = 512, BN = 128, KC = 32;
 constexpr int ROWB = KC * 2;      // 64-byte LDS rows
 constexpr int WTILE = BN * ROWB;  // 8 KiB weight tile
-constexpr int WRING = 3;
+constexpr int WRING = 6;   // weight tiles resident: 1 being read + 5 in flight (L2 latency under load ~1-2 us)
 
 __device__ __forceinline__ void dma16(const void* src, char* lds_dst) {
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_dst, 16, 0, 0);
@@ -30,6 +30,25 @@ __device__ __forceinline__ void dma16(const void* src, char* lds_dst) {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// counted wait with a run-time (wave-uniform) count: vmcnt takes an immediate, so dispatch over the possible values
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+  switch (n) {
+    case 0: wait_vmcnt<0>(); break;
+    case 1: wait_vmcnt<1>(); break;
+    case 2: wait_vmcnt<2>(); break;
+    case 3: wait_vmcnt<3>(); break;
+    case 4: wait_vmcnt<4>(); break;
+    case 5: wait_vmcnt<5>(); break;
+    case 6: wait_vmcnt<6>(); break;
+    case 7: wait_vmcnt<7>(); break;
+    case 8: wait_vmcnt<8>(); break;
+    case 9: wait_vmcnt<9>(); break;
+    case 10: wait_vmcnt<10>(); break;
+    case 11: wait_vmcnt<11>(); break;
+    case 12: wait_vmcnt<12>(); break;
+    default: wait_vmcnt<0>(); break;
+  }
 }
 __device__ __forceinline__ bf16x8 lds128(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
@@ -122,12 +141,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm3(const bf16* __restrict__
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
   // ---- prologue (issue order matters for the counted waits below)
+  constexpr int D = (TAPS == 9) ? WRING - 1 : 2;  // prefetch distance in (chunk,tap) tiles
   issue_x(0, 0);
-  issue_w(0, 0, 0);
-  if (T > 1) {
-    if (TAPS == 9) {
-      issue_w(0, 1, 1);
-    } else {
+  if (TAPS == 9) {
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (d < T) issue_w(d / TAPS, d % TAPS, d % WRING);
+  } else {
+    issue_w(0, 0, 0);
+    if (T > 1) {
       issue_x(1, 1);
       issue_w(1, 0, 1);
     }
@@ -136,32 +158,34 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm3(const bf16* __restrict__
   int chunk = 0, tap = 0;
   for (int t = 0; t < T; ++t) {
     // ---- retire tile t; the younger tile(s) stay in flight across the barrier
-    if (t + 1 >= T) {
+    if (TAPS == 9) {
+      // DMAs issued after W(t): the younger weight tiles, plus the next slab while it is younger than W(t)
+      // (slab c+1 is issued at tap 0 right after W(t+D), so it is younger than W(t) for taps 1..D of chunk c)
+      const int n_w = min(D - 1, T - 1 - t);
+      const int n_x = (tap >= 1 && tap <= D && chunk + 1 < nchunks) ? NX : 0;
+      wait_vmcnt_dyn(n_w + n_x);
+    } else if (t + 1 >= T) {
       wait_vmcnt<0>();
-    } else if (TAPS == 9) {
-      if ((tap == 1 || tap == 2) && chunk + 1 < nchunks) wait_vmcnt<NX + 1>();
-      else wait_vmcnt<1>();
     } else {
       wait_vmcnt<NX + 1>();
     }
     __builtin_amdgcn_s_barrier();
-    // ---- issue tile t+2 (its ring slot was last read at iteration t-1: every wave is past that barrier)
+    // ---- issue tile t+D (its ring slot was last read at iteration t-1: every wave is past that barrier)
     if (TAPS == 9) {
-      if (t + 2 < T) {
-        int tp2 = tap + 2, ch2 = chunk;
-        if (tp2 >= TAPS) { tp2 -= TAPS; ++ch2; }
-        issue_w(ch2, tp2, (t + 2) % WRING);
+      if (t + D < T) {
+        const int td = t + D;
+        issue_w(td / TAPS, td % TAPS, td % WRING);
       }
       if (tap == 0 && chunk + 1 < nchunks) issue_x(chunk + 1, (chunk + 1) & 1);
     } else {
       if (t + 2 < T) {
-        issue_w(t + 2, 0, (t + 2) % WRING);
+        issue_w(t + 2, 0, (t + 2) % 3);
         issue_x(t + 2, (t + 2) % XBUFS);
       }
     }
     // ---- 16 MFMAs over this (chunk, tap): 2 k-steps x (4 weight blocks x 2 pixel blocks)
     const int toff = (TAPS == 9) ? ((tap / 3 - 1) * W + (tap % 3 - 1)) : 0;
-    const char* wt = Wb + (t % WRING) * WTILE;
+    const char* wt = Wb + (t % ((TAPS == 9) ? WRING : 3)) * WTILE;
     const char* xs = Xb + ((TAPS == 9) ? (chunk & 1) : (t % XBUFS)) * XBYTES;
     const int r0 = brow[0] + toff, r1 = brow[1] + toff;
     const int s0 = (r0 >> 2) & 3, s1 = (r1 >> 2) & 3;

@@ -1,0 +1,259 @@
+// 3x3 implicit-GEMM convolution, fourth generation ("static schedule"): the tall-tile LDS-DMA kernel of
+// conv_igemm3.hip with every LDS address made a compile-time offset of a per-lane register.
+//
+//   Y[p, co] = alpha * sum_{tap, ci} X[p + off(tap), ci] * Wp[tap, co, ci]  (+ beta * R[p, co])
+//
+// Why: generations 2/3 spend ~4 vector-ALU instructions per MFMA on swizzle/tap address arithmetic, border
+// masks and 64-bit DMA source addresses; with 2-4 waves per SIMD the shared vector issue port, not the matrix
+// pipe, is what saturates (measured: fragment reads + MFMA alone reach only ~51 % of the MFMA rate).  Here:
+//  * the (tap, 2 ci-chunks) loop is unrolled 18x, so weight-ring slot, slab buffer and tap are constants:
+//    every ds_read_b128 is `base register + immediate`;
+//  * the 36 pixel-fragment addresses (9 taps x 2 pixel blocks x 2 k-steps) are computed ONCE per workgroup;
+//    border masks are folded into them: a masked lane simply reads a zero row of the slab buffer;
+//  * DMA source pointers advance by constants (one 64-bit add per weight tile); out-of-range rows are clamped
+//    to valid memory (their products are masked) and zero rows walk inside a 4 KiB zero page -- no selects.
+//  * 6-deep weight ring (5 tiles in flight), counted vmcnt immediates, raw s_barrier.
+// Geometry as generation 3: 512 pixels x 128 channels per workgroup, 8 waves x (128 co x 64 px), Cin % 64 == 0.
+#include "common.h"
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int BM = 512, BN = 128, KC = 32, TAPS = 9;
+constexpr int ROWB = KC * 2;      // 64-byte LDS rows
+constexpr int WTILE = BN * ROWB;  // 8 KiB weight tile
+constexpr int WRING = 6, D = WRING - 1;
+constexpr int ZERO_PAGE = 4096;
+
+__device__ __forceinline__ void dma16(const void* src, char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_dst, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ bf16x8 lds128(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+typedef __attribute__((address_space(3))) char lds_char;
+// read 16 B at an LDS byte offset held as an integer (keeps the access a ds_read_b128 after integer arithmetic)
+__device__ __forceinline__ bf16x8 lds128_at(unsigned off) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>((lds_char*)(uintptr_t)off);
+}
+
+template <int NX>
+__global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ X, const bf16* __restrict__ Wp,
+                                                         bf16* __restrict__ Y, const bf16* __restrict__ R,
+                                                         const char* __restrict__ zeros, float alpha, float beta,
+                                                         int Npix, int H, int W, int Cin, int Cout, int tiles_m,
+                                                         int tiles_n) {
+  constexpr int XROWS = NX * 8 * 16;  // LDS rows per slab buffer; rows >= xrows are zero rows
+  constexpr int XBYTES = XROWS * ROWB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Xb = smem;
+  char* const Wb = smem + 2 * XBYTES;
+
+  const int id = blockIdx.x;
+  const int xcd = id & 7, k = id >> 3;
+  const int tn = k % tiles_n, tm = (k / tiles_n) * 8 + xcd;
+  if (tm >= tiles_m) return;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int HALO = W + 1;
+  const int xrows = BM + 2 * HALO;  // < XROWS (host-checked): row XROWS-1 is always a zero row
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = pixel octant of this wave
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int drow = lane >> 2, dp = lane & 3;  // DMA lane -> (row in 16-row slot, physical 16-B chunk)
+
+  // ---- DMA sources (per lane, computed once; they then advance by constants)
+  // weight tile (chunk, tap): rows n0 + 16*wave + drow (clamped: rows >= Cout feed discarded outputs)
+  const char* wsrc;
+  {
+    const int row = wave * 16 + drow;
+    const int co = min(n0 + row, Cout - 1);
+    const int c = dp ^ ((row >> 2) & 3);
+    wsrc = reinterpret_cast<const char*>(Wp + (long)co * Cin + c * 8);
+  }
+  const long tap_stride = (long)Cout * Cin * 2;  // bytes between taps of the packed weights
+  // slab slot i: rows (wave + 8i)*16 + drow; chunk advances the pointer by 64 B
+  const char* xsrc[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int row = (wave + 8 * i) * 16 + drow;
+    const int c = dp ^ ((row >> 2) & 3);
+    if (row < xrows) {
+      long pix = (long)m0 - HALO + row;
+      pix = pix < 0 ? 0 : (pix >= Npix ? Npix - 1 : pix);  // out-of-range rows only feed masked taps
+      xsrc[i] = reinterpret_cast<const char*>(X + pix * Cin + c * 8);
+    } else {
+      xsrc[i] = zeros + c * 16;  // zero rows: the pointer walks inside the 4 KiB zero page
+    }
+  }
+
+  // ---- the 36 pixel-fragment LDS addresses (tap, pixel block, k-step), border masks folded in
+  const unsigned xb_off = (unsigned)(uintptr_t)(lds_char*)Xb;
+  unsigned bp[TAPS][2];  // LDS byte offsets for k-step 0; k-step 1 = same offset with bit 5 flipped (chunk ^ 2)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ml = wave * 64 + j * 32 + l31;
+    const int m = m0 + ml;
+    const int w = m % W, h = (m / W) % H;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+      const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+      const int r = ml + HALO + (t / 3 - 1) * W + (t % 3 - 1);
+      const int sw = (r >> 2) & 3;
+      bp[t][j] = xb_off + (ok ? r * ROWB + ((lhi ^ sw) << 4) : (XROWS - 1) * ROWB);
+    }
+  }
+  // weight-fragment rows i*32 + l31: swizzle term depends on l31 only
+  const int a_sw = (l31 >> 2) & 3;
+  const char* const ap[2] = {Wb + l31 * ROWB + (((0 + lhi) ^ a_sw) << 4), Wb + l31 * ROWB + (((2 + lhi) ^ a_sw) << 4)};
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nchunks = Cin / KC;  // even (host-checked)
+
+  // ---- prologue: slab 0, then weight tiles 0..D-1 (issue order fixes the counted waits)
+#pragma unroll
+  for (int i = 0; i < NX; ++i) dma16(xsrc[i], Xb + (wave + 8 * i) * 1024);
+#pragma unroll
+  for (int d = 0; d < D; ++d) dma16(wsrc + d * tap_stride, Wb + d * WTILE + wave * 1024);
+
+  for (int chunk2 = 0; chunk2 < nchunks; chunk2 += 2) {
+#pragma unroll
+    for (int u = 0; u < 2 * TAPS; ++u) {
+      const int tap = u % TAPS, cpar = u / TAPS;  // compile-time after unrolling
+      const int chunk = chunk2 + cpar;
+      const bool more_chunks = chunk + 1 < nchunks;
+      // ---- retire weight tile t (and slab `chunk` at tap 0); younger DMAs stay in flight across the barrier:
+      // D-1 younger weight tiles, plus slab chunk+1 while it is younger than W(t) (taps 1..D)
+      if (more_chunks) {
+        if (tap >= 1 && tap <= D) wait_vmcnt<D - 1 + NX>();
+        else wait_vmcnt<D - 1>();
+      } else {
+        switch ((TAPS - 1 - tap) < (D - 1) ? (TAPS - 1 - tap) : (D - 1)) {  // last chunk: the ring drains
+          case 4: wait_vmcnt<4>(); break;
+          case 3: wait_vmcnt<3>(); break;
+          case 2: wait_vmcnt<2>(); break;
+          case 1: wait_vmcnt<1>(); break;
+          default: wait_vmcnt<0>(); break;
+        }
+      }
+      __builtin_amdgcn_s_barrier();
+      // ---- issue weight tile t+D into the ring slot read at iteration t-1, then (tap 0) the next slab
+      {
+        const int tq = tap + D;                       // tap index of tile t+D, maybe in the next chunk
+        const int cq = cpar + (tq >= TAPS ? 1 : 0);   // chunk offset from chunk2 (0, 1 or 2)
+        const int tapq = tq >= TAPS ? tq - TAPS : tq;
+        if (chunk2 + cq < nchunks)
+          dma16(wsrc + (long)(chunk2 + cq) * (KC * 2) + tapq * tap_stride, Wb + ((u + D) % WRING) * WTILE + wave * 1024);
+      }
+      if (tap == 0 && more_chunks) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+          dma16(xsrc[i] + (long)(chunk + 1) * (KC * 2), Xb + (cpar ^ 1) * XBYTES + (wave + 8 * i) * 1024);
+      }
+      // ---- 16 MFMAs: 2 k-steps x (4 weight blocks x 2 pixel blocks); all addresses = register + immediate
+      // all 12 fragment reads are issued up front (48 registers) so the MFMAs never wait on a lone ds_read
+      bf16x8 b[2][2], a[2][4];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          unsigned off = bp[tap][j];
+          if (ks) asm volatile("v_xor_b32 %0, 32, %1" : "=v"(off) : "v"(bp[tap][j]));  // opaque: keep 18, not 36, address registers
+          b[ks][j] = lds128_at(off + cpar * XBYTES);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[ks][i] = lds128(ap[ks] + (u % WRING) * WTILE + i * 32 * ROWB);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // reads above, MFMAs below: the scheduler must not re-serialise them
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][0], acc[i][0], 0, 0, 0);
+          acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][1], acc[i][1], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- epilogue: lane holds, per (i,j), pixel = col(l31) and 4x4 consecutive output channels
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const long m = (long)m0 + wave * 64 + j * 32 + l31;
+    if (m >= Npix) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = n0 + i * 32 + 8 * g + 4 * lhi;
+        if (co < Cout) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = alpha * acc[i][j][4 * g + r];
+          if (R) {
+            bf16x4 rv = *reinterpret_cast<const bf16x4*>(R + m * Cout + co);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += beta * (float)rv[r];
+          }
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+          *reinterpret_cast<bf16x4*>(Y + m * Cout + co) = o;
+        }
+      }
+    }
+  }
+}
+
+char* g_zero_page4 = nullptr;
+
+template <int NX>
+void launch4(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int Npix, int H, int W,
+             int Cin, int Cout, hipStream_t st) {
+  const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + BN - 1) / BN;
+  const size_t lds = (size_t)2 * NX * 8 * 16 * ROWB + WRING * WTILE;
+  const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
+  auto kern = k_conv3x3_v4<NX>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const bf16*)X, (const bf16*)Wp, (bf16*)Y, (const bf16*)R,
+                     (const char*)g_zero_page4, alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n);
+}
+
+}  // namespace
+
+// 3x3 only.  Same contract as edm_conv_igemm; returns EDM_ERR_UNSUPPORTED (-3) for shapes it does not cover
+// (taps != 9, Cin % 64 != 0, Cin > 2048, W > 64, fewer than 9*Cin/32 >= 18 tiles ...).
+extern "C" int edm_conv_igemm_v4(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B,
+                                 int H, int W, int Cin, int Cout, int taps, hipStream_t st) {
+  EDM_REQUIRE(X && Wp && Y, "conv_igemm_v4: null pointer");
+  EDM_REQUIRE(B > 0 && H > 0 && W > 0 && (long)B * H * W < (1L << 31), "conv_igemm_v4: bad B/H/W");
+  EDM_REQUIRE(Cout > 0 && Cout % 8 == 0, "conv_igemm_v4: Cout %% 8 required");
+  if (taps != 9 || Cin <= 0 || Cin % 64 != 0 || Cin * 2 + 64 > ZERO_PAGE || W > 64) return EDM_ERR_UNSUPPORTED;
+  if (!g_zero_page4) {
+    if (hipMalloc((void**)&g_zero_page4, ZERO_PAGE) != hipSuccess || hipMemset(g_zero_page4, 0, ZERO_PAGE) != hipSuccess) {
+      edm_set_error("conv_igemm_v4: cannot allocate the zero page");
+      return EDM_ERR_LAUNCH;
+    }
+  }
+  const int Npix = B * H * W;
+  const int xrows = BM + 2 * (W + 1);
+  if (xrows < 5 * 128) launch4<5>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st);
+  else launch4<6>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st);
+  EDM_CHECK_LAUNCH("conv_igemm_v4");
+  return EDM_OK;
+}

@@ -298,7 +298,7 @@ def nhwc_bf16_to_nchw(x):
 IGEMM_VERSION = int(os.environ.get("EDM_IGEMM", "0"))
 
 
-def _igemm_entry(npix, W, Cout, taps):
+def _igemm_entry(npix, W, Cout, taps, Cin=0):
     if taps == 9 and W > 64:
         return "edm_conv_igemm"
     if IGEMM_VERSION == 1:
@@ -307,11 +307,15 @@ def _igemm_entry(npix, W, Cout, taps):
         return "edm_conv_igemm_v2"
     if IGEMM_VERSION == 3:
         return "edm_conv_igemm_v3"
+    if IGEMM_VERSION == 4:
+        return "edm_conv_igemm_v4" if (taps == 9 and Cin % 64 == 0 and Cin <= 2016) else "edm_conv_igemm_v3"
     # per-shape choice from the r01 microbenchmarks (tools/microbench_conv.py): the LDS-DMA tall-tile kernels only pay
     # off when they still give every CU >= 2 tiles; small feature maps keep the 128x128 register-staged kernel.
     if taps == 9:
         tiles3 = ((npix + 511) // 512) * ((Cout + 127) // 128)
-        return "edm_conv_igemm_v3" if tiles3 >= 512 else "edm_conv_igemm"
+        if tiles3 >= 512:
+            return "edm_conv_igemm_v4" if (Cin % 64 == 0 and Cin <= 2016 and W <= 64) else "edm_conv_igemm_v3"
+        return "edm_conv_igemm"
     tiles2 = ((npix + 255) // 256) * ((Cout + 127) // 128)
     return "edm_conv_igemm_v2" if tiles2 >= 1024 else "edm_conv_igemm"
 
@@ -329,7 +333,7 @@ def conv_igemm(x, wp, taps, residual=None, alpha=1.0, beta=0.0):
     npix = B * H * W
     with _prof("conv3x3_igemm" if taps == 9 else "conv1x1_igemm", 2.0 * npix * Cin * Cout * taps,
                2.0 * (npix * (Cin + Cout * (2 if residual is not None else 1)) + wp.numel())):
-        _lib.call(_igemm_entry(npix, W, Cout, taps), _p(x), _p(wp), _p(y), _p(residual), float(alpha), float(beta), B, H, W, Cin, Cout, taps, _stream())
+        _lib.call(_igemm_entry(npix, W, Cout, taps, Cin), _p(x), _p(wp), _p(y), _p(residual), float(alpha), float(beta), B, H, W, Cin, Cout, taps, _stream())
     return y
 
 
