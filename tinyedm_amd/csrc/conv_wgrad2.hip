@@ -22,6 +22,7 @@ typedef __attribute__((ext_vector_type(8))) short short8v;
 typedef short4v __attribute__((address_space(3))) * lds_s4p;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((address_space(3))) char lds_char;
 
 constexpr int KP = 64;                 // padded rows per stage
 constexpr int SUBB = KP * 64;          // bytes of one [64 rows][32 ch] sub-image stage
@@ -39,6 +40,21 @@ __device__ __forceinline__ void dma16(const void* src, char* lds_dst) {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ---- hand-scheduled fragment pipeline (3x3 path).  hipcc guards every ds_read_tr *builtin* that follows an LDS-DMA
+// with `s_waitcnt vmcnt(0)` (it cannot prove the read does not alias the DMA's LDS destination), which drains the
+// prefetched stages on every k-step.  The reads are therefore issued from inline asm (invisible to that pass) and
+// ordered by hand: LDS completion by counted `lgkmcnt`, DMA completion by the stage-level vmcnt + barrier.
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+#define TR_RD(dst, base, imm) \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "i"(imm))
+#define LGKM_WAIT(n)                                        \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory");   \
+  __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ bf16x8 frag_of(const u32x2_t& lo, const u32x2_t& hi) {
+  u32x4 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+  return __builtin_bit_cast(bf16x8, v);
 }
 
 struct Geo {  // padded flat-K geometry (host-computed)
@@ -168,9 +184,48 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad2(const bf16* __restrict__
       if (t + 2 < nst) issue_dy(t + 2);
     }
     // ---- 36 (or 4) MFMAs over this stage
-    if (wave_active) {
+    if (TAPS == 9 && wave_active) {
       const int slot = (t + 1) & 3;
-      const int base_row = ((TAPS == 9 && slot == 0) ? 4 : slot) * KP;
+      const int base_row = (slot == 0 ? 4 : slot) * KP;
+      const unsigned a_u = (unsigned)(uintptr_t)(lds_char*)dYb + (t % DYRING) * (2 * SUBB) + cb * SUBB + krow_l * 64 + chan_b;
+      const unsigned b_u = (unsigned)(uintptr_t)(lds_char*)Xb + ib * (XSLOTS * SUBB) + (base_row + krow_l) * 64 + chan_b;
+      unsigned tb[9];
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) tb[tp] = b_u + ((tp / 3 - 1) * PW + (tp % 3 - 1)) * 64;
+      u32x2_t A[2][2], Bf[2][3][2];
+      // item q = (k-step ks = q/3, tap group g = q%3) : 3 MFMAs; its reads are issued one item ahead
+#define RD_A(ks) TR_RD(A[(ks) & 1][0], a_u, (ks) * 1024); TR_RD(A[(ks) & 1][1], a_u, (ks) * 1024 + 256)
+#define RD_B(set, ks, g)                                                                                   \
+  TR_RD(Bf[set][0][0], tb[3 * (g) + 0], (ks) * 1024); TR_RD(Bf[set][0][1], tb[3 * (g) + 0], (ks) * 1024 + 256); \
+  TR_RD(Bf[set][1][0], tb[3 * (g) + 1], (ks) * 1024); TR_RD(Bf[set][1][1], tb[3 * (g) + 1], (ks) * 1024 + 256); \
+  TR_RD(Bf[set][2][0], tb[3 * (g) + 2], (ks) * 1024); TR_RD(Bf[set][2][1], tb[3 * (g) + 2], (ks) * 1024 + 256)
+#define MM3(set, ks, g)                                                                                           \
+  acc[3 * (g) + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(A[(ks) & 1][0], A[(ks) & 1][1]),             \
+                                                            frag_of(Bf[set][0][0], Bf[set][0][1]), acc[3 * (g) + 0], 0, 0, 0); \
+  acc[3 * (g) + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(A[(ks) & 1][0], A[(ks) & 1][1]),             \
+                                                            frag_of(Bf[set][1][0], Bf[set][1][1]), acc[3 * (g) + 1], 0, 0, 0); \
+  acc[3 * (g) + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(A[(ks) & 1][0], A[(ks) & 1][1]),             \
+                                                            frag_of(Bf[set][2][0], Bf[set][2][1]), acc[3 * (g) + 2], 0, 0, 0)
+      RD_A(0); RD_B(0, 0, 0);
+      RD_B(1, 0, 1); LGKM_WAIT(6); MM3(0, 0, 0);
+      RD_B(0, 0, 2); LGKM_WAIT(6); MM3(1, 0, 1);
+      RD_A(1); RD_B(1, 1, 0); LGKM_WAIT(8); MM3(0, 0, 2);
+      RD_B(0, 1, 1); LGKM_WAIT(6); MM3(1, 1, 0);
+      RD_B(1, 1, 2); LGKM_WAIT(6); MM3(0, 1, 1);
+      RD_A(2); RD_B(0, 2, 0); LGKM_WAIT(8); MM3(1, 1, 2);
+      RD_B(1, 2, 1); LGKM_WAIT(6); MM3(0, 2, 0);
+      RD_B(0, 2, 2); LGKM_WAIT(6); MM3(1, 2, 1);
+      RD_A(3); RD_B(1, 3, 0); LGKM_WAIT(8); MM3(0, 2, 2);
+      RD_B(0, 3, 1); LGKM_WAIT(6); MM3(1, 3, 0);
+      RD_B(1, 3, 2); LGKM_WAIT(6); MM3(0, 3, 1);
+      LGKM_WAIT(0); MM3(1, 3, 2);
+#undef RD_A
+#undef RD_B
+#undef MM3
+    }
+    if (TAPS != 9 && wave_active) {
+      const int slot = (t + 1) & 3;
+      const int base_row = slot * KP;
       const char* abase = dYb + (t % DYRING) * (2 * SUBB) + cb * SUBB + krow_l * 64 + chan_b;
       const char* bbase = Xb + ib * (XSLOTS * SUBB) + (base_row + krow_l) * 64 + chan_b;
 #pragma unroll 1
