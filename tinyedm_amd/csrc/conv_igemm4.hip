@@ -41,6 +41,23 @@ __device__ __forceinline__ bf16x8 lds128_at(unsigned off) {
   return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>((lds_char*)(uintptr_t)off);
 }
 
+// compile-time loop: f(IC<B>{}) ... f(IC<E-1>{}); the index is a constant expression inside f (inline-asm immediates)
+template <int N>
+struct IC { static constexpr int value = N; };
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(IC<B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+// Fragment reads are issued from inline asm and retired by hand-counted lgkmcnt: left to itself hipcc answers a
+// "6 older + 6 younger reads in flight" state with s_waitcnt lgkmcnt(0), which serialises the two halves again.
+#define LDS_RD128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
+#define LGKM_WAIT(n)                                       \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory");  \
+  __builtin_amdgcn_sched_barrier(0)
+
 template <int NX>
 __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ X, const bf16* __restrict__ Wp,
                                                          bf16* __restrict__ Y, const bf16* __restrict__ R,
@@ -110,7 +127,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
   }
   // weight-fragment rows i*32 + l31: swizzle term depends on l31 only
   const int a_sw = (l31 >> 2) & 3;
-  const char* const ap[2] = {Wb + l31 * ROWB + (((0 + lhi) ^ a_sw) << 4), Wb + l31 * ROWB + (((2 + lhi) ^ a_sw) << 4)};
+  const unsigned wb_off = (unsigned)(uintptr_t)(lds_char*)Wb;
+  const unsigned ap[2] = {wb_off + l31 * ROWB + (((0 + lhi) ^ a_sw) << 4), wb_off + l31 * ROWB + (((2 + lhi) ^ a_sw) << 4)};
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -128,20 +146,48 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
 #pragma unroll
   for (int d = 0; d < D; ++d) dma16(wsrc + d * tap_stride, Wb + d * WTILE + wave * 1024);
 
-  for (int chunk2 = 0; chunk2 < nchunks; chunk2 += 2) {
+  // Fragment pipeline: the 16 MFMAs of a step run as two halves (k-step 0 / k-step 1, 8 MFMAs each) and the 6 reads
+  // of the NEXT half are in flight while the current half computes, so the LDS pipe and the matrix pipe overlap
+  // inside one wave instead of alternating (all 8 waves of the group are barrier-aligned, so they would otherwise
+  // all read, then all compute).  The barrier at the top of step u therefore retires tile u+1 as well as tile u.
+  u32x4 fa[2][4], fb[2][2];
+  auto mfma_half = [&](int set) {
 #pragma unroll
-    for (int u = 0; u < 2 * TAPS; ++u) {
-      const int tap = u % TAPS, cpar = u / TAPS;  // compile-time after unrolling
+    for (int i = 0; i < 4; ++i) {
+      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][i]),
+                                                         __builtin_bit_cast(bf16x8, fb[set][0]), acc[i][0], 0, 0, 0);
+      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][i]),
+                                                         __builtin_bit_cast(bf16x8, fb[set][1]), acc[i][1], 0, 0, 0);
+    }
+  };
+#define READ_HALF(set, ks, tap, cpar, slot)                                               \
+  {                                                                                       \
+    unsigned o0 = bp[tap][0], o1 = bp[tap][1];                                            \
+    if (ks) { /* opaque xor: keep 18, not 36, address registers */                        \
+      asm volatile("v_xor_b32 %0, 32, %1" : "=v"(o0) : "v"(bp[tap][0]));                  \
+      asm volatile("v_xor_b32 %0, 32, %1" : "=v"(o1) : "v"(bp[tap][1]));                  \
+    }                                                                                     \
+    LDS_RD128(fb[set][0], o0, (cpar) * XBYTES);                                           \
+    LDS_RD128(fb[set][1], o1, (cpar) * XBYTES);                                           \
+    LDS_RD128(fa[set][0], ap[ks], (slot) * WTILE + 0 * 32 * ROWB);                        \
+    LDS_RD128(fa[set][1], ap[ks], (slot) * WTILE + 1 * 32 * ROWB);                        \
+    LDS_RD128(fa[set][2], ap[ks], (slot) * WTILE + 2 * 32 * ROWB);                        \
+    LDS_RD128(fa[set][3], ap[ks], (slot) * WTILE + 3 * 32 * ROWB);                        \
+  }
+
+  for (int chunk2 = 0; chunk2 < nchunks; chunk2 += 2) {
+    static_for<0, 2 * TAPS>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      constexpr int tap = u % TAPS, cpar = u / TAPS;
       const int chunk = chunk2 + cpar;
       const bool more_chunks = chunk + 1 < nchunks;
-      // ---- retire weight tile t (and slab `chunk` at tap 0); younger DMAs stay in flight across the barrier:
-      // D-1 younger weight tiles, plus slab chunk+1 while it is younger than W(t) (taps 1..D)
+      // ---- retire weight tiles t and t+1 (and slab chunk+1 before its first read at tap 8); younger DMAs stay in
+      // flight across the barrier: D-2 younger weight tiles, plus slab chunk+1 while it is younger than W(t+1)
       if (more_chunks) {
-        if (tap >= 1 && tap <= D) wait_vmcnt<D - 1 + NX>();
-        else wait_vmcnt<D - 1>();
+        if (tap >= 1 && tap <= D - 1) wait_vmcnt<D - 2 + NX>();
+        else wait_vmcnt<D - 2>();
       } else {
-        switch ((TAPS - 1 - tap) < (D - 1) ? (TAPS - 1 - tap) : (D - 1)) {  // last chunk: the ring drains
-          case 4: wait_vmcnt<4>(); break;
+        switch ((TAPS - 2 - tap) < (D - 2) ? (TAPS - 2 - tap) : (D - 2)) {  // last chunk: the ring drains
           case 3: wait_vmcnt<3>(); break;
           case 2: wait_vmcnt<2>(); break;
           case 1: wait_vmcnt<1>(); break;
@@ -151,9 +197,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
       __builtin_amdgcn_s_barrier();
       // ---- issue weight tile t+D into the ring slot read at iteration t-1, then (tap 0) the next slab
       {
-        const int tq = tap + D;                       // tap index of tile t+D, maybe in the next chunk
-        const int cq = cpar + (tq >= TAPS ? 1 : 0);   // chunk offset from chunk2 (0, 1 or 2)
-        const int tapq = tq >= TAPS ? tq - TAPS : tq;
+        constexpr int tq = tap + D;                       // tap index of tile t+D, maybe in the next chunk
+        constexpr int cq = cpar + (tq >= TAPS ? 1 : 0);   // chunk offset from chunk2 (0, 1 or 2)
+        constexpr int tapq = tq >= TAPS ? tq - TAPS : tq;
         if (chunk2 + cq < nchunks)
           dma16(wsrc + (long)(chunk2 + cq) * (KC * 2) + tapq * tap_stride, Wb + ((u + D) % WRING) * WTILE + wave * 1024);
       }
@@ -162,30 +208,23 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
         for (int i = 0; i < NX; ++i)
           dma16(xsrc[i] + (long)(chunk + 1) * (KC * 2), Xb + (cpar ^ 1) * XBYTES + (wave + 8 * i) * 1024);
       }
-      // ---- 16 MFMAs: 2 k-steps x (4 weight blocks x 2 pixel blocks); all addresses = register + immediate
-      // all 12 fragment reads are issued up front (48 registers) so the MFMAs never wait on a lone ds_read
-      bf16x8 b[2][2], a[2][4];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          unsigned off = bp[tap][j];
-          if (ks) asm volatile("v_xor_b32 %0, 32, %1" : "=v"(off) : "v"(bp[tap][j]));  // opaque: keep 18, not 36, address registers
-          b[ks][j] = lds128_at(off + cpar * XBYTES);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[ks][i] = lds128(ap[ks] + (u % WRING) * WTILE + i * 32 * ROWB);
+      // ---- 2 x 8 MFMAs; all addresses = register + immediate
+      if (u == 0 && chunk2 == 0) READ_HALF(0, 0, 0, 0, 0);  // pipeline fill (first step of the kernel only)
+      READ_HALF(1, 1, tap, cpar, u % WRING);
+      LGKM_WAIT(6);
+      mfma_half(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more_chunks || tap + 1 < TAPS) {
+        READ_HALF(0, 0, (tap + 1) % TAPS, (u + 1) / TAPS % 2, (u + 1) % WRING);
+        LGKM_WAIT(6);
+      } else {
+        LGKM_WAIT(0);
       }
-      __builtin_amdgcn_sched_barrier(0);  // reads above, MFMAs below: the scheduler must not re-serialise them
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][0], acc[i][0], 0, 0, 0);
-          acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][1], acc[i][1], 0, 0, 0);
-        }
-    }
+      mfma_half(1);
+      __builtin_amdgcn_sched_barrier(0);
+    });
   }
+#undef READ_HALF
 
   // ---- epilogue: lane holds, per (i,j), pixel = col(l31) and 4x4 consecutive output channels
 #pragma unroll
