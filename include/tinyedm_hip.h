@@ -52,6 +52,11 @@ int edm_conv_wgrad(const void* X, const void* dY, float* slabs, int B, int H, in
 /* second-generation weight-gradient kernel, same contract (LDS-DMA staging, rolling X window); -3 = not covered */
 int edm_conv_wgrad_v2(const void* X, const void* dY, float* slabs, int B, int H, int W, int Cin, int Cout, int taps,
                       int nsplit, edm_stream_t stream);
+/* 1x1 layers (networks.py:21-38 with kernel_size 1: skip projections, attention qkv/out): 256x128-output tiles,
+ * slabs fp32 [nsplit][Cout][Cin] with nsplit = edm_conv_wgrad_1x1_nsplit(npix, Cin, Cout); Cin, Cout % 32 == 0. */
+int edm_conv_wgrad_1x1_nsplit(long npix, int Cin, int Cout);
+int edm_conv_wgrad_1x1(const void* X, const void* dY, float* slabs, long npix, int Cin, int Cout, int nsplit,
+                       edm_stream_t stream);
 
 /* ---------------------------------------------------------------- weights (networks.py:17-19, 32-36, 55-59) */
 /* forced weight normalisation (in place when normalize_inplace) + effective weight w/(eps+|w|/sqrt(n))/sqrt(n),

@@ -78,10 +78,11 @@ def igemm_version(request, ops):
 
 @pytest.fixture(params=[1, 2], ids=["wgrad-v1", "wgrad-v2"])
 def wgrad_version(request, ops):
-    old = ops.WGRAD_VERSION
+    old, old1 = ops.WGRAD_VERSION, ops.WGRAD_1X1
     ops.WGRAD_VERSION = request.param
+    ops.WGRAD_1X1 = request.param == 2   # v1 also covers the 1x1 layers; v2 pairs with the dedicated 1x1 kernel
     yield request.param
-    ops.WGRAD_VERSION = old
+    ops.WGRAD_VERSION, ops.WGRAD_1X1 = old, old1
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", CONV_SHAPES)
@@ -181,6 +182,31 @@ def test_weight_prep_dgrad_and_wgrad(ops, wgrad_version, B, H, W, Cin, Cout, k):
     raw = slabs.sum(0).cpu()                                                       # (taps, O, I)
     raw_ref = what.grad.permute(2, 3, 0, 1).reshape(k * k, Cout, Cin)
     assert rel(raw, raw_ref) <= 1e-3, f"raw wgrad rel {rel(raw, raw_ref):.3e}"
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 5, 7, 160, 96), (2, 16, 16, 256, 768), (5, 8, 8, 512, 256),
+                                             (1, 3, 3, 32, 32), (16, 16, 16, 128, 320)])
+def test_conv_wgrad_1x1_ragged(ops, B, H, W, Cin, Cout):
+    """Dedicated 1x1 weight-gradient kernel: partial 256x128 tiles, pixel counts that are not a multiple of the
+    64-row stage, empty trailing splits; checked against an fp64 GEMM of the same bf16 operands."""
+    g = torch.Generator().manual_seed(B + H + Cin + Cout)
+    x = q(torch.randn(B, Cin, H, W, generator=g))
+    gy = q(torch.randn(B, Cout, H, W, generator=g))
+    assert ops.WGRAD_1X1
+    slabs = ops.conv_wgrad(nhwc(x), nhwc(gy), 1)
+    assert slabs.shape[1:] == (1, Cout, Cin)
+    xm = x.permute(0, 2, 3, 1).reshape(-1, Cin).double()
+    gm = gy.permute(0, 2, 3, 1).reshape(-1, Cout).double()
+    ref = gm.t() @ xm
+    got = slabs.double().sum(0)[0].cpu()
+    assert rel(got, ref) <= 1e-5, f"1x1 wgrad rel {rel(got, ref):.3e}"
+    # the two kernels agree on the same operands (different split counts, same sum)
+    ops.WGRAD_1X1 = False
+    try:
+        ref1 = ops.conv_wgrad(nhwc(x), nhwc(gy), 1).double().sum(0)[0].cpu()
+    finally:
+        ops.WGRAD_1X1 = True
+    assert rel(got, ref1) <= 1e-5
 
 
 def test_weight_prep_padding_and_perm(ops):

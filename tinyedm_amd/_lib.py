@@ -48,6 +48,8 @@ SIGNATURES = {
     "edm_conv_wgrad_nsplit": [I, I, I, I, I, I],
     "edm_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, P],
     "edm_conv_wgrad_v2": [P, P, P, I, I, I, I, I, I, I, P],
+    "edm_conv_wgrad_1x1_nsplit": [L, I, I],
+    "edm_conv_wgrad_1x1": [P, P, P, L, I, I, I, P],
     # attention.hip
     "edm_attention_fwd": [P, P, I, I, I, I, P],
     "edm_attention_bwd": [P, P, P, P, I, I, I, I, P],
@@ -72,7 +74,7 @@ SIGNATURES = {
     "edm_wgrad_finish": [P, I, P, P, P, I, I, I, I, F, I, P],
 }
 _RET = {"edm_last_error": ctypes.c_char_p}
-_NO_STATUS = {"edm_version", "edm_last_error", "edm_conv_wgrad_nsplit"}
+_NO_STATUS = {"edm_version", "edm_last_error", "edm_conv_wgrad_nsplit", "edm_conv_wgrad_1x1_nsplit"}
 
 _lib = None
 

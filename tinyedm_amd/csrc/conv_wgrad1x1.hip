@@ -1,0 +1,202 @@
+// Weight gradient of the 1x1 convolutions (skip projections, attention qkv/out):
+//
+//   dW[co, ci] = sum_p dY[p, co] * X[p, ci]            (fp32, split-K slabs [S][Cout][Cin])
+//
+// A 1x1 layer has 9x less arithmetic per operand byte than a 3x3 one, so the 64x64-output tiles of
+// conv_wgrad.hip / conv_wgrad2.hip (32 FLOP per staged byte) saturate the L2 -> LDS path at ~0.19 PFLOP/s.
+// This kernel keeps a 256(co) x 128(ci) output tile per workgroup (87 FLOP per staged byte):
+//  * 8 waves, each a 64x64 block (2x2 MFMA 32x32x16 accumulators);
+//  * both operands arrive by LDS-DMA (`global_load_lds_dwordx4`, 16 rows x 64 B per wave instruction) into
+//    [64 pixel rows][32 ch] sub-images, 12 per stage (8 dY + 4 X) = 48 KiB, 3-stage ring (144 KiB);
+//  * fragments come from `ds_read_b64_tr_b16` (K-major memory -> MFMA operand layout) issued from inline asm
+//    one k-step ahead of the MFMAs, retired by counted lgkmcnt; all LDS addresses are register + immediate;
+//  * counted `s_waitcnt vmcnt(6)` + raw s_barrier keep the next stage in flight across the barrier.
+#include "common.h"
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+
+constexpr int KP = 64;             // pixel rows per stage
+constexpr int SUBB = KP * 64;      // bytes of one [64 rows][32 ch] sub-image
+constexpr int NSUB = 12;           // 8 dY + 4 X sub-images per stage
+constexpr int STAGE = NSUB * SUBB; // 48 KiB
+constexpr int RING = 3;
+constexpr int TCO = 256, TCI = 128;
+
+__device__ __forceinline__ void dma16(const void* src, char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_dst, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+#define TR_RD(dst, base, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "i"(imm))
+#define LGKM_WAIT(n)                                       \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory");  \
+  __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ bf16x8 frag_of(const u32x2_t& lo, const u32x2_t& hi) {
+  u32x4 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(512, 1) void k_wgrad1x1(const bf16* __restrict__ X, const bf16* __restrict__ dY,
+                                                       float* __restrict__ slabs, const bf16* __restrict__ zeros,
+                                                       long Npix, int Cin, int Cout, int tiles_ci, long L) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tco = blockIdx.x / tiles_ci, tci = blockIdx.x % tiles_ci;
+  const int s = blockIdx.y;
+  const int co0 = tco * TCO, ci0 = tci * TCI;
+  const int wr = wave >> 1, wc = wave & 1;  // this wave's 64(co) x 64(ci) block
+  const long k0 = (long)s * L;
+  const long k1 = (k0 + L < Npix) ? k0 + L : Npix;
+  const int nst = (k1 > k0) ? (int)((k1 - k0 + KP - 1) / KP) : 0;
+
+  // ---- DMA plan: instruction j = wave + 8*i (i = 0..5) stages sub-image j/4, rows 16*(j%4) .. +15
+  const int drow = lane >> 2, dp = lane & 3;
+  const char* src[6];
+  long row_of[6];     // pixel row (within the stage) this lane stages: tail test
+  int stride[6];      // bytes per stage advance
+  bool chan_ok[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int j = wave + 8 * i;
+    const int sub = j >> 2, rg = j & 3;
+    const int row = rg * 16 + drow;
+    row_of[i] = k0 + row;
+    if (sub < 8) {
+      const int co = co0 + sub * 32;
+      chan_ok[i] = co < Cout;
+      src[i] = reinterpret_cast<const char*>(dY + (k0 + row) * Cout + co + dp * 8);
+      stride[i] = KP * Cout * 2;
+    } else {
+      const int ci = ci0 + (sub - 8) * 32;
+      chan_ok[i] = ci < Cin;
+      src[i] = reinterpret_cast<const char*>(X + (k0 + row) * Cin + ci + dp * 8);
+      stride[i] = KP * Cin * 2;
+    }
+  }
+  auto issue = [&](int t) {  // stage t from the current pointers, then advance them
+    char* dst = smem + (t % RING) * STAGE;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int j = wave + 8 * i;
+      const bool ok = chan_ok[i] && row_of[i] < k1;
+      dma16(ok ? (const void*)src[i] : (const void*)zeros, dst + (j >> 2) * SUBB + (j & 3) * 1024);
+      src[i] += stride[i];
+      row_of[i] += KP;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // transposing-read lane geometry (as conv_wgrad2.hip): 16 k-rows x 32 channels per fragment, two b64 reads
+  const int krow_l = 8 * (lane >> 5) + ((lane & 15) >> 2);
+  const int chan_b = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem + krow_l * 64 + chan_b;
+  const unsigned a_rel = lds0 + (wr * 2) * SUBB;       // dY sub-images 2wr, 2wr+1
+  const unsigned b_rel = lds0 + (8 + wc * 2) * SUBB;   // X sub-images 2wc, 2wc+1
+
+  if (nst > 0) {
+    issue(0);
+    if (nst > 1) issue(1);
+  }
+  for (int t = 0; t < nst; ++t) {
+    if (t + 1 < nst) wait_vmcnt<6>();  // stage t landed; stage t+1 (6 DMAs per wave) may stay in flight
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nst) issue(t + 2);  // ring slot of stage t-1: every wave is past its reads (barrier above)
+    const unsigned sb = (t % RING) * STAGE;
+    const unsigned au = a_rel + sb, bu = b_rel + sb;
+    u32x2_t A[2][2][2], Bf[2][2][2];  // [set][block][half]
+#define RD(set, ks)                                                                                   \
+  TR_RD(A[set][0][0], au, (ks) * 1024);         TR_RD(A[set][0][1], au, (ks) * 1024 + 256);           \
+  TR_RD(A[set][1][0], au, SUBB + (ks) * 1024);  TR_RD(A[set][1][1], au, SUBB + (ks) * 1024 + 256);    \
+  TR_RD(Bf[set][0][0], bu, (ks) * 1024);        TR_RD(Bf[set][0][1], bu, (ks) * 1024 + 256);          \
+  TR_RD(Bf[set][1][0], bu, SUBB + (ks) * 1024); TR_RD(Bf[set][1][1], bu, SUBB + (ks) * 1024 + 256)
+#define MM(set)                                                                                                  \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(A[set][0][0], A[set][0][1]),                       \
+                                                     frag_of(Bf[set][0][0], Bf[set][0][1]), acc[0][0], 0, 0, 0); \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(A[set][0][0], A[set][0][1]),                       \
+                                                     frag_of(Bf[set][1][0], Bf[set][1][1]), acc[0][1], 0, 0, 0); \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(A[set][1][0], A[set][1][1]),                       \
+                                                     frag_of(Bf[set][0][0], Bf[set][0][1]), acc[1][0], 0, 0, 0); \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(A[set][1][0], A[set][1][1]),                       \
+                                                     frag_of(Bf[set][1][0], Bf[set][1][1]), acc[1][1], 0, 0, 0)
+    RD(0, 0);
+    RD(1, 1); LGKM_WAIT(8); MM(0); __builtin_amdgcn_sched_barrier(0);
+    RD(0, 2); LGKM_WAIT(8); MM(1); __builtin_amdgcn_sched_barrier(0);
+    RD(1, 3); LGKM_WAIT(8); MM(0); __builtin_amdgcn_sched_barrier(0);
+    LGKM_WAIT(0); MM(1); __builtin_amdgcn_sched_barrier(0);
+#undef RD
+#undef MM
+  }
+
+  // ---- this split's slab: lane holds column ci = l31 of each block, rows (r&3) + 8*(r>>2) + 4*lhi
+  const int l31 = lane & 31, lhi = lane >> 5;
+  float* base = slabs + (long)s * Cout * Cin;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int ci = ci0 + wc * 64 + b * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (co < Cout && ci < Cin) base[(long)co * Cin + ci] = acc[a][b][r];
+      }
+    }
+}
+
+bf16* g_zero_page_1 = nullptr;
+
+}  // namespace
+
+// Number of split-K slabs edm_conv_wgrad_1x1 writes for this shape (sizes the workspace [S][Cout][Cin] fp32).
+extern "C" int edm_conv_wgrad_1x1_nsplit(long npix, int Cin, int Cout) {
+  if (npix <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  const int tiles = ((Cout + TCO - 1) / TCO) * ((Cin + TCI - 1) / TCI);
+  long S = (256 + tiles - 1) / tiles;            // ~one workgroup per CU
+  const long max_s = (npix + 4 * KP - 1) / (4 * KP);  // at least 4 stages per workgroup
+  if (S > max_s) S = max_s;
+  if (S < 1) S = 1;
+  return (int)S;
+}
+
+// X [npix, Cin] bf16, dY [npix, Cout] bf16 (NHWC flattened) -> slabs fp32 [nsplit][Cout][Cin]; Cin, Cout % 32 == 0.
+extern "C" int edm_conv_wgrad_1x1(const void* X, const void* dY, float* slabs, long npix, int Cin, int Cout, int nsplit,
+                                  hipStream_t st) {
+  EDM_REQUIRE(X && dY && slabs, "conv_wgrad_1x1: null pointer");
+  EDM_REQUIRE(npix > 0 && npix < (1L << 31), "conv_wgrad_1x1: bad pixel count");
+  EDM_REQUIRE(Cin > 0 && Cin % 32 == 0 && Cout > 0 && Cout % 32 == 0, "conv_wgrad_1x1: Cin, Cout must be multiples of 32");
+  EDM_REQUIRE(nsplit == edm_conv_wgrad_1x1_nsplit(npix, Cin, Cout), "conv_wgrad_1x1: nsplit mismatch");
+  if (!g_zero_page_1) {
+    if (hipMalloc((void**)&g_zero_page_1, 256) != hipSuccess || hipMemset(g_zero_page_1, 0, 256) != hipSuccess) {
+      edm_set_error("conv_wgrad_1x1: cannot allocate the zero page");
+      return EDM_ERR_LAUNCH;
+    }
+  }
+  long L = (npix + nsplit - 1) / nsplit;
+  L = (L + KP - 1) / KP * KP;
+  const int tiles_co = (Cout + TCO - 1) / TCO, tiles_ci = (Cin + TCI - 1) / TCI;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad1x1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_wgrad1x1, dim3(tiles_co * tiles_ci, nsplit), dim3(512), (size_t)RING * STAGE, st, (const bf16*)X,
+                     (const bf16*)dY, slabs, (const bf16*)g_zero_page_1, npix, Cin, Cout, tiles_ci, L);
+  EDM_CHECK_LAUNCH("conv_wgrad_1x1");
+  return EDM_OK;
+}

@@ -549,7 +549,7 @@ class _ResBlockFn(torch.autograd.Function):
             # d loss / d lin goes into this block's column slice of the shared buffer; _EmbedAllFn.backward turns
             # the whole buffer into the embed-weight and embedding gradients with two GEMMs
             gr1, _, ggain = ops.mod_silu_drop_bwd(r1, lin, gain, ga2, pdrop, seed, sub, step, glin_out=ctx.glin_view)
-            gtoken = torch.zeros(1, device=gout.device, dtype=f32)
+            gtoken = ops.zeros_f32((1,), gout.device)
         else:
             gr1, glin, ggain = ops.mod_silu_drop_bwd(r1, lin, gain, ga2, pdrop, seed, sub, step)
             dweh = ops.linear_wgrad(glin, emb)
@@ -742,10 +742,10 @@ class _EmbedAllFn(torch.autograd.Function):
         whs = [b.embed.packs()[2] for b in blocks]
         wcat = torch.cat(whs, 0)
         lin_all = ops.linear_fwd(emb, wcat)
-        glin_all = torch.zeros_like(lin_all)
+        glin_all = ops.zeros_f32(lin_all.shape, lin_all.device)
         ctx.den, ctx.glin_all = den, glin_all
         ctx.save_for_backward(emb, wcat)
-        token = torch.zeros(1, device=emb.device, dtype=f32)
+        token = ops.zeros_f32((1,), emb.device)
         ctx.mark_non_differentiable(lin_all, glin_all)
         return lin_all, glin_all, token
 

@@ -41,6 +41,40 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _ZeroPool:
+    """Zero-initialised fp32 scratch for the atomically-accumulated outputs (reductions, small weight grads).
+
+    One training step needs ~110 such tensors; a `torch.zeros` each is a fill launch each.  The pool zeroes a
+    16 MiB chunk with ONE fill and hands out disjoint 256-byte-aligned pieces; a chunk is never reused (pieces keep
+    its storage alive), so lifetime rules are those of ordinary tensors.  Pieces are fresh tensors on the shared
+    storage, not views, so they do not share autograd version counters.  During stream capture every request is
+    a real `torch.zeros` (a captured graph must re-zero its accumulators on every replay)."""
+    CHUNK = 1 << 22  # floats
+
+    def __init__(self):
+        self.buf, self.off = None, 0
+
+    def take(self, shape, device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n_al = (n + 63) // 64 * 64
+        if n_al > self.CHUNK // 4 or torch.cuda.is_current_stream_capturing():
+            return torch.zeros(shape, device=device, dtype=f32)
+        if self.buf is None or self.off + n_al > self.CHUNK or self.buf.device != device:
+            self.buf, self.off = torch.zeros(self.CHUNK, device=device, dtype=f32), 0
+        out = torch.empty(0, device=device, dtype=f32).set_(self.buf.untyped_storage(), self.off, tuple(shape))
+        self.off += n_al
+        return out
+
+
+_zero_pool = _ZeroPool()
+
+
+def zeros_f32(shape, device):
+    return _zero_pool.take(tuple(shape), device)
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -136,10 +170,10 @@ def mod_silu_drop_bwd(r, lin, gain, ga, pdrop, seed, sub, step, glin_out=None):
     ls = _lin_view(lin, B, C, "lin")
     _chk(ga, bf16, "ga", r.shape)
     gr = torch.empty_like(r)
-    gm = torch.zeros(B, C, device=r.device, dtype=f32)
+    gm = zeros_f32((B, C), r.device)
     glin = torch.empty(B, C, device=r.device, dtype=f32) if glin_out is None else glin_out
     gs = _lin_view(glin, B, C, "glin")
-    ggain = torch.zeros((), device=r.device, dtype=f32)
+    ggain = zeros_f32((), r.device)
     _lib.call("edm_mod_silu_drop_bwd", _p(r), _p(lin), ls, _p(gain), _p(ga), _p(gr), _p(gm), _p(glin), gs, _p(ggain), B,
               H * W, C, float(pdrop), int(seed), int(sub), int(step), _stream())
     return gr, glin, ggain
@@ -173,7 +207,7 @@ def reduce_hw(x, C=None, c_off=0, y=None, scale=1.0):
     C = Cx - c_off if C is None else C
     if c_off % 8 or c_off + C > Cx:
         raise ValueError("reduce_hw: bad channel slice")
-    out = torch.zeros(B, C, device=x.device, dtype=f32)
+    out = zeros_f32((B, C), x.device)
     ys = 0
     if y is not None:
         By, Hy, Wy, Cy = _nhwc(y, "y")
@@ -202,8 +236,8 @@ def scalelong_bwd(mean, w1h, w2h, gate, z1, ggate):
     R = w1h.shape[0]
     _chk(ggate, f32, "ggate", (B, C))
     gmean = torch.empty(B, C, device=mean.device, dtype=f32)
-    gw1 = torch.zeros_like(w1h)
-    gw2 = torch.zeros_like(w2h)
+    gw1 = zeros_f32(w1h.shape, w1h.device)
+    gw2 = zeros_f32(w2h.shape, w2h.device)
     _lib.call("edm_scalelong_bwd", _p(mean), _p(w1h), _p(w2h), _p(gate), _p(z1), _p(ggate), _p(gmean), _p(gw1), _p(gw2),
               B, C, R, _stream())
     return gmean, gw1, gw2
@@ -271,8 +305,8 @@ def conv_out_bwd(x, w_hat, gain_out, Fraw, dD, sigma, sigma_data):
     _chk(Fraw, f32, "Fraw", (B, Co, H, W))
     ss = _sigma_arg(sigma, B)
     gx = torch.empty_like(x)
-    gw = torch.zeros_like(w_hat)
-    gg = torch.zeros((), device=x.device, dtype=f32)
+    gw = zeros_f32(w_hat.shape, w_hat.device)
+    gg = zeros_f32((), x.device)
     _lib.call("edm_conv_out_bwd", _p(x), _p(w_hat), _p(gain_out), _p(Fraw), _p(dD), _p(sigma), ss, float(sigma_data),
               _p(gx), _p(gw), _p(gg), B, H * W, C, Co, _stream())
     return gx, gw, gg
@@ -337,6 +371,7 @@ def conv_igemm(x, wp, taps, residual=None, alpha=1.0, beta=0.0):
     return y
 
 
+WGRAD_1X1 = os.environ.get("EDM_WGRAD_1X1", "1") != "0"
 WGRAD_VERSION = int(os.environ.get("EDM_WGRAD", "2"))   # 1 = register-staged kernel, 2 = LDS-DMA rolling-window kernel
 
 
@@ -346,9 +381,16 @@ def conv_wgrad(x, dy, taps):
     Bd, Hd, Wd, Cout = _nhwc(dy, "dy")
     if (Bd, Hd, Wd) != (B, H, W):
         raise ValueError("conv_wgrad: x/dy spatial mismatch")
+    npix = B * H * W
+    if taps == 1 and WGRAD_1X1 and Cin % 32 == 0 and Cout % 32 == 0:
+        # dedicated 1x1 kernel: 256x128-output tiles (the 64x64 tiles below are L2->LDS bound on 1x1 layers)
+        S = _lib.call("edm_conv_wgrad_1x1_nsplit", npix, Cin, Cout)
+        slabs = torch.empty(S, 1, Cout, Cin, device=x.device, dtype=f32)
+        with _prof("conv1x1_wgrad", 2.0 * npix * Cin * Cout, 2.0 * npix * (Cin + Cout) + 4.0 * slabs.numel()):
+            _lib.call("edm_conv_wgrad_1x1", _p(x), _p(dy), _p(slabs), npix, Cin, Cout, S, _stream())
+        return slabs
     S = _lib.call("edm_conv_wgrad_nsplit", B, H, W, Cin, Cout, taps)
     slabs = torch.empty(S, taps, Cout, Cin, device=x.device, dtype=f32)
-    npix = B * H * W
     with _prof("conv3x3_wgrad" if taps == 9 else "conv1x1_wgrad", 2.0 * npix * Cin * Cout * taps,
                2.0 * npix * (Cin + Cout) + 4.0 * slabs.numel()):
         # 3x3: LDS-DMA rolling-window kernel; 1x1: the register-staged kernel is (slightly) faster (r01 microbench)
@@ -503,7 +545,7 @@ def embed_combine_bwd(gout, pre, labels, add_factor, wcls_shape):
     ges = torch.empty_like(pre)
     gw, K = None, 0
     if labels is not None:
-        gw = torch.zeros(wcls_shape, device=pre.device, dtype=f32)
+        gw = zeros_f32(wcls_shape, pre.device)
         K = wcls_shape[1]
     _lib.call("edm_embed_combine_bwd", _p(gout), _p(pre), _p(labels), float(add_factor), K, _p(ges), _p(gw), B, E, _stream())
     return ges, gw
@@ -540,7 +582,7 @@ def weighted_mse(D, clean, sigma, sigma_data, weight=None, want_grad=True):
         _chk(weight, f32, "weight", (B,))
     else:
         _chk(sigma, f32, "sigma", (B,))
-    loss = torch.zeros((), device=D.device, dtype=f32)
+    loss = zeros_f32((), D.device)
     dD = torch.empty_like(D) if want_grad else None
     _lib.call("edm_weighted_mse", _p(D), _p(clean), _p(sigma), _p(weight), float(sigma_data), _p(loss), _p(dD), B,
               D.numel() // B, _stream())
