@@ -89,58 +89,57 @@ __global__ __launch_bounds__(256) void k_weight_prep_multi(const PrepDesc* __res
 }
 
 // grad[mo, i, t] (=|+=) projection( scale * sum_s slabs[s, t, r, i] ) through w_hat = w/(d*sqrt(n))
-__global__ __launch_bounds__(256) void k_wgrad_finish(const float* __restrict__ slabs, int S, const float* __restrict__ w,
-                                                        float* __restrict__ grad, const int* __restrict__ perm, int O,
-                                                        int I, int Ipad, int taps, float scale, int accumulate) {
-  extern __shared__ __attribute__((aligned(16))) float g[];  // n floats
-  __shared__ float red[8];
+// One workgroup per packed row r.  The slab sum is a pure HBM stream of S*n floats per row whose rate is set by
+// the bytes in flight: work item (e4, sg) sums slabs sg, sg+G, ... of one 16-byte vector with 8 loads in flight,
+// G = s-groups per vector (host-chosen so that E4*G ~ one block), partials meet in LDS in a fixed order
+// (deterministic).  part: [G][n] floats in packed (t major, i minor) order; g: [n] floats in master order.
+__global__ __launch_bounds__(1024) void k_wgrad_finish(const float* __restrict__ slabs, int S, const float* __restrict__ w,
+                                                         float* __restrict__ grad, const int* __restrict__ perm, int O,
+                                                         int I, int Ipad, int taps, float scale, int accumulate, int G) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ float red[16];
   const int r = blockIdx.x;
   const int mo = perm ? perm[r] : r;
   const int n = I * taps;
+  float* part = sm;            // [G][n]
+  float* g = sm + (long)G * n; // [n]
   const float* row = w + (long)mo * n;
   const long slab_stride = (long)taps * O * Ipad;
-  float dot = 0.f, ss = 0.f;
-  // iterate in packed order (t major, i minor) for coalesced slab reads; 16-byte loads, 4 slabs in flight per lane
-  // (the pass is a pure HBM stream of S*n floats per row: bytes in flight per CU set its rate)
   if ((I & 3) == 0 && (Ipad & 3) == 0) {
-    const int I4 = I >> 2;
-    for (int e4 = threadIdx.x; e4 < taps * I4; e4 += blockDim.x) {
+    const int I4 = I >> 2, E4 = taps * I4;
+    for (int idx = threadIdx.x; idx < E4 * G; idx += blockDim.x) {
+      const int sg = idx / E4, e4 = idx - sg * E4;
       const int t = e4 / I4, i = (e4 - t * I4) * 4;
       const float* sp = slabs + ((long)t * O + r) * Ipad + i;
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
-      int s = 0;
-      for (; s + 4 <= S; s += 4) {
-        f32x4 v[4];
+      int s = sg;
+      for (; s + 7 * G < S; s += 8 * G) {
+        f32x4 v[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(sp + (s + u) * slab_stride);
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(sp + (long)(s + u * G) * slab_stride);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a += v[u];
+        for (int u = 0; u < 8; ++u) a += v[u];
       }
-      for (; s < S; ++s) a += *reinterpret_cast<const f32x4*>(sp + s * slab_stride);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float av = a[q] * scale;
-        const float wv = row[(i + q) * taps + t];
-        g[(i + q) * taps + t] = av;
-        dot += av * wv;
-        ss += wv * wv;
-      }
+      for (; s < S; s += G) a += *reinterpret_cast<const f32x4*>(sp + (long)s * slab_stride);
+      *reinterpret_cast<f32x4*>(part + (long)sg * n + e4 * 4) = a;
     }
-  } else
-  for (int e = threadIdx.x; e < n; e += blockDim.x) {
-    const int t = e / I, i = e - t * I;
-    const float* sp = slabs + ((long)t * O + r) * Ipad + i;
+  } else {
+    for (int idx = threadIdx.x; idx < n * G; idx += blockDim.x) {
+      const int sg = idx / n, e = idx - sg * n;
+      const int t = e / I, i = e - t * I;
+      const float* sp = slabs + ((long)t * O + r) * Ipad + i;
+      float a = 0.f;
+      for (int s = sg; s < S; s += G) a += sp[(long)s * slab_stride];
+      part[(long)sg * n + e] = a;
+    }
+  }
+  __syncthreads();
+  float dot = 0.f, ss = 0.f;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {  // e in packed order: (t, i)
     float a = 0.f;
-    int s = 0;
-    for (; s + 8 <= S; s += 8) {  // 8 independent loads in flight per lane
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = sp[(s + u) * slab_stride];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a += v[u];
-    }
-    for (; s < S; ++s) a += sp[s * slab_stride];
+    for (int sg = 0; sg < G; ++sg) a += part[(long)sg * n + e];
     a *= scale;
+    const int t = e / I, i = e - t * I;
     const float wv = row[i * taps + t];
     g[i * taps + t] = a;
     dot += a * wv;
@@ -193,9 +192,25 @@ extern "C" int edm_weight_prep_multi(const void* descs, const int* row2desc, int
 extern "C" int edm_wgrad_finish(const float* slabs, int S, const float* w, float* grad, const int* perm, int O, int I,
                                 int Ipad, int taps, float scale, int accumulate, hipStream_t st) {
   EDM_REQUIRE(slabs && w && grad && S > 0 && O > 0 && I > 0 && taps > 0 && Ipad >= I, "wgrad_finish: bad args");
-  EDM_REQUIRE((long)I * taps * 4 <= 64 * 1024, "wgrad_finish: fan_in %d too large for the LDS row buffer", I * taps);
-  hipLaunchKernelGGL(k_wgrad_finish, dim3(O), dim3(256), (size_t)I * taps * sizeof(float), st, slabs, S, w, grad, perm,
-                     O, I, Ipad, taps, scale, accumulate);
+  const int n = I * taps;
+  EDM_REQUIRE((long)n * 4 <= 64 * 1024, "wgrad_finish: fan_in %d too large for the LDS row buffer", n);
+  // work items = (16-byte vectors of the row) x (s-groups): aim at one full block, at most 8 groups, G | nothing
+  const int E = ((I & 3) == 0 && (Ipad & 3) == 0) ? n / 4 : n;
+  int G = 1;
+  while (G < 8 && 2 * G <= S && E * 2 * G <= 1024 && (long)(2 * G + 1) * n * 4 <= 96 * 1024) G *= 2;
+  const int items = E * G;
+  const int passes = (items + 1023) / 1024;
+  int threads = ((items + passes - 1) / passes + 63) / 64 * 64;
+  if (threads < 64) threads = 64;
+  if (threads > 1024) threads = 1024;
+  const size_t lds = (size_t)(G + 1) * n * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_finish), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_wgrad_finish, dim3(O), dim3(threads), lds, st, slabs, S, w, grad, perm, O, I, Ipad, taps, scale,
+                     accumulate, G);
   EDM_CHECK_LAUNCH("wgrad_finish");
   return EDM_OK;
 }
