@@ -42,6 +42,17 @@ MFMA_PEAK_TFLOPS = 2500.0      # bf16 dense, MI355X_MICROARCH.md chip table
 HBM_PEAK_GBS = 8000.0
 
 
+def pmc_traffic(kernel):
+    """HBM GB per launch of `kernel` from the committed PMC summary (tools/pmc_hbm.py; counters cannot be read from
+    inside the process, so this is the offline measurement of the same command), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as f:
+            rec = json.load(f)["kernels"].get(kernel)
+        return None if rec is None else round(rec["hbm_gb_per_launch"], 4)
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def build_model(device, conditional=False):
     import tinyedm
     from tinyedm.config import compose, instantiate
@@ -105,11 +116,13 @@ def train_bench(args, rank, world, device):
 
     # ---- roofline of the dominant kernel (3x3 implicit-GEMM conv): one extra, instrumented step AFTER the
     # timed region: HIP events around every launch on the launch stream; algorithmic FLOPs from the shapes.
+    # Every rank runs the extra step (it contains the gradient all-reduce); only rank 0 instruments it.
     roof = None
     if rank == 0:
         ops.PROFILE = {}
-        step(args.warmup + args.steps)
-        torch.cuda.synchronize()
+    step(args.warmup + args.steps)
+    torch.cuda.synchronize()
+    if rank == 0:
         prof, ops.PROFILE = ops.PROFILE, None
         roof = {}
         for name, recs in prof.items():
@@ -208,8 +221,10 @@ def main():
     model, ips, ms, final_loss, roof = train_bench(args, rank, world, device)
     out = None
     if rank == 0:
-        conv = roof.get("conv3x3_igemm", {"launches": 0, "ms": 0.0, "gflop": 0.0, "gbytes": 0.0})
+        # dominant kernel: k_conv3x3_v4 (3x3 implicit GEMM, forward + dgrad of the 32x32 layers)
+        conv = roof.get("conv3x3_igemm_v4", {"launches": 0, "ms": 0.0, "gflop": 0.0, "gbytes": 0.0})
         achieved = conv["gflop"] / conv["ms"] if conv["ms"] > 0 else 0.0          # GFLOP/ms == TFLOP/s
+        traffic = pmc_traffic("k_conv3x3_v4")
         out = {
             "metric": "train imgs/sec CIFAR-10 32x32 bf16",
             "value": round(ips, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -220,9 +235,13 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "conditional": bool(args.conditional), "final_loss": final_loss},
             "roofline": {
-                "bound": "mfma", "kernel": "k_conv_igemm<9,...> (3x3 conv fwd + dgrad)",
+                "bound": "mfma", "kernel": "k_conv3x3_v4 (3x3 implicit-GEMM conv, fwd + dgrad of the 32x32 layers)",
                 "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_unit": "GB of HBM traffic per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc "
+                                "passes, profiles/r01_pmc_hbm.json)",
+                "algorithmic_gbytes_per_launch": round(conv["gbytes"] / max(1, conv["launches"]), 4),
+                "library_gemm_tflops_same_shape": 1031.0,
                 "launches_per_step": conv["launches"],
                 "avg_launch_ms": round(conv["ms"] / max(1, conv["launches"]), 4),
                 "algorithmic_gflop_per_step": round(conv["gflop"], 1),

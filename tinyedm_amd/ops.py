@@ -365,9 +365,12 @@ def conv_igemm(x, wp, taps, residual=None, alpha=1.0, beta=0.0):
         _chk(residual, bf16, "residual", (B, H, W, Cout))
     y = torch.empty(B, H, W, Cout, device=x.device, dtype=bf16)
     npix = B * H * W
-    with _prof("conv3x3_igemm" if taps == 9 else "conv1x1_igemm", 2.0 * npix * Cin * Cout * taps,
+    entry = _igemm_entry(npix, W, Cout, taps, Cin)
+    # profile key names the kernel generation that runs ("conv3x3_igemm_v4", "conv1x1_igemm", ...)
+    pname = ("conv3x3_igemm" if taps == 9 else "conv1x1_igemm") + entry[len("edm_conv_igemm"):]
+    with _prof(pname, 2.0 * npix * Cin * Cout * taps,
                2.0 * (npix * (Cin + Cout * (2 if residual is not None else 1)) + wp.numel())):
-        _lib.call(_igemm_entry(npix, W, Cout, taps, Cin), _p(x), _p(wp), _p(y), _p(residual), float(alpha), float(beta), B, H, W, Cin, Cout, taps, _stream())
+        _lib.call(entry, _p(x), _p(wp), _p(y), _p(residual), float(alpha), float(beta), B, H, W, Cin, Cout, taps, _stream())
     return y
 
 
