@@ -89,3 +89,59 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
   return Philox4{c0, c1, c2, c3};
 }
 __device__ __forceinline__ float u32_to_unit(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }  // [0,1)
+
+// ---- wave-level transposed tile store for the implicit-GEMM kernels.
+// acc[NI][NJ] are 32x32 MFMA accumulator blocks whose ROWS are output channels cw0 + 32 i + (8 g + 4 lhi + r) and
+// whose COLUMNS are pixels mb0 + 32 j + l31.  Storing them straight from that layout puts 8-byte pieces of 64
+// different rows into each store instruction (measured 1.7-2x the algorithmic HBM write bytes).  Instead each wave
+// transposes 32 pixels x NI*32 channels at a time through `stage` (wave-private LDS, 32 * (NI*64 + 16) bytes,
+// padded rows): the residual is read and the result written 16 B per lane, whole rows per instruction.
+// y = alpha * acc + beta * R is formed in fp32 and rounded to bf16 once.  The caller must have passed a workgroup
+// barrier after its last read of the LDS bytes that `stage` overlays.
+template <int NI, int NJ>
+__device__ __forceinline__ void store_tile_transposed(const f32x16 (&acc)[NI][NJ], char* stage, bf16* __restrict__ Y,
+                                                      const bf16* __restrict__ R, float alpha, float beta, long mb0,
+                                                      long Npix, int cw0, int Cout) {
+  constexpr int EROW = NI * 64 + 16, CPR = NI * 4, RPI = 64 / CPR;  // 16-byte chunks per row, rows per instruction
+  const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int c16 = lane % CPR, prow = lane / CPR;
+  const int co_c = cw0 + c16 * 8;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const long mb = mb0 + j * 32;
+    if (R) {
+#pragma unroll
+      for (int it = 0; it < 32 / RPI; ++it) {
+        const int px = it * RPI + prow;
+        u32x4 rv = {0u, 0u, 0u, 0u};
+        if (mb + px < Npix && co_c < Cout) rv = *reinterpret_cast<const u32x4*>(R + (mb + px) * Cout + co_c);
+        *reinterpret_cast<u32x4*>(stage + px * EROW + c16 * 16) = rv;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        char* sp = stage + l31 * EROW + (i * 32 + 8 * g + 4 * lhi) * 2;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = alpha * acc[i][j][4 * g + r];
+        if (R) {
+          bf16x4 rv = *reinterpret_cast<const bf16x4*>(sp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += beta * (float)rv[r];
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+        *reinterpret_cast<bf16x4*>(sp) = o;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int px = it * RPI + prow;
+      const u32x4 ov = *reinterpret_cast<const u32x4*>(stage + px * EROW + c16 * 16);
+      if (mb + px < Npix && co_c < Cout) *reinterpret_cast<u32x4*>(Y + (mb + px) * Cout + co_c) = ov;
+    }
+  }
+}

@@ -174,33 +174,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ 
     chunk = nchunk;
   }
 
-  // ---- epilogue: lane holds, per (i,j), pixel = col(l31) and 4x4 consecutive output channels
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const long m = (long)m0 + wn * (32 * NJ) + j * 32 + l31;
-    if (m >= Npix) continue;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = n0 + wm * 64 + i * 32 + 8 * g + 4 * lhi;
-        if (co < Cout) {
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = alpha * acc[i][j][4 * g + r];
-          if (R) {
-            bf16x4 rv = *reinterpret_cast<const bf16x4*>(R + m * Cout + co);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += beta * (float)rv[r];
-          }
-          bf16x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
-          *reinterpret_cast<bf16x4*>(Y + m * Cout + co) = o;
-        }
-      }
-    }
-  }
+  // ---- epilogue: transposed through wave-private LDS (common.h: store_tile_transposed)
+  __syncthreads();  // every wave is done with the staged tiles
+  store_tile_transposed<2, NJ>(acc, smem + (wm * 2 + wn) * (32 * (2 * 64 + 16)), Y, R, alpha, beta,
+                               (long)m0 + wn * (32 * NJ), Npix, n0 + wm * 64, Cout);
 }
 
 template <int TAPS, int KC, int XL, int NJ = 2>

@@ -225,33 +225,10 @@ __global__ __launch_bounds__(512, 4) void k_conv_igemm2(const bf16* __restrict__
     atomicAdd(dbg + 5, 1ull);
   }
 
-  // ---- epilogue: lane holds, per (i,j), pixel = col(l31) and 4x4 consecutive output channels
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const long m = (long)m0 + wn * 64 + j * 32 + l31;
-    if (m >= Npix) continue;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = n0 + wm * 64 + i * 32 + 8 * g + 4 * lhi;
-        if (co < Cout) {
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = alpha * acc[i][j][4 * g + r];
-          if (R) {
-            bf16x4 rv = *reinterpret_cast<const bf16x4*>(R + m * Cout + co);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += beta * (float)rv[r];
-          }
-          bf16x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
-          *reinterpret_cast<bf16x4*>(Y + m * Cout + co) = o;
-        }
-      }
-    }
-  }
+  // ---- epilogue: transposed through wave-private LDS (common.h: store_tile_transposed)
+  __syncthreads();  // every wave is done with the staged tiles
+  store_tile_transposed<2, 2>(acc, smem + (wm * 4 + wn) * (32 * (2 * 64 + 16)), Y, R, alpha, beta, (long)m0 + wn * 64, Npix,
+                              n0 + wm * 64, Cout);
 }
 
 bf16* g_zero_page = nullptr;

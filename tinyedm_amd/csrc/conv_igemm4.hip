@@ -226,33 +226,11 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
   }
 #undef READ_HALF
 
-  // ---- epilogue: lane holds, per (i,j), pixel = col(l31) and 4x4 consecutive output channels
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const long m = (long)m0 + wave * 64 + j * 32 + l31;
-    if (m >= Npix) continue;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = n0 + i * 32 + 8 * g + 4 * lhi;
-        if (co < Cout) {
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = alpha * acc[i][j][4 * g + r];
-          if (R) {
-            bf16x4 rv = *reinterpret_cast<const bf16x4*>(R + m * Cout + co);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += beta * (float)rv[r];
-          }
-          bf16x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
-          *reinterpret_cast<bf16x4*>(Y + m * Cout + co) = o;
-        }
-      }
-    }
-  }
+  // ---- epilogue: transposed through wave-private LDS so that residual reads and stores are whole rows
+  // (common.h: store_tile_transposed; direct stores from the MFMA layout cost 1.7x the HBM write bytes)
+  __builtin_amdgcn_s_barrier();  // every wave is done with the slab / weight ring
+  store_tile_transposed<4, 2>(acc, smem + wave * (32 * (4 * 64 + 16)), Y, R, alpha, beta, (long)m0 + wave * 64, Npix, n0,
+                              Cout);
 }
 
 char* g_zero_page4 = nullptr;
