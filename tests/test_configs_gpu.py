@@ -1,0 +1,134 @@
+"""The reference's other configurations (BASELINE.json configs[0], [2]-[4]) as parity cases on the GPU:
+
+ * MNIST  (experiments/conf/mnist.yaml): 1 channel, 28x28 -> 14x14 -> 7x7, widths 128/256/512, head dims 64 and 128;
+ * CIFAR-10 class-conditional (conf/cifar10.yaml + num_classes 10);
+ * the default ImageNet-64 / latent `Denoiser` (networks.py:332-433 tables: 192/384/576/768, head dims 144 / 192,
+   in_channels 4 as in conf/imagenet.yaml) at 64x64 and at the 32x32 latent size.
+
+Each is checked against the CPU oracle run with the same bf16 rounding points on the same seeded parameters
+(the oracle itself is pinned to the reference by tests/test_oracle_golden.py); batches are tiny so the CPU side
+finishes in seconds.  Training-mode checks: loss against the oracle, finite gradients for every parameter.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import edm_oracle as O
+
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def build(ecfg, dcfg, P, device=DEV):
+    import tinyedm_amd as T
+    emb = T.Embedding(ecfg.fourier_dim, ecfg.embedding_dim, ecfg.num_classes, ecfg.add_factor)
+    den = T.Denoiser(dcfg.in_channels, dcfg.out_channels, tuple(dcfg.encoder_block_types),
+                     tuple(dcfg.decoder_block_types), tuple(dcfg.encoder_out_channels),
+                     tuple(dcfg.decoder_out_channels), tuple(dcfg.skip_connections), dcfg.dropout_rate,
+                     dcfg.sigma_data, dcfg.encoder_add_factor, dcfg.decoder_add_factor, dcfg.embedding_dim,
+                     dcfg.num_heads)
+    emb.load_state_dict({k[len("embedding."):]: v for k, v in P.items() if k.startswith("embedding.")}, strict=True)
+    den.load_state_dict({k[len("denoiser."):]: v for k, v in P.items() if k.startswith("denoiser.")}, strict=True)
+    return emb.to(device), den.to(device)
+
+
+def mnist_cfg():
+    e = O.EmbeddingCfg(64, 256, 10)
+    d = O.DenoiserCfg(
+        1, 1,
+        ["Enc", "Enc", "Enc", "EncD", "EncA", "EncA", "EncA", "EncD", "EncA", "EncA", "EncA"],
+        ["DecA", "Dec", "DecA", "DecA", "DecA", "DecA", "DecU", "DecA", "DecA", "DecA", "DecA", "DecU", "Dec", "Dec",
+         "Dec", "Dec"],
+        [128, 128, 128, 128, 256, 256, 256, 256, 512, 512, 512],
+        [512, 512, 512, 512, 512, 512, 512, 256, 256, 256, 256, 256, 128, 128, 128, 128],
+        [False, False, True, True, True, True, False, True, True, True, True, False, True, True, True, True],
+        dropout_rate=0.1, sigma_data=0.5, embedding_dim=256, num_heads=4)
+    return e, d
+
+
+def imagenet_cfg():
+    import tinyedm_amd.networks as N
+    e = O.EmbeddingCfg(192, 768, 1000)
+    d = O.DenoiserCfg(4, 4, list(N.get_encoder_blocks_types()), list(N.get_decoder_blocks_types()),
+                      list(N.get_encoder_out_channels()), list(N.get_decoder_out_channels()),
+                      list(N.get_skip_connections()), dropout_rate=0.0, sigma_data=0.5, embedding_dim=768, num_heads=4)
+    return e, d
+
+
+def eval_parity(ecfg, dcfg, shape, seed, tol):
+    g = torch.Generator().manual_seed(seed)
+    P = O.init_params(ecfg, dcfg, g)
+    emb, den = build(ecfg, dcfg, P)
+    emb.eval(); den.eval()
+    B = shape[0]
+    noisy = torch.randn(*shape, generator=g) * 1.3
+    sigma = torch.exp(torch.randn(B, generator=g) * 1.2 - 1.2)
+    labels = torch.randint(0, ecfg.num_classes, (B,), generator=g) if ecfg.num_classes else None
+    with torch.no_grad():
+        _, e = emb(sigma.to(DEV), None if labels is None else labels.to(DEV))
+        D = den(noisy.to(DEV), sigma.to(DEV), e)
+    assert D.shape == noisy.shape and D.dtype == torch.float32
+    D_or = O.edm_forward(P, ecfg, dcfg, noisy, sigma, labels, bf16=True)
+    c_skip, _, _ = O.precond_scalars(sigma, dcfg.sigma_data)
+    base = c_skip * noisy
+    r = rel(D.cpu() - base, D_or - base)
+    assert r <= tol, f"eval forward rel {r:.3e}"
+    return P, emb, den, (noisy, sigma, labels)
+
+
+def train_smoke(emb, den, batch, P=None, ecfg=None, dcfg=None, loss_tol=None):
+    """One training-mode forward/backward through the HIP path; with P: loss vs the bf16 oracle (dropout off)."""
+    from tinyedm_amd import metric
+    noisy, sigma, labels = batch
+    emb.train(); den.train()
+    clean = (noisy * 0.3).to(DEV)
+    _, e = emb(sigma.to(DEV), None if labels is None else labels.to(DEV))
+    D = den(noisy.to(DEV), sigma.to(DEV), e)
+    s = sigma.to(DEV)
+    w = (s ** 2 + 0.25) / (s * 0.5) ** 2
+    loss = metric.weighted_mse_loss(w, D, clean)
+    loss.backward()
+    assert torch.isfinite(loss)
+    for mod in (emb, den):
+        for k, p in mod.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    if P is not None:
+        # the oracle's training forward (in-place weight renormalisation, dropout off) with bf16 rounding points
+        Pb = {k: v.clone() for k, v in P.items()}
+        O.force_normalize_(Pb)
+        _, eo = O.embedding_forward(Pb, ecfg, sigma, labels)
+        Do = O.denoiser_forward(Pb, dcfg, noisy, sigma, eo, training=True, bf16=True)
+        lo = O.weighted_mse((sigma ** 2 + 0.25) / (sigma * 0.5) ** 2, Do, noisy * 0.3)
+        assert abs(loss.item() - lo.item()) <= loss_tol * abs(lo.item()), (loss.item(), lo.item())
+
+
+def test_mnist_config_forward_and_training_step():
+    ecfg, dcfg = mnist_cfg()
+    P, emb, den, batch = eval_parity(ecfg, dcfg, (2, 1, 28, 28), seed=11, tol=1.5e-2)
+    den.dropout_rate = 0.0
+    for m in den.modules():
+        if hasattr(m, "dropout_rate"):
+            m.dropout_rate = 0.0
+    train_smoke(emb, den, batch, P, ecfg, dcfg, loss_tol=3e-2)
+
+
+def test_cifar10_conditional_config_forward():
+    ecfg, dcfg = O.cifar10_cfg(num_classes=10)
+    eval_parity(ecfg, dcfg, (3, 3, 32, 32), seed=5, tol=1.5e-2)
+
+
+def test_imagenet64_default_denoiser_forward_and_training_step():
+    ecfg, dcfg = imagenet_cfg()
+    P, emb, den, batch = eval_parity(ecfg, dcfg, (1, 4, 64, 64), seed=3, tol=2e-2)
+    train_smoke(emb, den, batch)
+
+
+def test_latent32_default_denoiser_forward():
+    """ImageNet-256 latent diffusion: the same default net on 32x32x4 latents (attention at 8x8 and 4x4)."""
+    ecfg, dcfg = imagenet_cfg()
+    eval_parity(ecfg, dcfg, (2, 4, 32, 32), seed=9, tol=2e-2)

@@ -366,18 +366,23 @@ def _qkv_perm(C, heads):
     return idx
 
 
-@pytest.mark.parametrize("B,H,W,heads", [(2, 16, 16, 4), (3, 8, 8, 2), (2, 4, 4, 1), (1, 14, 14, 2), (2, 7, 7, 1)])
-def test_attention_fwd_bwd(ops, B, H, W, heads):
-    g = torch.Generator().manual_seed(B + H + heads)
-    C = 64 * heads
+@pytest.mark.parametrize("B,H,W,heads,hd", [
+    (2, 16, 16, 4, 64), (3, 8, 8, 2, 64), (2, 4, 4, 1, 64), (1, 14, 14, 2, 64), (2, 7, 7, 1, 64),
+    # head dims of the other reference configs (streamed-operand kernels, attention_generic.hip):
+    # MNIST 512/4 @7x7, ImageNet-64 576/4 @16x16 and 768/4 @8x8, plus ragged token counts
+    (2, 7, 7, 2, 128), (1, 16, 16, 2, 144), (2, 8, 8, 2, 192), (1, 14, 14, 1, 144), (2, 5, 5, 1, 32), (1, 12, 12, 1, 192),
+    (1, 16, 16, 1, 128)])
+def test_attention_fwd_bwd(ops, B, H, W, heads, hd):
+    g = torch.Generator().manual_seed(B + H + heads + hd)
+    C = hd * heads
     N = H * W
     qkv_ref_layout = q(torch.randn(B, 3 * C, H, W, generator=g))          # reference channel order
     gy = q(torch.randn(B, C, H, W, generator=g))
     x = qkv_ref_layout.clone().requires_grad_(True)
-    t = x.view(B, heads, 64, 3, N)
+    t = x.view(B, heads, hd, 3, N)
     t = O.q_bf16(O.rms_div(t, [2]))
     qq, kk, vv = t.unbind(3)
-    s = torch.einsum("bhdi,bhdj->bhij", qq, kk) / 8.0
+    s = torch.einsum("bhdi,bhdj->bhij", qq, kk) / math.sqrt(hd)
     p = O.q_bf16(torch.softmax(s, dim=-1))
     y_ref = torch.einsum("bhij,bhdj->bhdi", p, vv).reshape(B, C, H, W)
     y_ref.backward(gy)

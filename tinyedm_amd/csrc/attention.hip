@@ -385,16 +385,26 @@ void launch_bwd(const void* qkv, const void* y, const void* gy, void* gqkv, int 
 }
 
 int check(int B, int N, int C, int heads, const char* who) {
-  EDM_REQUIRE(B > 0 && N > 0 && heads > 0 && C > 0, "%s: bad args", who);
-  EDM_REQUIRE(C == heads * D, "%s: only head_dim 64 is implemented (C=%d heads=%d)", who, C, heads);
+  EDM_REQUIRE(B > 0 && N > 0 && heads > 0 && C > 0 && C % heads == 0, "%s: bad args", who);
   EDM_REQUIRE(N <= 256, "%s: at most 256 tokens (got %d)", who, N);
   return EDM_OK;
 }
 
 }  // namespace
 
+// attention_generic.hip: streamed-operand kernels for head_dim != 64
+int edm_attention_fwd_generic(const void* qkv, void* y, int B, int N, int C, int heads, int D, hipStream_t st);
+int edm_attention_bwd_generic(const void* qkv, const void* y, const void* gy, void* gqkv, int B, int N, int C, int heads,
+                              int D, hipStream_t st);
+
 extern "C" int edm_attention_fwd(const void* qkv, void* y, int B, int N, int C, int heads, hipStream_t st) {
   if (int rc = check(B, N, C, heads, "attention_fwd")) return rc;
+  if (C != heads * D) {
+    const int rc = edm_attention_fwd_generic(qkv, y, B, N, C, heads, C / heads, st);
+    EDM_REQUIRE(rc == EDM_OK, "attention_fwd: head_dim %d is not built (64, 32, 128, 144, 192 are)", C / heads);
+    EDM_CHECK_LAUNCH("attention_fwd (generic)");
+    return EDM_OK;
+  }
   const int nt = (N + 31) / 32;
   if (nt <= 1) launch_fwd<1>(qkv, y, B, N, C, heads, st);
   else if (nt <= 2) launch_fwd<2>(qkv, y, B, N, C, heads, st);
@@ -407,6 +417,12 @@ extern "C" int edm_attention_fwd(const void* qkv, void* y, int B, int N, int C, 
 extern "C" int edm_attention_bwd(const void* qkv, const void* y, const void* gy, void* gqkv, int B, int N, int C,
                                  int heads, hipStream_t st) {
   if (int rc = check(B, N, C, heads, "attention_bwd")) return rc;
+  if (C != heads * D) {
+    const int rc = edm_attention_bwd_generic(qkv, y, gy, gqkv, B, N, C, heads, C / heads, st);
+    EDM_REQUIRE(rc == EDM_OK, "attention_bwd: head_dim %d is not built (64, 32, 128, 144, 192 are)", C / heads);
+    EDM_CHECK_LAUNCH("attention_bwd (generic)");
+    return EDM_OK;
+  }
   const int nt = (N + 31) / 32;
   if (nt <= 1) launch_bwd<1>(qkv, y, gy, gqkv, B, N, C, heads, st);
   else if (nt <= 2) launch_bwd<2>(qkv, y, gy, gqkv, B, N, C, heads, st);
