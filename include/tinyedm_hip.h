@@ -157,6 +157,18 @@ int edm_heun_correct(const float* x, const float* dx, const float* x1, const flo
                      long n, edm_stream_t stream);
 int edm_scale_f32(const float* x, float s, float* y, long n, edm_stream_t stream);
 
+/* ---------------------------------------------------------------- data formats either side of the path */
+/* resident uint8 dataset [N][C][H][W] -> fp32 NCHW batch: sample b = image index[b]; (x/255 - mean)/std with the
+ * optional per-sample horizontal flip (datamodules/cifar10datamodule.py:18-32, mnistdatamodule.py:18-30). */
+int edm_u8_gather_normalize(const void* data, const long* index, float* out, int B, int C, int H, int W, long n_images,
+                            float mean, float stdv, int flip, unsigned long long seed, unsigned epoch,
+                            edm_stream_t stream);
+/* (x*scale + offset).clip(0,255) -> uint8, layout preserved (cifar10datamodule.py:34-35: scale 127.5, offset 128) */
+int edm_denormalize_u8(const float* x, void* out, long n, float scale, float offset, edm_stream_t stream);
+/* clamp(pred*std[c]*2 + mean[c], 0, 1)*255 -> uint8 NHWC (callbacks.py:126-156, PreditionWriter) */
+int edm_prediction_to_u8_nhwc(const float* pred, void* out, int B, int C, int H, int W, const float* mean,
+                              const float* stdv, edm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,10 +6,11 @@ import tinyedm_amd as _impl
 from tinyedm_amd import *  # noqa: F401,F403
 from tinyedm_amd import config, edm, ema, metric, networks, solvers, utils  # noqa: F401
 
-for _name in ("config", "edm", "ema", "metric", "networks", "solvers", "utils", "trainer", "datamodules"):
+for _name in ("config", "edm", "ema", "metric", "networks", "solvers", "utils", "trainer", "datamodules", "callbacks"):
     try:
         _mod = __import__(f"tinyedm_amd.{_name}", fromlist=["_"])
     except ImportError:
         continue
     sys.modules[f"tinyedm.{_name}"] = _mod
+    globals()[_name] = _mod
 __all__ = _impl.__all__

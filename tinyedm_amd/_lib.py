@@ -72,6 +72,10 @@ SIGNATURES = {
     "edm_weight_prep": [P, I, I, I, I, P, P, P, P, I, P],
     "edm_weight_prep_multi": [P, P, I, I, P],
     "edm_wgrad_finish": [P, I, P, P, P, I, I, I, I, F, I, P],
+    # data.hip
+    "edm_u8_gather_normalize": [P, P, P, I, I, I, I, L, F, F, I, U64, U, P],
+    "edm_denormalize_u8": [P, P, L, F, F, P],
+    "edm_prediction_to_u8_nhwc": [P, P, I, I, I, I, P, P, P],
 }
 _RET = {"edm_last_error": ctypes.c_char_p}
 _NO_STATUS = {"edm_version", "edm_last_error", "edm_conv_wgrad_nsplit", "edm_conv_wgrad_1x1_nsplit"}

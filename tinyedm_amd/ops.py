@@ -623,3 +623,38 @@ def scale_f32(x, s):
     y = torch.empty_like(x)
     _lib.call("edm_scale_f32", _p(x), float(s), _p(y), x.numel(), _stream())
     return y
+
+
+# ------------------------------------------------------------------ data formats (csrc/data.hip)
+def u8_gather_normalize(data, index, mean=0.5, std=0.5, flip=False, seed=0, epoch=0):
+    """data uint8 (N,C,H,W) resident on the device, index int64 (B,) -> fp32 (B,C,H,W) = (x/255-mean)/std,
+    optionally flipped left-right per sample (Philox(seed; epoch, b))."""
+    _chk(data, torch.uint8, "data")
+    _chk(index, torch.int64, "index")
+    if data.dim() != 4 or index.dim() != 1:
+        raise ValueError("u8_gather_normalize: data must be (N,C,H,W), index (B,)")
+    N, C, H, W = data.shape
+    B = index.shape[0]
+    out = torch.empty(B, C, H, W, device=data.device, dtype=f32)
+    _lib.call("edm_u8_gather_normalize", _p(data), _p(index), _p(out), B, C, H, W, N, float(mean), float(std),
+              int(bool(flip)), int(seed) & 0xFFFFFFFFFFFFFFFF, int(epoch) & 0xFFFFFFFF, _stream())
+    return out
+
+
+def denormalize_u8(x, scale=127.5, offset=128.0):
+    """fp32 tensor -> uint8, same shape: (x*scale+offset).clip(0,255) truncated."""
+    _chk(x, f32, "x")
+    out = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    _lib.call("edm_denormalize_u8", _p(x), _p(out), x.numel(), float(scale), float(offset), _stream())
+    return out
+
+
+def prediction_to_u8_nhwc(pred, mean, std):
+    """fp32 (B,C,H,W) -> uint8 (B,H,W,C): clamp(pred*std*2+mean, 0, 1)*255 truncated (per-channel mean/std tensors)."""
+    _chk(pred, f32, "pred")
+    B, C, H, W = pred.shape
+    _chk(mean, f32, "mean", (C,))
+    _chk(std, f32, "std", (C,))
+    out = torch.empty(B, H, W, C, device=pred.device, dtype=torch.uint8)
+    _lib.call("edm_prediction_to_u8_nhwc", _p(pred), _p(out), B, C, H, W, _p(mean), _p(std), _stream())
+    return out

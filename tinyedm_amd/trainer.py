@@ -76,6 +76,7 @@ class Trainer:
         self.global_rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.reducer: Optional[GradReducer] = None
+        self.datamodule = None
 
     # ------------------------------------------------------------------ setup
     def _setup_distributed(self, model):
@@ -117,7 +118,11 @@ class Trainer:
     def fit(self, model, datamodule=None, train_dataloaders=None, val_dataloaders=None, ckpt_path=None):
         self._setup_distributed(model)
         self._configure(model)
+        self.datamodule = datamodule
+        if datamodule is not None and hasattr(datamodule, "setup"):
+            datamodule.setup("fit")
         self._call("on_fit_start", model)
+        self._call("on_train_start", model)
         train = train_dataloaders if train_dataloaders is not None else datamodule.train_dataloader()
         val = val_dataloaders
         if val is None and datamodule is not None and hasattr(datamodule, "val_dataloader"):
@@ -178,6 +183,9 @@ class Trainer:
         self._setup_distributed(model)
         model.trainer = self
         model.eval()
+        self.datamodule = datamodule
+        if dataloaders is None and hasattr(datamodule, "setup"):
+            datamodule.setup("predict")
         loader = dataloaders if dataloaders is not None else datamodule.predict_dataloader()
         outs = []
         for bi, batch in enumerate(loader):
