@@ -96,3 +96,57 @@ def test_resident_cifar_datamodule_and_png_writer(ops, tmp_path):
     back = np.asarray(Image.open(tmp_path / "png" / "2.png"))
     assert back.shape == (32, 32, 3)
     assert np.abs(back.astype(int) - np.transpose(img[2], (1, 2, 0)).astype(int)).max() <= 1
+
+
+def test_generate_callback_inside_fit_and_checkpoint_roundtrip(ops, tmp_path):
+    """in-training sampling through swap_ema_weights (callbacks.py:12-58) restores the training
+    weights; a saved checkpoint reloads (optionally with its EMA weights) into a model that samples identically."""
+    import tinyedm_amd as T
+    from tinyedm_amd.callbacks import GenerateCallback
+    from tinyedm_amd.datamodules import SyntheticImageDataModule
+    from oracle.make_golden import tiny_cfgs
+    ecfg, dcfg = tiny_cfgs()
+    T.manual_seed(3)
+    torch.manual_seed(3)
+    emb = T.Embedding(ecfg.fourier_dim, ecfg.embedding_dim, ecfg.num_classes, ecfg.add_factor)
+    den = T.Denoiser(dcfg.in_channels, dcfg.out_channels, tuple(dcfg.encoder_block_types),
+                     tuple(dcfg.decoder_block_types), tuple(dcfg.encoder_out_channels),
+                     tuple(dcfg.decoder_out_channels), tuple(dcfg.skip_connections), 0.0, dcfg.sigma_data,
+                     dcfg.encoder_add_factor, dcfg.decoder_add_factor, dcfg.embedding_dim, dcfg.num_heads)
+    model = T.EDM(diffuser=T.Diffuser(-1.2, 1.2), embedding=emb, denoiser=den, use_ema=True, use_uncertainty=False,
+                  steady_steps=10, rampup_steps=2, scheduler_interval="step", lr=1e-3, ema_length=0.13)
+    cb = GenerateCallback(T.DeterministicSolver(num_steps=3), (3, 16, 16), num_samples=4, every_n_epochs=1,
+                          output_dir=str(tmp_path / "gen"))
+    dm = SyntheticImageDataModule(8, (3, 16, 16), num_classes=ecfg.num_classes, num_samples=24)
+    tr = T.Trainer(max_epochs=1, callbacks=[cb], check_val_every_n_epoch=100)
+    seen = {}
+    orig = cb.on_train_epoch_end
+
+    def wrapped(trainer, pl_module):
+        before = [p.detach().clone() for p in pl_module.parameters()]
+        orig(trainer, pl_module)
+        seen["same"] = all(torch.equal(a, b) for a, b in zip(before, pl_module.parameters()))
+    cb.on_train_epoch_end = wrapped
+    tr.fit(model, datamodule=dm)
+    assert seen["same"], "swap_ema_weights must restore the training weights"
+    assert cb.last_grid is not None and cb.last_grid.dtype == np.uint8
+    assert os.path.exists(tmp_path / "gen" / "epoch_00000.png")
+    assert model.training
+    # checkpoint in the reference's key layout -> load_from_checkpoint (edm.py:159-203), with and without EMA weights
+    path = str(tmp_path / "last.ckpt")
+    ck = tr.save_checkpoint(path)
+    assert {"state_dict", "hyper_parameters", "optimizer_states"} <= set(ck) and "ema" in ck["optimizer_states"][0]
+    x0 = torch.randn(4, 3, 16, 16, device=DEV)
+    lab = torch.arange(4, device=DEV) % ecfg.num_classes
+    sol = T.DeterministicSolver(num_steps=3)
+    model.eval()
+    with torch.no_grad():
+        ref_plain = sol.solve(model, x0, lab)
+        with model.swap_ema_weights(tr):
+            ref_ema = sol.solve(model, x0, lab)
+    m1 = T.EDM.load_from_checkpoint(path).to(DEV).eval()
+    m2 = T.EDM.load_from_checkpoint(path, load_ema=True).to(DEV).eval()
+    with torch.no_grad():
+        assert torch.equal(sol.solve(m1, x0, lab), ref_plain)
+        assert torch.equal(sol.solve(m2, x0, lab), ref_ema)
+    assert not torch.equal(ref_plain, ref_ema)

@@ -95,6 +95,7 @@ class Trainer:
 
     def _configure(self, model):
         model.trainer = self
+        self._model = model
         self.callbacks += [c for c in model.configure_callbacks()]
         cfg = model.configure_optimizers()
         if isinstance(cfg, dict):
@@ -177,6 +178,26 @@ class Trainer:
         self._call("on_validation_end", model)
         return model.val_mse.compute() if hasattr(model, "val_mse") else None
 
+    # ------------------------------------------------------------------ checkpoints
+    def save_checkpoint(self, path, model=None):
+        """Writes the Lightning checkpoint keys the reference's `EDM.load_from_checkpoint` reads (edm.py:159-203):
+        `state_dict`, `hyper_parameters` (deinstantiated config, utils.py:5-27) and `optimizer_states[0]["ema"]`."""
+        model = model if model is not None else self._model
+        ckpt = {"state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                "hyper_parameters": dict(model.hparams), "epoch": self.current_epoch, "global_step": self.global_step,
+                "optimizer_states": [_cpu_tree(o.state_dict()) for o in self.optimizers]}
+        if self.global_rank == 0:
+            torch.save(ckpt, path)
+        return ckpt
+
+    def load_checkpoint(self, path, model):
+        """Resume: weights, optimizer (Adam moments, EMA) and counters."""
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        model.load_state_dict(ckpt["state_dict"], strict=False)
+        for o, sd in zip(self.optimizers, ckpt.get("optimizer_states", [])):
+            o.load_state_dict(sd)
+        self.current_epoch, self.global_step = ckpt.get("epoch", 0), ckpt.get("global_step", 0)
+
     # ------------------------------------------------------------------ predict
     @torch.no_grad()
     def predict(self, model, datamodule=None, dataloaders=None, ckpt_path=None):
@@ -197,6 +218,16 @@ class Trainer:
                     fn(self, model, out, None, batch, bi, 0)
             outs.append(out)
         return outs
+
+
+def _cpu_tree(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu()
+    if isinstance(x, dict):
+        return {k: _cpu_tree(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_cpu_tree(v) for v in x)
+    return x
 
 
 def _to_device(batch, device):
