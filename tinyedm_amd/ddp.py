@@ -16,6 +16,11 @@ import torch
 import torch.distributed as dist
 
 
+def _aux_streams():
+    from . import ops
+    return ops.side_streams()
+
+
 class GradReducer:
     def __init__(self, arena, bucket_bytes: int = 32 << 20, process_group=None):
         self.arena = arena
@@ -69,6 +74,8 @@ class GradReducer:
         view = self.arena.grad[b["lo"]:b["hi"]]
         if self.is_cuda:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            for s in _aux_streams():          # gradients finished on the side stream (networks._wgrad)
+                self.comm_stream.wait_stream(s)
             with torch.cuda.stream(self.comm_stream):
                 b["work"] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:

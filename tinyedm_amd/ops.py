@@ -41,6 +41,24 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_SIDE_STREAMS = {}
+
+
+def side_stream(device):
+    """Per-device auxiliary HIP stream: weight-gradient kernels (off the backward's critical path) run here, under
+    the HBM-bound elementwise kernels of the main stream.  Created on first use."""
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    s = _SIDE_STREAMS.get(idx)
+    if s is None:
+        s = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    return s
+
+
+def side_streams():
+    return list(_SIDE_STREAMS.values())
+
+
 class _ZeroPool:
     """Zero-initialised fp32 scratch for the atomically-accumulated outputs (reductions, small weight grads).
 
