@@ -45,6 +45,12 @@ int edm_conv_igemm_v2_stamp(const void* X, const void* Wp, void* Y, int B, int H
 /* diagnostic (tools/ only): timing-only ablations of the v2 kernel (bit0 no MFMA, bit1 no DMA, bit2 no reads, bit3 no barrier) */
 int edm_conv_igemm_v2_ablate(const void* X, const void* Wp, void* Y, int B, int H, int W, int Cin, int Cout, int mode,
                              edm_stream_t stream);
+/* first 3x3 conv of a block with the embedding modulation fused into its epilogue (networks.py:253-260 / 317-324):
+ * Y = conv3x3(X) (bf16, may be NULL in eval), Y2 = dropout(mp_silu(Y * (lin[b,:]*gain + 1))) -- bit-identical to
+ * edm_mod_silu_drop_fwd applied to Y (same Philox counters), so edm_mod_silu_drop_bwd serves as its backward. */
+int edm_conv3x3_mod(const void* X, const void* Wp, void* Y, void* Y2, const float* lin, long lin_stride,
+                    const float* gain, float pdrop, unsigned long long seed, unsigned sub, unsigned step, int B, int H,
+                    int W, int Cin, int Cout, edm_stream_t stream);
 /* weight gradient: slabs[s,tap,co,ci] (fp32, nsplit = edm_conv_wgrad_nsplit(...)) partial sums over pixels. */
 int edm_conv_wgrad_nsplit(int B, int H, int W, int Cin, int Cout, int taps);
 int edm_conv_wgrad(const void* X, const void* dY, float* slabs, int B, int H, int W, int Cin, int Cout, int taps,

@@ -209,6 +209,27 @@ def test_conv_wgrad_1x1_ragged(ops, B, H, W, Cin, Cout):
     assert rel(got, ref1) <= 1e-5
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pdrop", [(2, 8, 8, 64, 128, 0.0), (3, 16, 16, 128, 64, 0.25), (1, 5, 7, 64, 72, 0.1),
+                                                   (128, 32, 32, 256, 256, 0.13)])
+def test_conv3x3_mod_epilogue_is_bit_identical_to_separate_kernels(ops, B, H, W, Cin, Cout, pdrop):
+    """Fused modulation epilogue (edm_conv3x3_mod) == conv_igemm followed by mod_silu_drop_fwd, bit for bit (same bf16
+    rounding of u, same Philox counters), on a small-tile shape, ragged shapes and the full-size 32x32 layer (v4)."""
+    g = torch.Generator().manual_seed(B + Cin + Cout)
+    x = nhwc(q(torch.randn(B, Cin, H, W, generator=g)))
+    wp = pack_fwd(q(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)))
+    lin_all = torch.randn(B, Cout + 40, generator=g).to(DEV)
+    lin = lin_all[:, 8:8 + Cout]                                     # strided rows, like the batched embed output
+    gain = torch.tensor(0.7, device=DEV)
+    u_ref = ops.conv_igemm(x, wp, 9)
+    a_ref = ops.mod_silu_drop_fwd(u_ref, lin, gain, pdrop, 1234, 5, 6)
+    u, a2 = ops.conv3x3_mod(x, wp, lin, gain, pdrop, 1234, 5, 6)
+    assert torch.equal(u, u_ref) and torch.equal(a2, a_ref)
+    none_u, a3 = ops.conv3x3_mod(x, wp, lin, gain, pdrop, 1234, 5, 6, want_u=False)
+    assert none_u is None and torch.equal(a3, a_ref)
+    if pdrop > 0:
+        assert 0.5 * pdrop < (a2 == 0).float().mean().item() < 2.0 * pdrop + 0.01
+
+
 def test_weight_prep_padding_and_perm(ops):
     g = torch.Generator().manual_seed(11)
     w0 = torch.randn(64, 4, 3, 3, generator=g)

@@ -90,6 +90,42 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
 }
 __device__ __forceinline__ float u32_to_unit(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }  // [0,1)
 
+__device__ __forceinline__ bool keep_elem(uint32_t r, float p) { return u32_to_unit(r) >= p; }
+
+// Optional second epilogue output of the implicit-GEMM kernels: the embedding modulation + mp_silu + dropout that
+// follows the first 3x3 conv of every block (networks.py:255-260 / 319-324), a2 = dropout(mp_silu(u*(lin*gain+1))),
+// computed from the bf16-rounded conv output u exactly like k_mod_silu_drop_fwd (same Philox counters), so the
+// backward kernel regenerates the same mask.  Y2 == nullptr: plain conv.
+struct ModEpilogue {
+  const float* lin;   // [B][lin_stride] fp32 embed-linear output
+  const float* gain;  // device scalar
+  bf16* Y2;           // second output, same shape as Y
+  long lin_stride;
+  int HW;
+  float pdrop;
+  uint32_t seed_lo, seed_hi, sub, step;
+};
+__device__ __forceinline__ u32x4 mod_silu_drop8(const u32x4& uraw, long i8, const float* __restrict__ lp, float g,
+                                                const ModEpilogue& m) {
+  const bf16x8 uv = __builtin_bit_cast(bf16x8, uraw);
+  Philox4 r0, r1;
+  if (m.pdrop > 0.f) {
+    r0 = philox4x32_10((uint32_t)(2 * i8), (uint32_t)((2 * i8) >> 32), m.sub, m.step, m.seed_lo, m.seed_hi);
+    r1 = philox4x32_10((uint32_t)(2 * i8 + 1), (uint32_t)((2 * i8 + 1) >> 32), m.sub, m.step, m.seed_lo, m.seed_hi);
+  }
+  const uint32_t rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+  const float keep_scale = m.pdrop > 0.f ? 1.0f / (1.0f - m.pdrop) : 1.0f;
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float mm = lp[j] * g + 1.0f;
+    float v = mp_silu_f((float)uv[j] * mm);
+    if (m.pdrop > 0.f) v = keep_elem(rr[j], m.pdrop) ? v * keep_scale : 0.f;
+    o[j] = (bf16)v;
+  }
+  return __builtin_bit_cast(u32x4, o);
+}
+
 // ---- wave-level transposed tile store for the implicit-GEMM kernels.
 // acc[NI][NJ] are 32x32 MFMA accumulator blocks whose ROWS are output channels cw0 + 32 i + (8 g + 4 lhi + r) and
 // whose COLUMNS are pixels mb0 + 32 j + l31.  Storing them straight from that layout puts 8-byte pieces of 64
@@ -101,7 +137,7 @@ __device__ __forceinline__ float u32_to_unit(uint32_t u) { return (float)(u >> 8
 template <int NI, int NJ>
 __device__ __forceinline__ void store_tile_transposed(const f32x16 (&acc)[NI][NJ], char* stage, bf16* __restrict__ Y,
                                                       const bf16* __restrict__ R, float alpha, float beta, long mb0,
-                                                      long Npix, int cw0, int Cout) {
+                                                      long Npix, int cw0, int Cout, const ModEpilogue& mod = ModEpilogue{}) {
   constexpr int EROW = NI * 64 + 16, CPR = NI * 4, RPI = 64 / CPR;  // 16-byte chunks per row, rows per instruction
   const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
   const int c16 = lane % CPR, prow = lane / CPR;
@@ -141,7 +177,14 @@ __device__ __forceinline__ void store_tile_transposed(const f32x16 (&acc)[NI][NJ
     for (int it = 0; it < 32 / RPI; ++it) {
       const int px = it * RPI + prow;
       const u32x4 ov = *reinterpret_cast<const u32x4*>(stage + px * EROW + c16 * 16);
-      if (mb + px < Npix && co_c < Cout) *reinterpret_cast<u32x4*>(Y + (mb + px) * Cout + co_c) = ov;
+      if (mb + px < Npix && co_c < Cout) {
+        const long e = (mb + px) * Cout + co_c;
+        if (Y) *reinterpret_cast<u32x4*>(Y + e) = ov;
+        if (mod.Y2) {
+          const long b = (mb + px) / mod.HW;
+          *reinterpret_cast<u32x4*>(mod.Y2 + e) = mod_silu_drop8(ov, e >> 3, mod.lin + b * mod.lin_stride + co_c, *mod.gain, mod);
+        }
+      }
     }
   }
 }

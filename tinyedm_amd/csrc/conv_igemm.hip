@@ -32,7 +32,7 @@ template <int TAPS, int KC, int XL, int NJ = 2>  // NJ = 32-pixel blocks per wav
 __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ X, const bf16* __restrict__ Wp,
                                                          bf16* __restrict__ Y, const bf16* __restrict__ R,
                                                          float alpha, float beta, int Npix, int H, int W, int Cin,
-                                                         int Cout, int tiles_m, int tiles_n) {
+                                                         int Cout, int tiles_m, int tiles_n, ModEpilogue mod) {
   constexpr int BM = 64 * NJ, BN = 128;
   constexpr int ROWB = Cfg<KC>::ROWB, CPR = Cfg<KC>::CPR;
   constexpr int WL = BN * CPR / 256;  // W loads per thread
@@ -177,12 +177,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ 
   // ---- epilogue: transposed through wave-private LDS (common.h: store_tile_transposed)
   __syncthreads();  // every wave is done with the staged tiles
   store_tile_transposed<2, NJ>(acc, smem + (wm * 2 + wn) * (32 * (2 * 64 + 16)), Y, R, alpha, beta,
-                               (long)m0 + wn * (32 * NJ), Npix, n0 + wm * 64, Cout);
+                               (long)m0 + wn * (32 * NJ), Npix, n0 + wm * 64, Cout, mod);
 }
 
 template <int TAPS, int KC, int XL, int NJ = 2>
 int launch(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int Npix, int H, int W,
-           int Cin, int Cout, hipStream_t st) {
+           int Cin, int Cout, hipStream_t st, const ModEpilogue& mod = ModEpilogue{}) {
   constexpr int BM = 64 * NJ, BN = 128;
   const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + BN - 1) / BN;
   const int HALO = (TAPS == 9) ? (W + 1) : 0;
@@ -196,16 +196,17 @@ int launch(const void* X, const void* Wp, void* Y, const void* R, float alpha, f
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, (const bf16*)X, (const bf16*)Wp, (bf16*)Y, (const bf16*)R,
-                     alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n);
+                     alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n, mod);
   return 0;
 }
 
 }  // namespace
 
 // X [B*H*W, Cin] bf16, Wp [taps, Cout, Cin] bf16, Y/R [B*H*W, Cout] bf16.  taps in {1, 9}.
-extern "C" int edm_conv_igemm(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B,
-                              int H, int W, int Cin, int Cout, int taps, hipStream_t st) {
-  EDM_REQUIRE(X && Wp && Y, "conv_igemm: null pointer");
+// internal form with the optional fused modulation epilogue (Y may be null when only mod.Y2 is wanted)
+int edm_conv_igemm_v1_ex(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
+                         int W, int Cin, int Cout, int taps, const ModEpilogue& mod, hipStream_t st) {
+  EDM_REQUIRE(X && Wp && (Y || mod.Y2), "conv_igemm: null pointer");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && (long)B * H * W < (1L << 31), "conv_igemm: bad B/H/W");
   EDM_REQUIRE(taps == 1 || taps == 9, "conv_igemm: taps must be 1 or 9 (got %d)", taps);
   EDM_REQUIRE(Cin > 0 && Cin % 32 == 0, "conv_igemm: Cin=%d must be a multiple of 32", Cin);
@@ -215,23 +216,29 @@ extern "C" int edm_conv_igemm(const void* X, const void* Wp, void* Y, const void
   // small feature maps (fewer than ~1.5 tiles per CU at 128 pixels): halve the pixel tile to fill the chip
   const long tiles128 = (long)((Npix + 127) / 128) * ((Cout + 127) / 128);
   if (Cin % 64 == 0 && tiles128 < 384 && W <= 30) {
-    if (taps == 1) launch<1, 64, 2, 1>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st);
-    else launch<9, 64, 4, 1>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st);   // (64 + 2*(W+1)) * 8 <= 1024 chunks
+    if (taps == 1) launch<1, 64, 2, 1>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod);
+    else launch<9, 64, 4, 1>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod);   // (64 + 2*(W+1)) * 8 <= 1024 chunks
     EDM_CHECK_LAUNCH("conv_igemm");
     return EDM_OK;
   }
   const int xrows = 128 + (taps == 9 ? 2 * (W + 1) : 0);
   if (Cin % 64 == 0) {
     const int need = (xrows * 8 + 255) / 256;
-    if (taps == 1) launch<1, 64, 4>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st);
-    else if (need <= 7) launch<9, 64, 7>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st);
-    else launch<9, 64, 9>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st);
+    if (taps == 1) launch<1, 64, 4>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod);
+    else if (need <= 7) launch<9, 64, 7>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod);
+    else launch<9, 64, 9>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod);
   } else {
     const int need = (xrows * 4 + 255) / 256;
-    if (taps == 1) launch<1, 32, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st);
-    else if (need <= 4) launch<9, 32, 4>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st);
-    else launch<9, 32, 5>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st);
+    if (taps == 1) launch<1, 32, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod);
+    else if (need <= 4) launch<9, 32, 4>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod);
+    else launch<9, 32, 5>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod);
   }
   EDM_CHECK_LAUNCH("conv_igemm");
   return EDM_OK;
+}
+
+extern "C" int edm_conv_igemm(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B,
+                              int H, int W, int Cin, int Cout, int taps, hipStream_t st) {
+  EDM_REQUIRE(Y, "conv_igemm: null pointer");
+  return edm_conv_igemm_v1_ex(X, Wp, Y, R, alpha, beta, B, H, W, Cin, Cout, taps, ModEpilogue{}, st);
 }

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
                                                          bf16* __restrict__ Y, const bf16* __restrict__ R,
                                                          const char* __restrict__ zeros, float alpha, float beta,
                                                          int Npix, int H, int W, int Cin, int Cout, int tiles_m,
-                                                         int tiles_n) {
+                                                         int tiles_n, ModEpilogue mod) {
   constexpr int XROWS = NX * 8 * 16;  // LDS rows per slab buffer; rows >= xrows are zero rows
   constexpr int XBYTES = XROWS * ROWB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -230,14 +230,14 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
   // (common.h: store_tile_transposed; direct stores from the MFMA layout cost 1.7x the HBM write bytes)
   __builtin_amdgcn_s_barrier();  // every wave is done with the slab / weight ring
   store_tile_transposed<4, 2>(acc, smem + wave * (32 * (4 * 64 + 16)), Y, R, alpha, beta, (long)m0 + wave * 64, Npix, n0,
-                              Cout);
+                              Cout, mod);
 }
 
 char* g_zero_page4 = nullptr;
 
 template <int NX>
 void launch4(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int Npix, int H, int W,
-             int Cin, int Cout, hipStream_t st) {
+             int Cin, int Cout, const ModEpilogue& mod, hipStream_t st) {
   const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + BN - 1) / BN;
   const size_t lds = (size_t)2 * NX * 8 * 16 * ROWB + WRING * WTILE;
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
@@ -248,16 +248,16 @@ void launch4(const void* X, const void* Wp, void* Y, const void* R, float alpha,
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const bf16*)X, (const bf16*)Wp, (bf16*)Y, (const bf16*)R,
-                     (const char*)g_zero_page4, alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n);
+                     (const char*)g_zero_page4, alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n, mod);
 }
 
 }  // namespace
 
 // 3x3 only.  Same contract as edm_conv_igemm; returns EDM_ERR_UNSUPPORTED (-3) for shapes it does not cover
 // (taps != 9, Cin % 64 != 0, Cin > 2048, W > 64, fewer than 9*Cin/32 >= 18 tiles ...).
-extern "C" int edm_conv_igemm_v4(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B,
-                                 int H, int W, int Cin, int Cout, int taps, hipStream_t st) {
-  EDM_REQUIRE(X && Wp && Y, "conv_igemm_v4: null pointer");
+int edm_conv_igemm_v4_ex(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
+                         int W, int Cin, int Cout, int taps, const ModEpilogue& mod, hipStream_t st) {
+  EDM_REQUIRE(X && Wp && (Y || mod.Y2), "conv_igemm_v4: null pointer");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && (long)B * H * W < (1L << 31), "conv_igemm_v4: bad B/H/W");
   EDM_REQUIRE(Cout > 0 && Cout % 8 == 0, "conv_igemm_v4: Cout %% 8 required");
   if (taps != 9 || Cin <= 0 || Cin % 64 != 0 || Cin * 2 + 64 > ZERO_PAGE || W > 64) return EDM_ERR_UNSUPPORTED;
@@ -269,8 +269,36 @@ extern "C" int edm_conv_igemm_v4(const void* X, const void* Wp, void* Y, const v
   }
   const int Npix = B * H * W;
   const int xrows = BM + 2 * (W + 1);
-  if (xrows < 5 * 128) launch4<5>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st);
-  else launch4<6>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st);
+  if (xrows < 5 * 128) launch4<5>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st);
+  else launch4<6>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st);
   EDM_CHECK_LAUNCH("conv_igemm_v4");
   return EDM_OK;
+}
+
+extern "C" int edm_conv_igemm_v4(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B,
+                                 int H, int W, int Cin, int Cout, int taps, hipStream_t st) {
+  EDM_REQUIRE(Y, "conv_igemm_v4: null pointer");
+  return edm_conv_igemm_v4_ex(X, Wp, Y, R, alpha, beta, B, H, W, Cin, Cout, taps, ModEpilogue{}, st);
+}
+
+int edm_conv_igemm_v1_ex(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
+                         int W, int Cin, int Cout, int taps, const ModEpilogue& mod, hipStream_t st);
+
+// 3x3 conv with the fused embedding modulation epilogue (networks.py:253-260 / 317-324):
+//   u  = conv3x3(X, Wp)                               -> Y  (bf16; may be null when the caller does not need it: eval)
+//   a2 = dropout(mp_silu(u * (lin[b,:]*gain + 1)))     -> Y2 (bf16)   [same values as edm_mod_silu_drop_fwd on u]
+// Picks the static-schedule kernel for layers with >= 512 tall tiles and the 128x128-tile kernel otherwise.
+extern "C" int edm_conv3x3_mod(const void* X, const void* Wp, void* Y, void* Y2, const float* lin, long lin_stride,
+                               const float* gain, float pdrop, unsigned long long seed, unsigned sub, unsigned step,
+                               int B, int H, int W, int Cin, int Cout, hipStream_t st) {
+  EDM_REQUIRE(X && Wp && Y2 && lin && gain, "conv3x3_mod: null pointer");
+  EDM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0 && lin_stride >= Cout && pdrop >= 0.f && pdrop < 1.f,
+              "conv3x3_mod: bad args");
+  ModEpilogue mod{lin, gain, (bf16*)Y2, lin_stride, H * W, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), sub, step};
+  const long tiles3 = (((long)B * H * W + BM - 1) / BM) * ((Cout + BN - 1) / BN);
+  if (tiles3 >= 512) {
+    const int rc = edm_conv_igemm_v4_ex(X, Wp, Y, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
+    if (rc != EDM_ERR_UNSUPPORTED) return rc;
+  }
+  return edm_conv_igemm_v1_ex(X, Wp, Y, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
 }

@@ -222,7 +222,6 @@ extern "C" int edm_axpby(const void* a, float alpha, const void* b, float beta, 
 // ------------------------------------------------------------------ embedding modulation + mp_silu + dropout
 // networks.py:255-260 / 319-324:  a = dropout(mp_silu(r * (lin*gain + 1)))
 // lin is the per-block embed Linear output (B,C) fp32, gain a device scalar.
-__device__ __forceinline__ bool keep_elem(uint32_t r, float p) { return u32_to_unit(r) >= p; }
 
 __global__ void k_mod_silu_drop_fwd(const bf16* __restrict__ r, const float* __restrict__ lin,
                                     const float* __restrict__ gain, bf16* __restrict__ a, int HW, int C, long n8,

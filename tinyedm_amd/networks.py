@@ -563,11 +563,16 @@ class _ResBlockFn(torch.autograd.Function):
                 xres = ops.conv_igemm(u, wf11, 1)
             s = ops.silu_fwd(u)
             dsave = None
-        r1 = ops.conv_igemm(s, wf1, taps)
         lin = lin_view if batched else ops.linear_fwd(emb, weh)
         pdrop = blk.dropout_rate if blk.training else 0.0
         seed, sub, step = rng.seed, blk.rng_sub, rng.step
-        a2 = ops.mod_silu_drop_fwd(r1, lin, gain, pdrop, seed, sub, step)
+        if ops.FUSE_MOD and ops.IGEMM_VERSION == 0:
+            # modulation + mp_silu + dropout ride in the conv epilogue; the pre-activation r1 is only written when
+            # a backward pass will need it
+            r1, a2 = ops.conv3x3_mod(s, wf1, lin, gain, pdrop, seed, sub, step, want_u=any(ctx.needs_input_grad))
+        else:
+            r1 = ops.conv_igemm(s, wf1, taps)
+            a2 = ops.mod_silu_drop_fwd(r1, lin, gain, pdrop, seed, sub, step)
         a, b = _mp_coeffs(blk.add_factor)
         out = ops.conv_igemm(a2, wf2, taps, residual=xres, alpha=b, beta=a)
         ctx.blk, ctx.enc, ctx.has1 = blk, enc, has1

@@ -392,6 +392,30 @@ def conv_igemm(x, wp, taps, residual=None, alpha=1.0, beta=0.0):
     return y
 
 
+FUSE_MOD = os.environ.get("EDM_FUSE_MOD", "1") != "0"
+
+
+def conv3x3_mod(x, wp, lin, gain, pdrop, seed, sub, step, want_u=True):
+    """First 3x3 conv of a block with the modulation epilogue fused: returns (u, a2) with u = conv(x) (None when
+    want_u is False) and a2 = dropout(mp_silu(u*(lin*gain+1))) -- same values as conv_igemm + mod_silu_drop_fwd."""
+    B, H, W, Cin = _nhwc(x, "x")
+    _chk(wp, bf16, "wp")
+    if wp.dim() != 3 or wp.shape[0] != 9 or wp.shape[2] != Cin:
+        raise ValueError(f"conv3x3_mod: pack shape {tuple(wp.shape)} does not match taps=9, Cin={Cin}")
+    Cout = wp.shape[1]
+    ls = _lin_view(lin, B, Cout, "lin")
+    _chk(gain, f32, "gain")
+    u = torch.empty(B, H, W, Cout, device=x.device, dtype=bf16) if want_u else None
+    a2 = torch.empty(B, H, W, Cout, device=x.device, dtype=bf16)
+    npix = B * H * W
+    entry = _igemm_entry(npix, W, Cout, 9, Cin)
+    pname = "conv3x3_igemm" + ("_v4" if entry == "edm_conv_igemm_v4" else "")
+    with _prof(pname, 2.0 * npix * Cin * Cout * 9, 2.0 * (npix * (Cin + Cout * (2 if want_u else 1)) + wp.numel())):
+        _lib.call("edm_conv3x3_mod", _p(x), _p(wp), _p(u), _p(a2), _p(lin), ls, _p(gain), float(pdrop), int(seed),
+                  int(sub), int(step), B, H, W, Cin, Cout, _stream())
+    return u, a2
+
+
 WGRAD_1X1 = os.environ.get("EDM_WGRAD_1X1", "1") != "0"
 WGRAD_VERSION = int(os.environ.get("EDM_WGRAD", "2"))   # 1 = register-staged kernel, 2 = LDS-DMA rolling-window kernel
 
