@@ -267,7 +267,9 @@ def main():
                 "per_kernel": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in roof.items()},
             },
         }
-        if not args.no_sampler:
+        # sampler + CPU baseline ride on the single-GPU line only (the N>1 lines are the training scaling series;
+        # hipGraph capture beside a live RCCL communicator is avoided)
+        if not args.no_sampler and world == 1:
             out["sampler"] = sampler_bench(args, model, device)
             out["sampler"]["mfma_frac"] = round(out["sampler"]["img_per_s"] * 63 * FWD_GFLOP_PER_IMG / 1e3 / MFMA_PEAK_TFLOPS, 4)
         if world == 1 and not args.no_cpu_baseline:

@@ -70,9 +70,10 @@ int edm_conv_wgrad_1x1(const void* X, const void* dY, float* slabs, long npix, i
 int edm_weight_prep(float* w, int O, int I, int taps, int Ipad, void* wp_fwd, void* wp_dgrad, float* w_hat,
                     const int* perm, int normalize_inplace, edm_stream_t stream);
 /* multi-tensor form: one launch for every weight of a network.  descs = device array of 64-byte records
- * {float* w; bf16* fwd; bf16* dgrad; float* hat; const int* perm; int O, I, taps, Ipad, row0, pad;}, row2desc = device
- * int32 [total_rows] mapping each packed output row to its record (row0 = first global row of the record). */
-int edm_weight_prep_multi(const void* descs, const int* row2desc, int total_rows, int normalize_inplace,
+ * {float* w; bf16* fwd; bf16* dgrad; float* hat; const int* perm; int O, I, taps, Ipad, row0, rb;}; groups = device
+ * int32 [n_groups][2] = (record index, first packed row): one workgroup prepares <= rb consecutive rows of a record
+ * through an LDS tile of rb*I*taps bf16 (lds_bytes = the largest such tile, <= 128 KiB). */
+int edm_weight_prep_multi(const void* descs, const int* groups, int n_groups, int lds_bytes, int normalize_inplace,
                           edm_stream_t stream);
 /* reduce split-K slabs and project through the normalisation -> gradient of the fp32 master weight [O,I,taps]. */
 int edm_wgrad_finish(const float* slabs, int S, const float* w, float* grad, const int* perm, int O, int I, int Ipad,

@@ -71,7 +71,7 @@ SIGNATURES = {
     "edm_scale_f32": [P, F, P, L, P],
     # weights.hip
     "edm_weight_prep": [P, I, I, I, I, P, P, P, P, I, P],
-    "edm_weight_prep_multi": [P, P, I, I, P],
+    "edm_weight_prep_multi": [P, P, I, I, I, P],
     "edm_wgrad_finish": [P, I, P, P, P, I, I, I, I, F, I, P],
     # data.hip
     "edm_u8_gather_normalize": [P, P, P, I, I, I, I, L, F, F, I, U64, U, P],

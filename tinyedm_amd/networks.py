@@ -167,7 +167,7 @@ class _PrepPlan:
             ("w", "<u8"), ("fwd", "<u8"), ("dgrad", "<u8"), ("hat", "<u8"), ("perm", "<u8"),
             ("O", "<i4"), ("I", "<i4"), ("taps", "<i4"), ("Ipad", "<i4"), ("row0", "<i4"), ("pad", "<i4")]))
         assert desc.dtype.itemsize == 64
-        rows, row0 = [], 0
+        groups, row0, lds = [], 0, 0
         self.caches = []
         for k, m in enumerate(mods):
             w = m.weight
@@ -178,15 +178,21 @@ class _PrepPlan:
             wh = torch.empty(O, I * taps, device=dev, dtype=f32) if "hat" in m._want else None
             if m._perm is not None and m._perm.device != dev:
                 m._perm = m._perm.to(dev)
+            # rows per workgroup: the bf16 tile rb x (I*taps) must fit LDS; power of two <= 32
+            rb = 32
+            while rb > 1 and (rb * I * taps * 2 > 96 * 1024 or rb > O):
+                rb //= 2
+            lds = max(lds, rb * I * taps * 2)
             desc[k] = (w.data_ptr(), wf.data_ptr() if wf is not None else 0, wd.data_ptr() if wd is not None else 0,
                        wh.data_ptr() if wh is not None else 0, m._perm.data_ptr() if m._perm is not None else 0,
-                       O, I, taps, ipad, row0, 0)
-            rows.append(np.full(O, k, dtype=np.int32))
+                       O, I, taps, ipad, row0, rb)
+            groups += [(k, r) for r in range(0, O, rb)]
             row0 += O
             self.caches.append((wf, wd, wh))
         self.total_rows = row0
         self.desc = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
-        self.row2desc = torch.from_numpy(np.concatenate(rows)).to(dev)
+        self.groups = torch.tensor(groups, dtype=torch.int32).to(dev)
+        self.lds_bytes = lds
         self.eval_key = None
 
     def valid_for(self, mods):
@@ -195,7 +201,7 @@ class _PrepPlan:
     def run(self, training: bool):
         key = (tuple(m.weight._version for m in self.mods), _WEIGHT_EPOCH)
         if training or key != self.eval_key:
-            ops.weight_prep_multi(self.desc, self.row2desc, self.total_rows, training)
+            ops.weight_prep_multi(self.desc, self.groups, self.lds_bytes, training)
             # the in-place normalisation does not go through torch: remember what the packs correspond to
             self.eval_key = None if training else key
         for m, c in zip(self.mods, self.caches):

@@ -464,13 +464,15 @@ def weight_prep(w, taps, Ipad=None, want_fwd=True, want_dgrad=True, want_hat=Fal
     return wf, wd, wh
 
 
-def weight_prep_multi(desc, row2desc, total_rows, normalize_inplace):
-    """desc: uint8 tensor of 64-byte PrepDesc records (see csrc/weights.hip), row2desc: int32 [total_rows]."""
+def weight_prep_multi(desc, groups, lds_bytes, normalize_inplace):
+    """desc: uint8 tensor of 64-byte PrepDesc records (see csrc/weights.hip), groups: int32 [n_groups, 2] of
+    (record, first row); lds_bytes: the largest rb*I*taps*2 over the records."""
     _chk(desc, torch.uint8, "desc")
-    _chk(row2desc, torch.int32, "row2desc", (total_rows,))
-    if desc.numel() % 64:
-        raise ValueError("weight_prep_multi: descriptor table must be a multiple of 64 bytes")
-    _lib.call("edm_weight_prep_multi", _p(desc), _p(row2desc), int(total_rows), int(bool(normalize_inplace)), _stream())
+    _chk(groups, torch.int32, "groups")
+    if desc.numel() % 64 or groups.dim() != 2 or groups.shape[1] != 2:
+        raise ValueError("weight_prep_multi: bad descriptor / group tables")
+    _lib.call("edm_weight_prep_multi", _p(desc), _p(groups), int(groups.shape[0]), int(lds_bytes),
+              int(bool(normalize_inplace)), _stream())
 
 
 def wgrad_finish(slabs, w, taps, I, perm=None, scale=1.0, out=None):
