@@ -51,6 +51,14 @@ int edm_conv_igemm_v2_ablate(const void* X, const void* Wp, void* Y, int B, int 
 int edm_conv3x3_mod(const void* X, const void* Wp, void* Y, void* Y2, const float* lin, long lin_stride,
                     const float* gain, float pdrop, unsigned long long seed, unsigned sub, unsigned step, int B, int H,
                     int W, int Cin, int Cout, edm_stream_t stream);
+/* backward counterpart: dgrad of the block's second 3x3 conv (ga = alpha*conv3x3(dY, Wd), never written) with the
+ * modulation backward in the epilogue: GR = ga*keep*mp_silu'(u*m)*m, gm[b,c] += sum_px ga*keep*mp_silu'(u*m)*u (gm
+ * zero-filled [B][Cout] fp32); finish with edm_mod_finish.  -3 when H*W % 32 != 0 (use the separate kernels). */
+int edm_conv3x3_modbwd(const void* dY, const void* Wd, float alpha, const void* U, const float* lin, long lin_stride,
+                       const float* gain, void* GR, float* gm, float pdrop, unsigned long long seed, unsigned sub,
+                       unsigned step, int B, int H, int W, int Cin, int Cout, edm_stream_t stream);
+int edm_mod_finish(const float* gm, const float* lin, long lin_stride, const float* gain, float* glin, long glin_stride,
+                   float* ggain, int B, int C, edm_stream_t stream);
 /* weight gradient: slabs[s,tap,co,ci] (fp32, nsplit = edm_conv_wgrad_nsplit(...)) partial sums over pixels. */
 int edm_conv_wgrad_nsplit(int B, int H, int W, int Cin, int Cout, int taps);
 int edm_conv_wgrad(const void* X, const void* dY, float* slabs, int B, int H, int W, int Cin, int Cout, int taps,

@@ -230,6 +230,25 @@ def test_conv3x3_mod_epilogue_is_bit_identical_to_separate_kernels(ops, B, H, W,
         assert 0.5 * pdrop < (a2 == 0).float().mean().item() < 2.0 * pdrop + 0.01
 
 
+@pytest.mark.parametrize("B,H,W,C1,C2,pdrop", [(2, 8, 8, 64, 128, 0.0), (3, 16, 16, 128, 64, 0.25), (2, 4, 8, 64, 72, 0.1),
+                                                 (128, 32, 32, 256, 256, 0.13)])
+def test_conv3x3_modbwd_epilogue_matches_separate_kernels(ops, B, H, W, C1, C2, pdrop):
+    """Fused modulation backward (edm_conv3x3_modbwd + edm_mod_finish) == conv_igemm (dgrad) then mod_silu_drop_bwd:
+    gr bit for bit, glin / ggain up to fp32 summation order (both paths accumulate with atomics)."""
+    g = torch.Generator().manual_seed(B + C1 + C2)
+    gout = nhwc(q(torch.randn(B, C1, H, W, generator=g)))
+    wd = pack_fwd(q(torch.randn(C2, C1, 3, 3, generator=g) / math.sqrt(C1 * 9)))      # any [9][C2][C1] pack
+    r1 = nhwc(q(torch.randn(B, C2, H, W, generator=g)))
+    lin_all = torch.randn(B, C2 + 24, generator=g).to(DEV)
+    lin = lin_all[:, 8:8 + C2]
+    gain = torch.tensor(0.6, device=DEV)
+    ga = ops.conv_igemm(gout, wd, 9, alpha=0.8)
+    gr_ref, glin_ref, gg_ref = ops.mod_silu_drop_bwd(r1, lin, gain, ga, pdrop, 99, 3, 4)
+    gr, glin, gg = ops.conv3x3_modbwd(gout, wd, 0.8, r1, lin, gain, pdrop, 99, 3, 4)
+    assert torch.equal(gr, gr_ref)
+    assert rel(glin, glin_ref) <= 1e-5 and abs(gg.item() - gg_ref.item()) <= 1e-4 * (abs(gg_ref.item()) + 1e-3)
+
+
 def test_weight_prep_padding_and_perm(ops):
     g = torch.Generator().manual_seed(11)
     w0 = torch.randn(64, 4, 3, 3, generator=g)

@@ -96,15 +96,45 @@ __device__ __forceinline__ bool keep_elem(uint32_t r, float p) { return u32_to_u
 // follows the first 3x3 conv of every block (networks.py:255-260 / 319-324), a2 = dropout(mp_silu(u*(lin*gain+1))),
 // computed from the bf16-rounded conv output u exactly like k_mod_silu_drop_fwd (same Philox counters), so the
 // backward kernel regenerates the same mask.  Y2 == nullptr: plain conv.
+//
+// Backward form (U != nullptr): the kernel is the dgrad of the block's SECOND conv, its bf16 result ga is consumed in
+// the epilogue instead of being written: Y2 = gr = ga*keep*mp_silu'(u*m)*m and gm[b,c] += sum_px ga*keep*silu'(u*m)*u
+// (same arithmetic as k_mod_silu_drop_bwd; needs HW % 32 == 0 so that a 32-pixel block never straddles images).
 struct ModEpilogue {
   const float* lin;   // [B][lin_stride] fp32 embed-linear output
   const float* gain;  // device scalar
-  bf16* Y2;           // second output, same shape as Y
+  bf16* Y2;           // second output, same shape as Y (forward: a2; backward: gr)
   long lin_stride;
   int HW;
   float pdrop;
   uint32_t seed_lo, seed_hi, sub, step;
+  const bf16* U;      // backward form: pre-activation conv output u saved by the forward
+  float* gm;          // backward form: [B][Cout] fp32, zero-filled by the caller, accumulated with atomics
 };
+// backward form on 8 channels: returns gr, accumulates ga*keep*silu'(u*m)*u into part[]
+__device__ __forceinline__ u32x4 mod_silu_drop_bwd8(const u32x4& garaw, const u32x4& uraw, long i8,
+                                                    const float* __restrict__ lp, float g, const ModEpilogue& m,
+                                                    float (&part)[8]) {
+  const bf16x8 gv = __builtin_bit_cast(bf16x8, garaw), uv = __builtin_bit_cast(bf16x8, uraw);
+  Philox4 r0, r1;
+  if (m.pdrop > 0.f) {
+    r0 = philox4x32_10((uint32_t)(2 * i8), (uint32_t)((2 * i8) >> 32), m.sub, m.step, m.seed_lo, m.seed_hi);
+    r1 = philox4x32_10((uint32_t)(2 * i8 + 1), (uint32_t)((2 * i8 + 1) >> 32), m.sub, m.step, m.seed_lo, m.seed_hi);
+  }
+  const uint32_t rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+  const float keep_scale = m.pdrop > 0.f ? 1.0f / (1.0f - m.pdrop) : 1.0f;
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float mm = lp[j] * g + 1.0f;
+    const float u = (float)uv[j];
+    float gu = (float)gv[j] * mp_silu_grad_f(u * mm);
+    if (m.pdrop > 0.f) gu = keep_elem(rr[j], m.pdrop) ? gu * keep_scale : 0.f;
+    part[j] += gu * u;
+    o[j] = (bf16)(gu * mm);
+  }
+  return __builtin_bit_cast(u32x4, o);
+}
 __device__ __forceinline__ u32x4 mod_silu_drop8(const u32x4& uraw, long i8, const float* __restrict__ lp, float g,
                                                 const ModEpilogue& m) {
   const bf16x8 uv = __builtin_bit_cast(bf16x8, uraw);
@@ -134,7 +164,7 @@ __device__ __forceinline__ u32x4 mod_silu_drop8(const u32x4& uraw, long i8, cons
 // padded rows): the residual is read and the result written 16 B per lane, whole rows per instruction.
 // y = alpha * acc + beta * R is formed in fp32 and rounded to bf16 once.  The caller must have passed a workgroup
 // barrier after its last read of the LDS bytes that `stage` overlays.
-template <int NI, int NJ>
+template <int NI, int NJ, bool BWD = false>
 __device__ __forceinline__ void store_tile_transposed(const f32x16 (&acc)[NI][NJ], char* stage, bf16* __restrict__ Y,
                                                       const bf16* __restrict__ R, float alpha, float beta, long mb0,
                                                       long Npix, int cw0, int Cout, const ModEpilogue& mod = ModEpilogue{}) {
@@ -173,7 +203,8 @@ __device__ __forceinline__ void store_tile_transposed(const f32x16 (&acc)[NI][NJ
         *reinterpret_cast<bf16x4*>(sp) = o;
       }
     }
-#pragma unroll
+    float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // backward form: per-lane sums over this block's pixels
+#pragma unroll(BWD ? 1 : 32 / RPI)
     for (int it = 0; it < 32 / RPI; ++it) {
       const int px = it * RPI + prow;
       const u32x4 ov = *reinterpret_cast<const u32x4*>(stage + px * EROW + c16 * 16);
@@ -182,8 +213,26 @@ __device__ __forceinline__ void store_tile_transposed(const f32x16 (&acc)[NI][NJ
         if (Y) *reinterpret_cast<u32x4*>(Y + e) = ov;
         if (mod.Y2) {
           const long b = (mb + px) / mod.HW;
-          *reinterpret_cast<u32x4*>(mod.Y2 + e) = mod_silu_drop8(ov, e >> 3, mod.lin + b * mod.lin_stride + co_c, *mod.gain, mod);
+          const float* lp = mod.lin + b * mod.lin_stride + co_c;
+          if (BWD) {
+            const u32x4 uraw = *reinterpret_cast<const u32x4*>(mod.U + e);
+            *reinterpret_cast<u32x4*>(mod.Y2 + e) = mod_silu_drop_bwd8(ov, uraw, e >> 3, lp, *mod.gain, mod, part);
+          } else {
+            *reinterpret_cast<u32x4*>(mod.Y2 + e) = mod_silu_drop8(ov, e >> 3, lp, *mod.gain, mod);
+          }
         }
+      }
+    }
+    if (BWD) {  // lanes with equal c16 hold partial sums of the same 8 channels: fold the RPI pixel rows
+#pragma unroll
+      for (int j8 = 0; j8 < 8; ++j8) {
+#pragma unroll
+        for (int off = CPR; off < 64; off <<= 1) part[j8] += __shfl_xor(part[j8], off, 64);
+      }
+      if (prow == 0 && mb < Npix && co_c < Cout) {
+        float* gp = mod.gm + (mb / mod.HW) * Cout + co_c;
+#pragma unroll
+        for (int j8 = 0; j8 < 8; ++j8) atomicAdd(gp + j8, part[j8]);
       }
     }
   }

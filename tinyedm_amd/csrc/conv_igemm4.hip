@@ -58,7 +58,7 @@ __device__ __forceinline__ void static_for(F&& f) {
   asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory");  \
   __builtin_amdgcn_sched_barrier(0)
 
-template <int NX>
+template <int NX, bool BWD = false>
 __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ X, const bf16* __restrict__ Wp,
                                                          bf16* __restrict__ Y, const bf16* __restrict__ R,
                                                          const char* __restrict__ zeros, float alpha, float beta,
@@ -229,19 +229,19 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
   // ---- epilogue: transposed through wave-private LDS so that residual reads and stores are whole rows
   // (common.h: store_tile_transposed; direct stores from the MFMA layout cost 1.7x the HBM write bytes)
   __builtin_amdgcn_s_barrier();  // every wave is done with the slab / weight ring
-  store_tile_transposed<4, 2>(acc, smem + wave * (32 * (4 * 64 + 16)), Y, R, alpha, beta, (long)m0 + wave * 64, Npix, n0,
-                              Cout, mod);
+  store_tile_transposed<4, 2, BWD>(acc, smem + wave * (32 * (4 * 64 + 16)), Y, R, alpha, beta, (long)m0 + wave * 64, Npix,
+                                   n0, Cout, mod);
 }
 
 char* g_zero_page4 = nullptr;
 
-template <int NX>
+template <int NX, bool BWD = false>
 void launch4(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int Npix, int H, int W,
              int Cin, int Cout, const ModEpilogue& mod, hipStream_t st) {
   const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + BN - 1) / BN;
   const size_t lds = (size_t)2 * NX * 8 * 16 * ROWB + WRING * WTILE;
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
-  auto kern = k_conv3x3_v4<NX>;
+  auto kern = k_conv3x3_v4<NX, BWD>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -269,7 +269,10 @@ int edm_conv_igemm_v4_ex(const void* X, const void* Wp, void* Y, const void* R, 
   }
   const int Npix = B * H * W;
   const int xrows = BM + 2 * (W + 1);
-  if (xrows < 5 * 128) launch4<5>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st);
+  if (mod.U) {  // modulation-backward epilogue: its own instantiation (keeps the common kernels free of its registers)
+    if (xrows < 5 * 128) launch4<5, true>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st);
+    else launch4<6, true>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st);
+  } else if (xrows < 5 * 128) launch4<5>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st);
   else launch4<6>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st);
   EDM_CHECK_LAUNCH("conv_igemm_v4");
   return EDM_OK;
@@ -294,11 +297,36 @@ extern "C" int edm_conv3x3_mod(const void* X, const void* Wp, void* Y, void* Y2,
   EDM_REQUIRE(X && Wp && Y2 && lin && gain, "conv3x3_mod: null pointer");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0 && lin_stride >= Cout && pdrop >= 0.f && pdrop < 1.f,
               "conv3x3_mod: bad args");
-  ModEpilogue mod{lin, gain, (bf16*)Y2, lin_stride, H * W, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), sub, step};
+  ModEpilogue mod{lin, gain, (bf16*)Y2, lin_stride, H * W, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), sub, step,
+                  nullptr, nullptr};
   const long tiles3 = (((long)B * H * W + BM - 1) / BM) * ((Cout + BN - 1) / BN);
   if (tiles3 >= 512) {
     const int rc = edm_conv_igemm_v4_ex(X, Wp, Y, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
     if (rc != EDM_ERR_UNSUPPORTED) return rc;
   }
   return edm_conv_igemm_v1_ex(X, Wp, Y, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
+}
+
+// Backward counterpart: the dgrad of a block's second 3x3 conv with the modulation backward fused into its epilogue
+// (networks.py:253-263 under autograd).  With ga = alpha * conv3x3(dY, Wd) (bf16, never written):
+//   gr = ga * keep * mp_silu'(u*m) * m   -> GR (bf16),     gm[b,c] += sum_px ga * keep * mp_silu'(u*m) * u   (fp32 atomics)
+// where m = lin*gain + 1 and u = U is the forward's pre-activation.  gm must be zero-filled [B][Cout]; follow with
+// edm_mod_finish.  Same values as edm_conv_igemm + edm_mod_silu_drop_bwd (gm up to summation order).
+// Returns EDM_ERR_UNSUPPORTED (-3) when H*W is not a multiple of 32 (a 32-pixel block would straddle images).
+extern "C" int edm_conv3x3_modbwd(const void* dY, const void* Wd, float alpha, const void* U, const float* lin,
+                                  long lin_stride, const float* gain, void* GR, float* gm, float pdrop,
+                                  unsigned long long seed, unsigned sub, unsigned step, int B, int H, int W, int Cin,
+                                  int Cout, hipStream_t st) {
+  EDM_REQUIRE(dY && Wd && U && lin && gain && GR && gm, "conv3x3_modbwd: null pointer");
+  EDM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0 && lin_stride >= Cout && pdrop >= 0.f && pdrop < 1.f,
+              "conv3x3_modbwd: bad args");
+  if ((H * W) % 32 != 0) return EDM_ERR_UNSUPPORTED;
+  ModEpilogue mod{lin, gain, (bf16*)GR, lin_stride, H * W, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), sub, step,
+                  (const bf16*)U, gm};
+  const long tiles3 = (((long)B * H * W + BM - 1) / BM) * ((Cout + BN - 1) / BN);
+  if (tiles3 >= 512) {
+    const int rc = edm_conv_igemm_v4_ex(dY, Wd, nullptr, nullptr, alpha, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
+    if (rc != EDM_ERR_UNSUPPORTED) return rc;
+  }
+  return edm_conv_igemm_v1_ex(dY, Wd, nullptr, nullptr, alpha, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
 }

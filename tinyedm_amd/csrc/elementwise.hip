@@ -355,6 +355,17 @@ extern "C" int edm_mod_silu_drop_bwd(const void* r, const float* lin, long lin_s
   return EDM_OK;
 }
 
+// second half of edm_mod_silu_drop_bwd on its own (the first half can ride in a conv epilogue: edm_conv3x3_modbwd)
+extern "C" int edm_mod_finish(const float* gm, const float* lin, long lin_stride, const float* gain, float* glin,
+                              long glin_stride, float* ggain, int B, int C, hipStream_t st) {
+  EDM_REQUIRE(gm && lin && gain && glin && ggain && B > 0 && C > 0 && lin_stride >= C && glin_stride >= C,
+              "mod_finish: bad args");
+  hipLaunchKernelGGL(k_mod_finish, dim3(grid_for((long)B * C, 256, 64)), dim3(256), 0, st, gm, lin, gain, glin, ggain,
+                     (long)B * C, C, lin_stride, glin_stride);
+  EDM_CHECK_LAUNCH("mod_finish");
+  return EDM_OK;
+}
+
 // exported for tests: the keep-mask the two kernels above derive from (seed, sub, step)
 __global__ void k_dropout_mask(uint8_t* __restrict__ mask, long n8, float pdrop, uint32_t seed_lo, uint32_t seed_hi,
                                uint32_t sub, uint32_t step) {

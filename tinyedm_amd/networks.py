@@ -595,16 +595,20 @@ class _ResBlockFn(torch.autograd.Function):
         pdrop, seed, sub, step = ctx.drop
         gout = gout.contiguous()
         a, b = _mp_coeffs(blk.add_factor)
-        ga2 = ops.conv_igemm(gout, wd2, 9, alpha=b)
+        # d loss / d lin goes (batched mode) into this block's column slice of the shared buffer; _EmbedAllFn.backward
+        # turns the whole buffer into the embed-weight and embedding gradients with two GEMMs
+        glin_out = ctx.glin_view if ctx.batched else None
+        if ops.FUSE_MOD and ops.IGEMM_VERSION == 0 and (gout.shape[1] * gout.shape[2]) % 32 == 0:
+            # conv2's dgrad with the modulation backward in its epilogue: ga2 never touches HBM
+            gr1, glin, ggain = ops.conv3x3_modbwd(gout, wd2, b, r1, lin, gain, pdrop, seed, sub, step, glin_out=glin_out)
+        else:
+            ga2 = ops.conv_igemm(gout, wd2, 9, alpha=b)
+            gr1, glin, ggain = ops.mod_silu_drop_bwd(r1, lin, gain, ga2, pdrop, seed, sub, step, glin_out=glin_out)
         gw2 = _wgrad(blk.conv_3x3_2, a2, gout, 9, b)
         gwemb = gemb = gtoken = None
         if ctx.batched:
-            # d loss / d lin goes into this block's column slice of the shared buffer; _EmbedAllFn.backward turns
-            # the whole buffer into the embed-weight and embedding gradients with two GEMMs
-            gr1, _, ggain = ops.mod_silu_drop_bwd(r1, lin, gain, ga2, pdrop, seed, sub, step, glin_out=ctx.glin_view)
             gtoken = ops.zeros_f32((1,), gout.device)
         else:
-            gr1, glin, ggain = ops.mod_silu_drop_bwd(r1, lin, gain, ga2, pdrop, seed, sub, step)
             dweh = ops.linear_wgrad(glin, emb)
             gwemb = blk.embed.finish_grad(dweh.view(1, 1, *dweh.shape))
             gemb = ops.linear_dgrad(glin, weh) if ctx.needs_input_grad[1] else None

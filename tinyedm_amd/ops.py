@@ -416,6 +416,34 @@ def conv3x3_mod(x, wp, lin, gain, pdrop, seed, sub, step, want_u=True):
     return u, a2
 
 
+def conv3x3_modbwd(gout, wd, alpha, r1, lin, gain, pdrop, seed, sub, step, glin_out=None):
+    """dgrad of a block's second 3x3 conv with the modulation backward in its epilogue: returns (gr1, glin, ggain),
+    the values conv_igemm(gout, wd, 9, alpha=alpha) followed by mod_silu_drop_bwd would give (H*W % 32 == 0)."""
+    B, H, W, Cin = _nhwc(gout, "gout")
+    _chk(wd, bf16, "wd")
+    if wd.dim() != 3 or wd.shape[0] != 9 or wd.shape[2] != Cin:
+        raise ValueError(f"conv3x3_modbwd: pack shape {tuple(wd.shape)} does not match taps=9, Cin={Cin}")
+    Cout = wd.shape[1]
+    _chk(r1, bf16, "r1", (B, H, W, Cout))
+    if (H * W) % 32:
+        raise ValueError("conv3x3_modbwd: H*W must be a multiple of 32")
+    ls = _lin_view(lin, B, Cout, "lin")
+    _chk(gain, f32, "gain")
+    gr = torch.empty_like(r1)
+    gm = zeros_f32((B, Cout), r1.device)
+    glin = torch.empty(B, Cout, device=r1.device, dtype=f32) if glin_out is None else glin_out
+    gs = _lin_view(glin, B, Cout, "glin")
+    ggain = zeros_f32((), r1.device)
+    npix = B * H * W
+    entry = _igemm_entry(npix, W, Cout, 9, Cin)
+    pname = "conv3x3_igemm" + ("_v4" if entry == "edm_conv_igemm_v4" else "")
+    with _prof(pname, 2.0 * npix * Cin * Cout * 9, 2.0 * (npix * (Cin + 2 * Cout) + wd.numel())):
+        _lib.call("edm_conv3x3_modbwd", _p(gout), _p(wd), float(alpha), _p(r1), _p(lin), ls, _p(gain), _p(gr), _p(gm),
+                  float(pdrop), int(seed), int(sub), int(step), B, H, W, Cin, Cout, _stream())
+    _lib.call("edm_mod_finish", _p(gm), _p(lin), ls, _p(gain), _p(glin), gs, _p(ggain), B, Cout, _stream())
+    return gr, glin, ggain
+
+
 WGRAD_1X1 = os.environ.get("EDM_WGRAD_1X1", "1") != "0"
 WGRAD_VERSION = int(os.environ.get("EDM_WGRAD", "2"))   # 1 = register-staged kernel, 2 = LDS-DMA rolling-window kernel
 
