@@ -57,6 +57,10 @@ int edm_conv3x3_mod(const void* X, const void* Wp, void* Y, void* Y2, const floa
 int edm_conv3x3_modbwd(const void* dY, const void* Wd, float alpha, const void* U, const float* lin, long lin_stride,
                        const float* gain, void* GR, float* gm, float pdrop, unsigned long long seed, unsigned sub,
                        unsigned step, int B, int H, int W, int Cin, int Cout, edm_stream_t stream);
+/* dgrad of a block's first 3x3 conv with the mp_silu backward of the block input in its epilogue
+ * (g = conv3x3(dY, Wd) never written): GX = mp_silu'(Xpre)*g + add_scale*ADD (ADD may be NULL). */
+int edm_conv3x3_silubwd(const void* dY, const void* Wd, const void* Xpre, const void* ADD, float add_scale, void* GX,
+                        int B, int H, int W, int Cin, int Cout, edm_stream_t stream);
 int edm_mod_finish(const float* gm, const float* lin, long lin_stride, const float* gain, float* glin, long glin_stride,
                    float* ggain, int B, int C, edm_stream_t stream);
 /* weight gradient: slabs[s,tap,co,ci] (fp32, nsplit = edm_conv_wgrad_nsplit(...)) partial sums over pixels. */

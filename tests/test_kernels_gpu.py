@@ -249,6 +249,19 @@ def test_conv3x3_modbwd_epilogue_matches_separate_kernels(ops, B, H, W, C1, C2, 
     assert rel(glin, glin_ref) <= 1e-5 and abs(gg.item() - gg_ref.item()) <= 1e-4 * (abs(gg_ref.item()) + 1e-3)
 
 
+@pytest.mark.parametrize("B,H,W,C1,C2", [(2, 8, 8, 64, 128), (3, 5, 7, 128, 72), (128, 32, 32, 256, 256)])
+@pytest.mark.parametrize("with_extra", [False, True])
+def test_conv3x3_silubwd_epilogue_is_bit_identical(ops, B, H, W, C1, C2, with_extra):
+    g = torch.Generator().manual_seed(B + C1 + C2)
+    gr = nhwc(q(torch.randn(B, C1, H, W, generator=g)))
+    wd = pack_fwd(q(torch.randn(C2, C1, 3, 3, generator=g) / math.sqrt(C1 * 9)))
+    xpre = nhwc(q(torch.randn(B, C2, H, W, generator=g)))
+    extra = nhwc(q(torch.randn(B, C2, H, W, generator=g))) if with_extra else None
+    ref = ops.silu_bwd(xpre, ops.conv_igemm(gr, wd, 9), extra, 0.7)
+    got = ops.conv3x3_silubwd(gr, wd, xpre, extra, 0.7)
+    assert torch.equal(got, ref)
+
+
 def test_weight_prep_padding_and_perm(ops):
     g = torch.Generator().manual_seed(11)
     w0 = torch.randn(64, 4, 3, 3, generator=g)

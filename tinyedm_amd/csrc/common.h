@@ -108,9 +108,22 @@ struct ModEpilogue {
   int HW;
   float pdrop;
   uint32_t seed_lo, seed_hi, sub, step;
-  const bf16* U;      // backward form: pre-activation conv output u saved by the forward
-  float* gm;          // backward form: [B][Cout] fp32, zero-filled by the caller, accumulated with atomics
+  const bf16* U;      // backward forms: pre-activation tensor saved by the forward
+  float* gm;          // modulation backward: [B][Cout] fp32, zero-filled by the caller, accumulated with atomics
+  const bf16* ADD;    // silu backward: optional extra gradient, Y2 = mp_silu'(U)*g + add_scale*ADD
+  float add_scale;
+  int mode;           // 0: none / forward modulation (Y2 set), 1: modulation backward, 2: mp_silu backward
 };
+// mode 2 on 8 channels: gx = mp_silu'(x)*g + s*ge  (k_silu_bwd's arithmetic; g = the conv result rounded to bf16)
+__device__ __forceinline__ u32x4 silu_bwd8(const u32x4& graw, const u32x4& xraw, const bf16* __restrict__ add, float s) {
+  const bf16x8 gv = __builtin_bit_cast(bf16x8, graw), xv = __builtin_bit_cast(bf16x8, xraw);
+  bf16x8 ev;
+  if (add) ev = *reinterpret_cast<const bf16x8*>(add);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16)(mp_silu_grad_f((float)xv[j]) * (float)gv[j] + (add ? s * (float)ev[j] : 0.f));
+  return __builtin_bit_cast(u32x4, o);
+}
 // backward form on 8 channels: returns gr, accumulates ga*keep*silu'(u*m)*u into part[]
 __device__ __forceinline__ u32x4 mod_silu_drop_bwd8(const u32x4& garaw, const u32x4& uraw, long i8,
                                                     const float* __restrict__ lp, float g, const ModEpilogue& m,
@@ -164,7 +177,7 @@ __device__ __forceinline__ u32x4 mod_silu_drop8(const u32x4& uraw, long i8, cons
 // padded rows): the residual is read and the result written 16 B per lane, whole rows per instruction.
 // y = alpha * acc + beta * R is formed in fp32 and rounded to bf16 once.  The caller must have passed a workgroup
 // barrier after its last read of the LDS bytes that `stage` overlays.
-template <int NI, int NJ, bool BWD = false>
+template <int NI, int NJ, int EPI = 0>
 __device__ __forceinline__ void store_tile_transposed(const f32x16 (&acc)[NI][NJ], char* stage, bf16* __restrict__ Y,
                                                       const bf16* __restrict__ R, float alpha, float beta, long mb0,
                                                       long Npix, int cw0, int Cout, const ModEpilogue& mod = ModEpilogue{}) {
@@ -204,7 +217,7 @@ __device__ __forceinline__ void store_tile_transposed(const f32x16 (&acc)[NI][NJ
       }
     }
     float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // backward form: per-lane sums over this block's pixels
-#pragma unroll(BWD ? 1 : 32 / RPI)
+#pragma unroll(EPI ? 1 : 32 / RPI)
     for (int it = 0; it < 32 / RPI; ++it) {
       const int px = it * RPI + prow;
       const u32x4 ov = *reinterpret_cast<const u32x4*>(stage + px * EROW + c16 * 16);
@@ -212,18 +225,21 @@ __device__ __forceinline__ void store_tile_transposed(const f32x16 (&acc)[NI][NJ
         const long e = (mb + px) * Cout + co_c;
         if (Y) *reinterpret_cast<u32x4*>(Y + e) = ov;
         if (mod.Y2) {
-          const long b = (mb + px) / mod.HW;
-          const float* lp = mod.lin + b * mod.lin_stride + co_c;
-          if (BWD) {
+          const float* lp = nullptr;
+          if (EPI != 2) lp = mod.lin + ((mb + px) / mod.HW) * mod.lin_stride + co_c;
+          if (EPI == 1) {
             const u32x4 uraw = *reinterpret_cast<const u32x4*>(mod.U + e);
             *reinterpret_cast<u32x4*>(mod.Y2 + e) = mod_silu_drop_bwd8(ov, uraw, e >> 3, lp, *mod.gain, mod, part);
+          } else if (EPI == 2) {
+            const u32x4 xraw = *reinterpret_cast<const u32x4*>(mod.U + e);
+            *reinterpret_cast<u32x4*>(mod.Y2 + e) = silu_bwd8(ov, xraw, mod.ADD ? mod.ADD + e : nullptr, mod.add_scale);
           } else {
             *reinterpret_cast<u32x4*>(mod.Y2 + e) = mod_silu_drop8(ov, e >> 3, lp, *mod.gain, mod);
           }
         }
       }
     }
-    if (BWD) {  // lanes with equal c16 hold partial sums of the same 8 channels: fold the RPI pixel rows
+    if (EPI == 1) {  // lanes with equal c16 hold partial sums of the same 8 channels: fold the RPI pixel rows
 #pragma unroll
       for (int j8 = 0; j8 < 8; ++j8) {
 #pragma unroll

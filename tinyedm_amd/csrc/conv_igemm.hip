@@ -28,7 +28,7 @@ struct Cfg {
   static constexpr int CPR = KC / 8;        // 16-B chunks per row
 };
 
-template <int TAPS, int KC, int XL, int NJ = 2, bool BWD = false>  // NJ = 32-pixel blocks per wave: tile = (64*NJ) pixels x 128 channels
+template <int TAPS, int KC, int XL, int NJ = 2, int EPI = 0>  // NJ = 32-pixel blocks per wave: tile = (64*NJ) pixels x 128 channels
 __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ X, const bf16* __restrict__ Wp,
                                                          bf16* __restrict__ Y, const bf16* __restrict__ R,
                                                          float alpha, float beta, int Npix, int H, int W, int Cin,
@@ -176,11 +176,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ 
 
   // ---- epilogue: transposed through wave-private LDS (common.h: store_tile_transposed)
   __syncthreads();  // every wave is done with the staged tiles
-  store_tile_transposed<2, NJ, BWD>(acc, smem + (wm * 2 + wn) * (32 * (2 * 64 + 16)), Y, R, alpha, beta,
+  store_tile_transposed<2, NJ, EPI>(acc, smem + (wm * 2 + wn) * (32 * (2 * 64 + 16)), Y, R, alpha, beta,
                                (long)m0 + wn * (32 * NJ), Npix, n0 + wm * 64, Cout, mod);
 }
 
-template <int TAPS, int KC, int XL, int NJ = 2, bool BWD = false>
+template <int TAPS, int KC, int XL, int NJ = 2, int EPI = 0>
 int launch(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int Npix, int H, int W,
            int Cin, int Cout, hipStream_t st, const ModEpilogue& mod = ModEpilogue{}) {
   constexpr int BM = 64 * NJ, BN = 128;
@@ -189,7 +189,7 @@ int launch(const void* X, const void* Wp, void* Y, const void* R, float alpha, f
   const int xrows = BM + 2 * HALO;
   const size_t lds = ((xrows * Cfg<KC>::ROWB + 15) & ~15) + 2 * BN * Cfg<KC>::ROWB;
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
-  auto kern = k_conv_igemm<TAPS, KC, XL, NJ, BWD>;
+  auto kern = k_conv_igemm<TAPS, KC, XL, NJ, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -202,8 +202,9 @@ int launch(const void* X, const void* Wp, void* Y, const void* R, float alpha, f
 
 // 3x3 launches come in two epilogue flavours: plain / forward modulation, and modulation backward (mod.U set)
 #define LAUNCH9(KC, XL, NJ)                                                                                      \
-  (mod.U ? launch<9, KC, XL, NJ, true>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod)                 \
-         : launch<9, KC, XL, NJ, false>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod))
+  (mod.mode == 1   ? launch<9, KC, XL, NJ, 1>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod)          \
+   : mod.mode == 2 ? launch<9, KC, XL, NJ, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod)          \
+                   : launch<9, KC, XL, NJ, 0>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod))
 
 }  // namespace
 
@@ -212,7 +213,7 @@ int launch(const void* X, const void* Wp, void* Y, const void* R, float alpha, f
 int edm_conv_igemm_v1_ex(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
                          int W, int Cin, int Cout, int taps, const ModEpilogue& mod, hipStream_t st) {
   EDM_REQUIRE(X && Wp && (Y || mod.Y2), "conv_igemm: null pointer");
-  EDM_REQUIRE(!mod.U || taps == 9, "conv_igemm: the modulation-backward epilogue is 3x3 only");
+  EDM_REQUIRE(mod.mode == 0 || taps == 9, "conv_igemm: the backward epilogues are 3x3 only");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && (long)B * H * W < (1L << 31), "conv_igemm: bad B/H/W");
   EDM_REQUIRE(taps == 1 || taps == 9, "conv_igemm: taps must be 1 or 9 (got %d)", taps);
   EDM_REQUIRE(Cin > 0 && Cin % 32 == 0, "conv_igemm: Cin=%d must be a multiple of 32", Cin);

@@ -58,7 +58,7 @@ __device__ __forceinline__ void static_for(F&& f) {
   asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory");  \
   __builtin_amdgcn_sched_barrier(0)
 
-template <int NX, bool BWD = false>
+template <int NX, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ X, const bf16* __restrict__ Wp,
                                                          bf16* __restrict__ Y, const bf16* __restrict__ R,
                                                          const char* __restrict__ zeros, float alpha, float beta,
@@ -229,19 +229,19 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
   // ---- epilogue: transposed through wave-private LDS so that residual reads and stores are whole rows
   // (common.h: store_tile_transposed; direct stores from the MFMA layout cost 1.7x the HBM write bytes)
   __builtin_amdgcn_s_barrier();  // every wave is done with the slab / weight ring
-  store_tile_transposed<4, 2, BWD>(acc, smem + wave * (32 * (4 * 64 + 16)), Y, R, alpha, beta, (long)m0 + wave * 64, Npix,
+  store_tile_transposed<4, 2, EPI>(acc, smem + wave * (32 * (4 * 64 + 16)), Y, R, alpha, beta, (long)m0 + wave * 64, Npix,
                                    n0, Cout, mod);
 }
 
 char* g_zero_page4 = nullptr;
 
-template <int NX, bool BWD = false>
+template <int NX, int EPI = 0>
 void launch4(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int Npix, int H, int W,
              int Cin, int Cout, const ModEpilogue& mod, hipStream_t st) {
   const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + BN - 1) / BN;
   const size_t lds = (size_t)2 * NX * 8 * 16 * ROWB + WRING * WTILE;
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
-  auto kern = k_conv3x3_v4<NX, BWD>;
+  auto kern = k_conv3x3_v4<NX, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -269,9 +269,12 @@ int edm_conv_igemm_v4_ex(const void* X, const void* Wp, void* Y, const void* R, 
   }
   const int Npix = B * H * W;
   const int xrows = BM + 2 * (W + 1);
-  if (mod.U) {  // modulation-backward epilogue: its own instantiation (keeps the common kernels free of its registers)
-    if (xrows < 5 * 128) launch4<5, true>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st);
-    else launch4<6, true>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st);
+  if (mod.mode == 1) {  // backward epilogues: their own instantiations (keep the common kernels free of their registers)
+    if (xrows < 5 * 128) launch4<5, 1>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st);
+    else launch4<6, 1>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st);
+  } else if (mod.mode == 2) {
+    if (xrows < 5 * 128) launch4<5, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st);
+    else launch4<6, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st);
   } else if (xrows < 5 * 128) launch4<5>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st);
   else launch4<6>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st);
   EDM_CHECK_LAUNCH("conv_igemm_v4");
@@ -298,7 +301,7 @@ extern "C" int edm_conv3x3_mod(const void* X, const void* Wp, void* Y, void* Y2,
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0 && lin_stride >= Cout && pdrop >= 0.f && pdrop < 1.f,
               "conv3x3_mod: bad args");
   ModEpilogue mod{lin, gain, (bf16*)Y2, lin_stride, H * W, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), sub, step,
-                  nullptr, nullptr};
+                  nullptr, nullptr, nullptr, 0.f, 0};
   const long tiles3 = (((long)B * H * W + BM - 1) / BM) * ((Cout + BN - 1) / BN);
   if (tiles3 >= 512) {
     const int rc = edm_conv_igemm_v4_ex(X, Wp, Y, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
@@ -322,11 +325,29 @@ extern "C" int edm_conv3x3_modbwd(const void* dY, const void* Wd, float alpha, c
               "conv3x3_modbwd: bad args");
   if ((H * W) % 32 != 0) return EDM_ERR_UNSUPPORTED;
   ModEpilogue mod{lin, gain, (bf16*)GR, lin_stride, H * W, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), sub, step,
-                  (const bf16*)U, gm};
+                  (const bf16*)U, gm, nullptr, 0.f, 1};
   const long tiles3 = (((long)B * H * W + BM - 1) / BM) * ((Cout + BN - 1) / BN);
   if (tiles3 >= 512) {
     const int rc = edm_conv_igemm_v4_ex(dY, Wd, nullptr, nullptr, alpha, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
     if (rc != EDM_ERR_UNSUPPORTED) return rc;
   }
   return edm_conv_igemm_v1_ex(dY, Wd, nullptr, nullptr, alpha, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
+}
+
+// dgrad of a block's FIRST 3x3 conv with the mp_silu backward of the block input fused into its epilogue
+// (networks.py:249-252 / 313-316 under autograd): with g = conv3x3(dY, Wd) (bf16, never written),
+//   GX = mp_silu'(Xpre) * g + add_scale * ADD        (ADD optional: the residual-path gradient)
+// Same values as edm_conv_igemm followed by edm_silu_bwd.
+extern "C" int edm_conv3x3_silubwd(const void* dY, const void* Wd, const void* Xpre, const void* ADD, float add_scale,
+                                   void* GX, int B, int H, int W, int Cin, int Cout, hipStream_t st) {
+  EDM_REQUIRE(dY && Wd && Xpre && GX, "conv3x3_silubwd: null pointer");
+  EDM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0, "conv3x3_silubwd: bad args");
+  ModEpilogue mod{nullptr, nullptr, (bf16*)GX, 0, H * W, 0.f, 0u, 0u, 0u, 0u, (const bf16*)Xpre, nullptr, (const bf16*)ADD,
+                  add_scale, 2};
+  const long tiles3 = (((long)B * H * W + BM - 1) / BM) * ((Cout + BN - 1) / BN);
+  if (tiles3 >= 512) {
+    const int rc = edm_conv_igemm_v4_ex(dY, Wd, nullptr, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
+    if (rc != EDM_ERR_UNSUPPORTED) return rc;
+  }
+  return edm_conv_igemm_v1_ex(dY, Wd, nullptr, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
 }

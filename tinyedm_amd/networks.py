@@ -612,7 +612,8 @@ class _ResBlockFn(torch.autograd.Function):
             dweh = ops.linear_wgrad(glin, emb)
             gwemb = blk.embed.finish_grad(dweh.view(1, 1, *dweh.shape))
             gemb = ops.linear_dgrad(glin, weh) if ctx.needs_input_grad[1] else None
-        gs = ops.conv_igemm(gr1, wd1, 9)
+        fuse = ops.FUSE_MOD and ops.IGEMM_VERSION == 0 and not enc
+        gs = None if fuse else ops.conv_igemm(gr1, wd1, 9)      # decoder: mp_silu backward rides in the dgrad epilogue
         gw1 = _wgrad(blk.conv_3x3_1, s, gr1, 9)
         gw11 = None
         if enc:
@@ -624,11 +625,11 @@ class _ResBlockFn(torch.autograd.Function):
                 gu = gx
         else:
             if has1:
-                t = ops.silu_bwd(u, gs)
+                t = ops.conv3x3_silubwd(gr1, wd1, u) if fuse else ops.silu_bwd(u, gs)
                 gu = ops.conv_igemm(gout, wd11, 1, residual=t, alpha=a, beta=1.0)
                 gw11 = _wgrad(blk.conv_1x1, u, gout, 1, a)
             else:
-                gu = ops.silu_bwd(u, gs, gout, a)
+                gu = ops.conv3x3_silubwd(gr1, wd1, u, gout, a) if fuse else ops.silu_bwd(u, gs, gout, a)
         return gu, gemb, gw11, gw1, gw2, gwemb, ggain, None, None, None, gtoken
 
 

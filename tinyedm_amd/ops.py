@@ -444,6 +444,28 @@ def conv3x3_modbwd(gout, wd, alpha, r1, lin, gain, pdrop, seed, sub, step, glin_
     return gr, glin, ggain
 
 
+def conv3x3_silubwd(g, wd, xpre, gextra=None, extra_scale=1.0):
+    """dgrad of a block's first 3x3 conv with the mp_silu backward in its epilogue:
+    mp_silu'(xpre) * conv_igemm(g, wd, 9) + extra_scale * gextra  (== conv_igemm followed by silu_bwd)."""
+    B, H, W, Cin = _nhwc(g, "g")
+    _chk(wd, bf16, "wd")
+    if wd.dim() != 3 or wd.shape[0] != 9 or wd.shape[2] != Cin:
+        raise ValueError(f"conv3x3_silubwd: pack shape {tuple(wd.shape)} does not match taps=9, Cin={Cin}")
+    Cout = wd.shape[1]
+    _chk(xpre, bf16, "xpre", (B, H, W, Cout))
+    if gextra is not None:
+        _chk(gextra, bf16, "gextra", xpre.shape)
+    gx = torch.empty_like(xpre)
+    npix = B * H * W
+    entry = _igemm_entry(npix, W, Cout, 9, Cin)
+    pname = "conv3x3_igemm" + ("_v4" if entry == "edm_conv_igemm_v4" else "")
+    with _prof(pname, 2.0 * npix * Cin * Cout * 9,
+               2.0 * (npix * (Cin + Cout * (3 if gextra is not None else 2)) + wd.numel())):
+        _lib.call("edm_conv3x3_silubwd", _p(g), _p(wd), _p(xpre), _p(gextra), float(extra_scale), _p(gx), B, H, W, Cin,
+                  Cout, _stream())
+    return gx
+
+
 WGRAD_1X1 = os.environ.get("EDM_WGRAD_1X1", "1") != "0"
 WGRAD_VERSION = int(os.environ.get("EDM_WGRAD", "2"))   # 1 = register-staged kernel, 2 = LDS-DMA rolling-window kernel
 
