@@ -59,11 +59,17 @@ class GradReducer:
         for b in self.buckets:
             b["pending"] = len(b["params"])
             b["work"] = None
+        self._fired = set()
 
     def _make_hook(self, idx):
         def hook(_param):
-            if not self.enabled:
+            if not self.enabled or idx in self._fired:
                 return
+            # A parameter is counted once per backward pass.  Weights whose gradient the HIP finish kernel writes
+            # straight into the arena announce themselves through `_edm_hooks`, and autograd may ALSO run the
+            # post-accumulate hook for the same parameter (it does so even though the Function returned no gradient
+            # for it): without this guard every bucket was launched before half of its gradients existed.
+            self._fired.add(idx)
             b = self._bucket_of[idx]
             b["pending"] -= 1
             if b["pending"] == 0:
