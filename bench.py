@@ -227,11 +227,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
+    # Test hook (tests/test_ddp_gpu.py): EDM_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 with the gloo backend so the
+    # N>1 code path can be exercised on a one-GPU box (RCCL refuses two ranks on one device).  Never set by the driver.
+    one_device = os.environ.get("EDM_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     model, ips, ms, final_loss, roof = train_bench(args, rank, world, device)

@@ -126,3 +126,26 @@ def test_two_rank_hip_backward_reduces_to_the_mean_of_shard_gradients():
         assert close(a0, ref), (np.linalg.norm(a0 - ref) / np.linalg.norm(ref), np.abs(a0 - ref).max())
         assert close(a1, ref)                                   # second step: same inputs, weights already normalised
     assert np.array_equal(res[0][3], res[1][3])                  # replicas stay bit-identical after the Adam step
+
+
+def test_bench_runs_with_two_ranks_on_one_gpu():
+    """bench.py's N>1 path end to end (rank set-up, barriers, max-over-ranks timing, the instrumented steps on every
+    rank, one JSON line from rank 0), launched exactly as the driver does but with both ranks on cuda:0 over gloo."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EDM_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "8"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 16 and out["value"] > 0
+    assert "sampler" not in out and "cpu_baseline" not in out and out["roofline"]["bound"] == "mfma"
