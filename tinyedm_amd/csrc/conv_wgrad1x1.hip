@@ -170,6 +170,7 @@ extern "C" int edm_conv_wgrad_1x1_nsplit(long npix, int Cin, int Cout) {
   long S = (256 + tiles - 1) / tiles;            // ~one workgroup per CU
   const long max_s = (npix + 4 * KP - 1) / (4 * KP);  // at least 4 stages per workgroup
   if (S > max_s) S = max_s;
+  if (S > 64) S = 64;  // more splits buy no kernel time (r01 sweep) but every slab is re-read by the finish pass
   if (S < 1) S = 1;
   return (int)S;
 }
