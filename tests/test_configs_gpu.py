@@ -132,3 +132,31 @@ def test_latent32_default_denoiser_forward():
     """ImageNet-256 latent diffusion: the same default net on 32x32x4 latents (attention at 8x8 and 4x4)."""
     ecfg, dcfg = imagenet_cfg()
     eval_parity(ecfg, dcfg, (2, 4, 32, 32), seed=9, tol=2e-2)
+
+
+@pytest.mark.parametrize("name", ["mnist", "cifar10_cond", "default32"])
+def test_full_size_configs_match_reference_golden(golden_dir, name):
+    """HIP path vs the output the REFERENCE produced for the same seeded weights and inputs (tests/golden/configs.npz,
+    oracle/make_golden_configs.py): on the network part D - c_skip*x, no worse than 2x the reference's own
+    bf16-autocast deviation from its fp32 output (floor 5e-3)."""
+    import os
+    import numpy as np
+    import tinyedm_amd.networks as N
+    from oracle.make_golden_configs import config_cases
+    ecfg, dcfg, shape, seed = config_cases(N)[name]
+    g = np.load(os.path.join(golden_dir, "configs.npz"))
+    P = O.init_params(ecfg, dcfg, torch.Generator().manual_seed(seed))
+    emb, den = build(ecfg, dcfg, P)
+    emb.eval(); den.eval()
+    noisy = torch.from_numpy(g[name + "::noisy"])
+    sigma = torch.from_numpy(g[name + "::sigma"])
+    labels = torch.from_numpy(g[name + "::labels"])
+    with torch.no_grad():
+        _, e = emb(sigma.to(DEV), labels.to(DEV))
+        D = den(noisy.to(DEV), sigma.to(DEV), e).cpu()
+    ref32, refbf = torch.from_numpy(g[name + "::D"]), torch.from_numpy(g[name + "::D_autocast_bf16"])
+    c_skip, _, _ = O.precond_scalars(sigma, dcfg.sigma_data)
+    base = c_skip * noisy
+    r_hip, r_ref = rel(D - base, ref32 - base), rel(refbf - base, ref32 - base)
+    print(f"{name}: HIP vs reference fp32 {r_hip:.3e}; reference's own bf16 autocast {r_ref:.3e}")
+    assert r_hip <= max(2.0 * r_ref, 5e-3)

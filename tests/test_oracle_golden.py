@@ -176,3 +176,31 @@ def test_adam_matches_torch_optim():
         opt.step()
         O.adam_step(th, gr, m, v, step, 0.02)
         assert torch.allclose(th, p.data, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["mnist", "cifar10_cond", "default32"])
+def test_full_size_configs_eval_forward_matches_reference(golden_dir, name):
+    """The oracle on the reference's full-size configurations (MNIST 87 M, CIFAR-10 conditional 35.6 M, default
+    ImageNet / latent net 272.9 M parameters; head dims 64/128/144/192) vs outputs the reference itself produced
+    (oracle/make_golden_configs.py)."""
+    from oracle.make_golden_configs import config_cases
+
+    class _Tables:   # the default-architecture tables, pinned separately by tests/golden/tables.npz
+        pass
+    t = np.load(os.path.join(golden_dir, "tables.npz"))
+    tb = _Tables()
+    tb.get_encoder_blocks_types = lambda: [str(s) for s in t["enc_types"]]
+    tb.get_decoder_blocks_types = lambda: [str(s) for s in t["dec_types"]]
+    tb.get_encoder_out_channels = lambda: [int(v) for v in t["enc_ch"]]
+    tb.get_decoder_out_channels = lambda: [int(v) for v in t["dec_ch"]]
+    tb.get_skip_connections = lambda: [bool(v) for v in t["skips"]]
+    ecfg, dcfg, shape, seed = config_cases(tb)[name]
+    g = np.load(os.path.join(golden_dir, "configs.npz"))
+    P = O.init_params(ecfg, dcfg, torch.Generator().manual_seed(seed))
+    noisy, sigma, labels = T(g[name + "::noisy"]), T(g[name + "::sigma"]), T(g[name + "::labels"])
+    assert tuple(noisy.shape) == shape
+    with torch.no_grad():
+        D = O.edm_forward(P, ecfg, dcfg, noisy, sigma, labels)
+    ref = T(g[name + "::D"])
+    rel = ((D - ref).norm() / ref.norm()).item()
+    assert rel <= 1e-4, f"{name}: oracle vs reference rel {rel:.3e}"
