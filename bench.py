@@ -47,7 +47,8 @@ def pmc_traffic(kernel):
     inside the process, so this is the offline measurement of the same command), or None."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as f:
-            rec = json.load(f)["kernels"].get(kernel)
+            ks = json.load(f)["kernels"]
+        rec = ks.get(kernel + "<5, 0>") or ks.get(kernel)
         return None if rec is None else round(rec["hbm_gb_per_launch"], 4)
     except (OSError, ValueError, KeyError):
         return None
@@ -245,7 +246,9 @@ def main():
     model, ips, ms, final_loss, roof = train_bench(args, rank, world, device)
     out = None
     if rank == 0:
-        # dominant kernel: k_conv3x3_v4 (3x3 implicit GEMM, forward + dgrad of the 32x32 layers)
+        # dominant kernel: k_conv3x3_v4<5,0> (3x3 implicit GEMM of the 32x32 layers: forward convs, with the modulation
+        # epilogue on the first conv of each block, and plain dgrads; the two backward-epilogue instantiations
+        # <5,1>/<5,2> are reported beside it in per_kernel as ..._v4_modbwd / ..._v4_silubwd)
         conv = roof.get("conv3x3_igemm_v4", {"launches": 0, "ms": 0.0, "gflop": 0.0, "gbytes": 0.0})
         achieved = conv["gflop"] / conv["ms"] if conv["ms"] > 0 else 0.0          # GFLOP/ms == TFLOP/s
         traffic = pmc_traffic("k_conv3x3_v4")
@@ -259,7 +262,8 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "conditional": bool(args.conditional), "final_loss": final_loss},
             "roofline": {
-                "bound": "mfma", "kernel": "k_conv3x3_v4 (3x3 implicit-GEMM conv, fwd + dgrad of the 32x32 layers)",
+                "bound": "mfma", "kernel": "k_conv3x3_v4<5,0> (3x3 implicit-GEMM conv of the 32x32 layers: forward, incl. fused modulation "
+                                           "epilogue, and plain dgrad)",
                 "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "traffic_unit": "GB of HBM traffic per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc "

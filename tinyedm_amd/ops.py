@@ -436,7 +436,7 @@ def conv3x3_modbwd(gout, wd, alpha, r1, lin, gain, pdrop, seed, sub, step, glin_
     ggain = zeros_f32((), r1.device)
     npix = B * H * W
     entry = _igemm_entry(npix, W, Cout, 9, Cin)
-    pname = "conv3x3_igemm" + ("_v4" if entry == "edm_conv_igemm_v4" else "")
+    pname = "conv3x3_igemm" + ("_v4" if entry == "edm_conv_igemm_v4" else "") + "_modbwd"   # own kernel instantiation
     with _prof(pname, 2.0 * npix * Cin * Cout * 9, 2.0 * (npix * (Cin + 2 * Cout) + wd.numel())):
         _lib.call("edm_conv3x3_modbwd", _p(gout), _p(wd), float(alpha), _p(r1), _p(lin), ls, _p(gain), _p(gr), _p(gm),
                   float(pdrop), int(seed), int(sub), int(step), B, H, W, Cin, Cout, _stream())
@@ -458,7 +458,7 @@ def conv3x3_silubwd(g, wd, xpre, gextra=None, extra_scale=1.0):
     gx = torch.empty_like(xpre)
     npix = B * H * W
     entry = _igemm_entry(npix, W, Cout, 9, Cin)
-    pname = "conv3x3_igemm" + ("_v4" if entry == "edm_conv_igemm_v4" else "")
+    pname = "conv3x3_igemm" + ("_v4" if entry == "edm_conv_igemm_v4" else "") + "_silubwd"  # own kernel instantiation
     with _prof(pname, 2.0 * npix * Cin * Cout * 9,
                2.0 * (npix * (Cin + Cout * (3 if gextra is not None else 2)) + wd.numel())):
         _lib.call("edm_conv3x3_silubwd", _p(g), _p(wd), _p(xpre), _p(gextra), float(extra_scale), _p(gx), B, H, W, Cin,
