@@ -215,7 +215,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (BASELINE.json configs[1]: 128)")
     ap.add_argument("--conditional", action="store_true")
-    ap.add_argument("--sampler-batch", type=int, default=256)
+    ap.add_argument("--sampler-batch", type=int, default=512)
     ap.add_argument("--sampler-iters", type=int, default=2)
     ap.add_argument("--no-sampler", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
