@@ -201,3 +201,48 @@ def test_heun_trajectory_matches_reference_and_hipgraph_replay(tiny, golden_dir)
     x_graph2 = sol.solve(model, x0, lab, graph=True)       # second call = pure replay
     assert torch.equal(x_graph, x_eager) and torch.equal(x_graph2, x_eager)
     print(f"heun trajectory rel err: vs reference fp32 {r_ref:.2e}, vs bf16 oracle {r_or:.2e}")
+
+
+def test_uncertainty_branch_matches_reference_and_oracle(tiny, golden_dir):
+    """UncertaintyNet forward vs the reference's own output, and the `use_uncertainty=True` training
+    loss (edm.py:213-219: wMSE(weight/exp(u)) + mean(u)) vs the oracle's restatement, with gradients reaching u."""
+    import tinyedm_amd as T
+    from tinyedm_amd.networks import UncertaintyNet
+    gu = np.load(os.path.join(golden_dir, "uncertainty.npz"))
+    un = UncertaintyNet(32, 32).to(DEV)
+    with torch.no_grad():
+        un.linear1.weight.copy_(T_(gu["w1"]))
+        un.linear2.weight.copy_(T_(gu["w2"]))
+        un.gain.fill_(float(gu["gain"]))
+    un.eval()
+    with torch.no_grad():
+        y = un(T_(gu["x"]).to(DEV))
+    assert torch.allclose(y.cpu(), T_(gu["y"]), rtol=1e-4, atol=1e-5)
+
+    g, ecfg, dcfg, P = tiny
+    emb, den = build(ecfg, dcfg, P)
+    model = T.EDM(diffuser=T.Diffuser(-1.2, 1.2), embedding=emb, denoiser=den, use_ema=False, use_uncertainty=True,
+                  steady_steps=10, rampup_steps=2, scheduler_interval="step", lr=1e-3).to(DEV).train()
+    with torch.no_grad():
+        model.u.gain.fill_(0.5)
+    clean, labels = T_(g["clean"]).to(DEV), T_(g["labels"]).to(DEV)
+    noisy, sigma = T_(g["noisy"]).to(DEV), T_(g["sigma"]).to(DEV)
+    four, e = model.embedding(sigma, labels)
+    D = model.denoiser(noisy, sigma, e)
+    w = (sigma ** 2 + 0.25) / (sigma * 0.5) ** 2
+    u = model.u(four).flatten()
+    loss = model.train_mse(w / u.exp(), D, clean) + u.mean()
+    loss.backward()
+    # oracle: same weights (after the training forward's in-place normalisation), bf16 rounding points
+    Pb = {k: v.clone() for k, v in P.items()}
+    O.force_normalize_(Pb)
+    fo, eo = O.embedding_forward(Pb, ecfg, T_(g["sigma"]), T_(g["labels"]))
+    Do = O.denoiser_forward(Pb, dcfg, T_(g["noisy"]), T_(g["sigma"]), eo, training=True, bf16=True)
+    U = {"u.linear1.weight": O.weight_normalize(model.u.linear1.weight.detach().cpu()),
+         "u.linear2.weight": O.weight_normalize(model.u.linear2.weight.detach().cpu()), "u.gain": torch.tensor(0.5)}
+    uo = O.uncertainty_forward(U, fo).flatten()
+    wo = O.loss_weight(T_(g["sigma"]), 0.5)
+    lo = O.weighted_mse(wo / uo.exp(), Do, T_(g["clean"])) + uo.mean()
+    assert abs(loss.item() - lo.item()) <= 3e-2 * abs(lo.item()), (loss.item(), lo.item())
+    for name, p in model.u.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0, name

@@ -204,3 +204,10 @@ def test_full_size_configs_eval_forward_matches_reference(golden_dir, name):
     ref = T(g[name + "::D"])
     rel = ((D - ref).norm() / ref.norm()).item()
     assert rel <= 1e-4, f"{name}: oracle vs reference rel {rel:.3e}"
+
+
+def test_uncertainty_net_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "uncertainty.npz"))
+    U = {"u.linear1.weight": T(g["w1"]), "u.linear2.weight": T(g["w2"]), "u.gain": torch.tensor(float(g["gain"]))}
+    y = O.uncertainty_forward(U, T(g["x"]))
+    assert torch.allclose(y, T(g["y"]), rtol=1e-5, atol=1e-6)
