@@ -246,3 +246,81 @@ def test_uncertainty_branch_matches_reference_and_oracle(tiny, golden_dir):
     assert abs(loss.item() - lo.item()) <= 3e-2 * abs(lo.item()), (loss.item(), lo.item())
     for name, p in model.u.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0, name
+
+
+def test_three_optimizer_steps_track_the_oracle(tiny):
+    """End to end: EDM.training_step -> backward -> FusedAdam+EMA (one fused kernel) under the LR schedule, three
+    steps with injected noise, vs the oracle's restatement (training_loss + adam_step + ema_step + lr_lambda).
+    Pins the integration the per-kernel tests cannot: in-place weight renormalisation every step, bias corrections,
+    the 0-based EMA beta schedule, scheduler stepping, zero_grad."""
+    import tinyedm_amd as T
+    from tinyedm_amd.ema import EMAOptimizer
+    g, ecfg, dcfg, P = tiny
+    emb, den = build(ecfg, dcfg, P)
+    model = T.EDM(diffuser=T.Diffuser(-1.2, 1.2), embedding=emb, denoiser=den, use_ema=True, use_uncertainty=False,
+                  steady_steps=2, rampup_steps=2, scheduler_interval="step", lr=2e-3, ema_length=0.13).to(DEV).train()
+    cfg = model.configure_optimizers()
+    base, sched = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
+    gamma = T.sigma_rel_to_gamma(0.13)
+    opt = EMAOptimizer(base, device=DEV, gamma=gamma)
+    gi = torch.Generator().manual_seed(77)
+    B = 4
+    clean = 0.5 * torch.randn(B, 3, 8, 8, generator=gi)
+    labels = torch.randint(0, 10, (B,), generator=gi)
+    draws = [(torch.randn(B, generator=gi), torch.randn(B, 3, 8, 8, generator=gi)) for _ in range(3)]
+
+    class Fixed(torch.nn.Module):       # Diffuser with the two normal draws injected (edm.py:86-93)
+        def __init__(self):
+            super().__init__()
+            self.k = 0
+
+        def forward(self, x):
+            eps, noise = draws[self.k]
+            self.k += 1
+            noisy, sigma = O.diffuse(x.cpu(), eps, noise, -1.2, 1.2)
+            return noisy.to(DEV), sigma.to(DEV)
+    model.diffuser = Fixed()
+
+    # ---- oracle side
+    Po = {k: v.clone() for k, v in P.items()}
+    keys = O.trainable_keys(Po)
+    for k in keys:
+        Po[k].requires_grad_(True)
+    m = {k: torch.zeros_like(Po[k]) for k in keys}
+    v = {k: torch.zeros_like(Po[k]) for k in keys}
+    ema = {k: Po[k].detach().clone() for k in keys}
+    theta0 = {k: Po[k].detach().clone() for k in keys}
+    losses_o, losses_h = [], []
+    opt.zero_grad()
+    for it in range(3):
+        lr = 2e-3 * O.lr_lambda(it, 2, 2)
+        eps, noise = draws[it]
+        lo = O.training_loss(Po, ecfg, dcfg, clean, eps, noise, -1.2, 1.2, labels, bf16=True)
+        grads = torch.autograd.grad(lo, [Po[k] for k in keys])
+        with torch.no_grad():
+            for k, gr in zip(keys, grads):
+                O.adam_step(Po[k], gr, m[k], v[k], it + 1, lr)
+                O.ema_step(ema[k], Po[k], O.ema_beta(it, gamma))
+        losses_o.append(lo.item())
+        # ---- HIP side
+        assert abs(sched.get_last_lr()[0] - lr) <= 1e-12 + 1e-6 * lr
+        lh = model.training_step((clean.to(DEV), labels.to(DEV)), it)
+        lh.backward()
+        opt.step()
+        opt.zero_grad()
+        sched.step()
+        losses_h.append(lh.item())
+    for a, b in zip(losses_h, losses_o):
+        assert abs(a - b) <= 3e-2 * abs(b), (losses_h, losses_o)
+    named = {("embedding." + k): p for k, p in model.embedding.named_parameters()}
+    named.update({("denoiser." + k): p for k, p in model.denoiser.named_parameters()})
+    ema_h = dict(zip([k for k, _ in model.named_parameters()], opt.ema_params))
+    up_h = torch.cat([(named[k].detach().cpu() - theta0[k]).flatten() for k in keys if named[k].numel() > 1])
+    up_o = torch.cat([(Po[k].detach() - theta0[k]).flatten() for k in keys if Po[k].numel() > 1])
+    cos = torch.nn.functional.cosine_similarity(up_h, up_o, dim=0).item()
+    assert cos >= 0.97, f"parameter update direction after 3 steps: cosine {cos:.4f}"
+    assert abs(up_h.norm().item() / up_o.norm().item() - 1.0) <= 0.05
+    # EMA: the fused kernel's average tracks the oracle's ema_step chain
+    e_h = torch.cat([ema_h[k].detach().cpu().flatten() for k in ema_h if ema_h[k].numel() > 1 and k in ema])
+    e_o = torch.cat([ema[k].flatten() for k in ema_h if ema_h[k].numel() > 1 and k in ema])
+    assert rel(e_h, e_o) <= 2e-3
