@@ -584,6 +584,7 @@ class _ResBlockFn(torch.autograd.Function):
         ctx.blk, ctx.enc, ctx.has1 = blk, enc, has1
         ctx.drop = (pdrop, seed, sub, step)
         ctx.batched, ctx.glin_view = batched, glin_view
+        ctx.has_token = token is not None
         ctx.save_for_backward(u, xres if enc else None, dsave, s, r1, lin, a2, None if batched else emb, gain, wd1, wd2,
                               wd11, weh)
         return out
@@ -598,16 +599,26 @@ class _ResBlockFn(torch.autograd.Function):
         # d loss / d lin goes (batched mode) into this block's column slice of the shared buffer; _EmbedAllFn.backward
         # turns the whole buffer into the embed-weight and embedding gradients with two GEMMs
         glin_out = ctx.glin_view if ctx.batched else None
+        # flat-arena mode: d loss / d gain is accumulated straight into the gradient arena (no AccumulateGrad add)
+        gp = blk.gain
+        gdirect = gp.grad is not None and getattr(gp, "_edm_direct", False) and gp.grad.is_contiguous()
+        ggain_out = gp.grad if gdirect else None
         if ops.FUSE_MOD and ops.IGEMM_VERSION == 0 and (gout.shape[1] * gout.shape[2]) % 32 == 0:
             # conv2's dgrad with the modulation backward in its epilogue: ga2 never touches HBM
-            gr1, glin, ggain = ops.conv3x3_modbwd(gout, wd2, b, r1, lin, gain, pdrop, seed, sub, step, glin_out=glin_out)
+            gr1, glin, ggain = ops.conv3x3_modbwd(gout, wd2, b, r1, lin, gain, pdrop, seed, sub, step, glin_out=glin_out,
+                                                     ggain_out=ggain_out)
         else:
             ga2 = ops.conv_igemm(gout, wd2, 9, alpha=b)
-            gr1, glin, ggain = ops.mod_silu_drop_bwd(r1, lin, gain, ga2, pdrop, seed, sub, step, glin_out=glin_out)
+            gr1, glin, ggain = ops.mod_silu_drop_bwd(r1, lin, gain, ga2, pdrop, seed, sub, step, glin_out=glin_out,
+                                                        ggain_out=ggain_out)
+        if gdirect:
+            ggain = None
+            for hook in getattr(gp, "_edm_hooks", ()):
+                hook(gp)
         gw2 = _wgrad(blk.conv_3x3_2, a2, gout, 9, b)
         gwemb = gemb = gtoken = None
         if ctx.batched:
-            gtoken = ops.zeros_f32((1,), gout.device)
+            gtoken = ops.zeros_f32((1,), gout.device) if ctx.has_token else None
         else:
             dweh = ops.linear_wgrad(glin, emb)
             gwemb = blk.embed.finish_grad(dweh.view(1, 1, *dweh.shape))
@@ -942,9 +953,12 @@ class Denoiser(nn.Module):
         blocks = self._res_blocks()
         lin_all, glin_all, token = _EmbedAllFn.apply(emb, self, *[b.embed.weight for b in blocks])
         lins, off = {}, 0
-        for b in blocks:
+        for k, b in enumerate(blocks):
             C = b.embed.weight.shape[0]
-            lins[b] = (lin_all[:, off:off + C], glin_all[:, off:off + C], token)
+            # the ordering edge goes to the FIRST block only: every other block is downstream of its output, so its
+            # backward -- and with it _EmbedAllFn.backward -- runs after all of them (one edge instead of 21 that
+            # autograd would sum with 20 tiny adds)
+            lins[b] = (lin_all[:, off:off + C], glin_all[:, off:off + C], token if k == 0 else None)
             off += C
 
         x = _ConvInFn.apply(noisy, sig, self.conv_in.weight, self)

@@ -182,8 +182,9 @@ def mod_silu_drop_fwd(r, lin, gain, pdrop, seed, sub, step):
     return a
 
 
-def mod_silu_drop_bwd(r, lin, gain, ga, pdrop, seed, sub, step, glin_out=None):
-    """glin_out: optional (B, C) strided fp32 view to receive d loss / d lin (else a fresh tensor)."""
+def mod_silu_drop_bwd(r, lin, gain, ga, pdrop, seed, sub, step, glin_out=None, ggain_out=None):
+    """glin_out: optional (B, C) strided fp32 view to receive d loss / d lin (else a fresh tensor);
+    ggain_out: optional 0-dim fp32 tensor that d loss / d gain is ACCUMULATED into (else a fresh zero scalar)."""
     B, H, W, C = _nhwc(r, "r")
     ls = _lin_view(lin, B, C, "lin")
     _chk(ga, bf16, "ga", r.shape)
@@ -191,7 +192,7 @@ def mod_silu_drop_bwd(r, lin, gain, ga, pdrop, seed, sub, step, glin_out=None):
     gm = zeros_f32((B, C), r.device)
     glin = torch.empty(B, C, device=r.device, dtype=f32) if glin_out is None else glin_out
     gs = _lin_view(glin, B, C, "glin")
-    ggain = zeros_f32((), r.device)
+    ggain = zeros_f32((), r.device) if ggain_out is None else _chk(ggain_out, f32, "ggain_out", ())
     _lib.call("edm_mod_silu_drop_bwd", _p(r), _p(lin), ls, _p(gain), _p(ga), _p(gr), _p(gm), _p(glin), gs, _p(ggain), B,
               H * W, C, float(pdrop), int(seed), int(sub), int(step), _stream())
     return gr, glin, ggain
@@ -416,7 +417,7 @@ def conv3x3_mod(x, wp, lin, gain, pdrop, seed, sub, step, want_u=True):
     return u, a2
 
 
-def conv3x3_modbwd(gout, wd, alpha, r1, lin, gain, pdrop, seed, sub, step, glin_out=None):
+def conv3x3_modbwd(gout, wd, alpha, r1, lin, gain, pdrop, seed, sub, step, glin_out=None, ggain_out=None):
     """dgrad of a block's second 3x3 conv with the modulation backward in its epilogue: returns (gr1, glin, ggain),
     the values conv_igemm(gout, wd, 9, alpha=alpha) followed by mod_silu_drop_bwd would give (H*W % 32 == 0)."""
     B, H, W, Cin = _nhwc(gout, "gout")
@@ -433,7 +434,7 @@ def conv3x3_modbwd(gout, wd, alpha, r1, lin, gain, pdrop, seed, sub, step, glin_
     gm = zeros_f32((B, Cout), r1.device)
     glin = torch.empty(B, Cout, device=r1.device, dtype=f32) if glin_out is None else glin_out
     gs = _lin_view(glin, B, Cout, "glin")
-    ggain = zeros_f32((), r1.device)
+    ggain = zeros_f32((), r1.device) if ggain_out is None else _chk(ggain_out, f32, "ggain_out", ())
     npix = B * H * W
     entry = _igemm_entry(npix, W, Cout, 9, Cin)
     pname = "conv3x3_igemm" + ("_v4" if entry == "edm_conv_igemm_v4" else "") + "_modbwd"   # own kernel instantiation
