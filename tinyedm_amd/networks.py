@@ -371,18 +371,22 @@ class ScaleLong(nn.Module):
 
 class _ConcatGateFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, inp, skip, w1, w2, sl: ScaleLong):
+    def forward(ctx, inp, skip, w1, w2, sl: ScaleLong, want_silu: bool = False):
         B, H, W, Cs = skip.shape
         w1h, w2h = sl.layer1.packs()[2], sl.layer2.packs()[2]
         mean = ops.reduce_hw(skip, scale=1.0 / (H * W))
         gate, z1 = ops.scalelong_fwd(mean, w1h, w2h)
-        cat, _ = ops.concat_gate_fwd(inp, skip, gate, False)
+        # want_silu: also emit mp_silu(cat), the input of the block's first conv, from the same pass
+        cat, sil = ops.concat_gate_fwd(inp, skip, gate, want_silu)
         ctx.sl, ctx.Ci = sl, inp.shape[-1]
         ctx.save_for_backward(skip, mean, gate, z1, w1h, w2h)
+        if want_silu:
+            ctx.mark_non_differentiable(sil)
+            return cat, sil
         return cat
 
     @staticmethod
-    def backward(ctx, gcat):
+    def backward(ctx, gcat, _gsil=None):
         skip, mean, gate, z1, w1h, w2h = ctx.saved_tensors
         gcat = gcat.contiguous()
         Ci, Cs = ctx.Ci, skip.shape[-1]
@@ -391,7 +395,7 @@ class _ConcatGateFn(torch.autograd.Function):
         ginp, gskip = ops.concat_gate_bwd(gcat, gate, gmean, Ci)
         gw1 = ctx.sl.layer1.finish_grad(gw1h.view(1, 1, *gw1h.shape))
         gw2 = ctx.sl.layer2.finish_grad(gw2h.view(1, 1, *gw2h.shape))
-        return ginp, gskip, gw1, gw2, None
+        return ginp, gskip, gw1, gw2, None, None
 
 
 # --------------------------------------------------------------------------------------
@@ -547,7 +551,7 @@ class _ResBlockFn(torch.autograd.Function):
     -> conv3x3 -> mp_add with the skip path (networks.py:246-263 encoder / 312-327 decoder)."""
 
     @staticmethod
-    def forward(ctx, u, emb, w1x1, w1, w2, wemb, gain, blk, lin_view, glin_view, token):
+    def forward(ctx, u, emb, w1x1, w1, w2, wemb, gain, blk, lin_view, glin_view, token, s_pre=None):
         enc = blk.is_encoder
         has1 = w1x1 is not None
         taps = 9
@@ -567,7 +571,7 @@ class _ResBlockFn(torch.autograd.Function):
             if has1:
                 wf11, wd11, _ = blk.conv_1x1.packs()
                 xres = ops.conv_igemm(u, wf11, 1)
-            s = ops.silu_fwd(u)
+            s = s_pre if s_pre is not None else ops.silu_fwd(u)     # s_pre: emitted by the concat kernel
             dsave = None
         lin = lin_view if batched else ops.linear_fwd(emb, weh)
         pdrop = blk.dropout_rate if blk.training else 0.0
@@ -641,7 +645,7 @@ class _ResBlockFn(torch.autograd.Function):
                 gw11 = _wgrad(blk.conv_1x1, u, gout, 1, a)
             else:
                 gu = ops.conv3x3_silubwd(gr1, wd1, u, gout, a) if fuse else ops.silu_bwd(u, gs, gout, a)
-        return gu, gemb, gw11, gw1, gw2, gwemb, ggain, None, None, None, gtoken
+        return gu, gemb, gw11, gw1, gw2, gwemb, ggain, None, None, None, gtoken, None
 
 
 _rng_sub_counter = [0]
@@ -659,15 +663,15 @@ class _BlockBase(nn.Module):
         _rng_sub_counter[0] += 1
         self.rng_sub = _rng_sub_counter[0]
 
-    def _res(self, u: Tensor, embedding: Tensor, lin=None) -> Tensor:
+    def _res(self, u: Tensor, embedding: Tensor, lin=None, s_pre=None) -> Tensor:
         w11 = self.conv_1x1.weight if isinstance(self.conv_1x1, Conv2d) else None
         if lin is None:
             out = _ResBlockFn.apply(u, embedding, w11, self.conv_3x3_1.weight, self.conv_3x3_2.weight,
-                                    self.embed.weight, self.gain, self, None, None, None)
+                                    self.embed.weight, self.gain, self, None, None, None, s_pre)
         else:
             lin_view, glin_view, token = lin
             out = _ResBlockFn.apply(u, None, w11, self.conv_3x3_1.weight, self.conv_3x3_2.weight, None, self.gain,
-                                    self, lin_view, glin_view, token)
+                                    self, lin_view, glin_view, token, s_pre)
         if isinstance(self.attention, CosineAttention):
             out = self.attention.forward_nhwc(out)
         return out
@@ -725,13 +729,19 @@ class DecoderBlock(_BlockBase):
 
     def forward(self, input: Tensor, embedding: Tensor, skip: Tensor | None = None, _lin=None) -> Tensor:
         x, conv = _as_nhwc(input)
+        s_pre = None
         if skip is not None:
             assert self.cat_factor is not None
             sk, _ = _as_nhwc(skip)
-            x = _ConcatGateFn.apply(x, sk, self.cat_factor.layer1.weight, self.cat_factor.layer2.weight, self.cat_factor)
+            fuse_silu = not isinstance(self.resample, UpSample)    # mp_silu(cat) is conv1's input unless an upsample follows
+            x = _ConcatGateFn.apply(x, sk, self.cat_factor.layer1.weight, self.cat_factor.layer2.weight, self.cat_factor,
+                                    fuse_silu)
+            if fuse_silu:
+                x, s_pre = x
         if isinstance(self.resample, UpSample):
             x = _ResampleFn.apply(x, True)
-        out = self._res(x, None if _lin is not None else _emb32(embedding, x.shape[0]), _lin)
+            s_pre = None
+        out = self._res(x, None if _lin is not None else _emb32(embedding, x.shape[0]), _lin, s_pre)
         return ops.nhwc_bf16_to_nchw(out).to(input.dtype) if conv else _tag(out)
 
 
