@@ -3,6 +3,9 @@ random labels like the reference's RandomNoiseDataset, run the hipGraph-captured
 
     python experiments/generate.py --ckpt last.ckpt --num-samples 50000 --batch-size 512 --out samples [--load-ema]
     python experiments/generate.py --config-name cifar10 --num-samples 64      # random-init weights (plumbing)
+
+Multi-GPU = replicas only: under `python -m torch.distributed.run --nproc-per-node N` every rank samples
+its own contiguous index range with its own noise seed and writes `<global index>.png`; there is no collective.
 """
 import argparse
 import os
@@ -33,6 +36,11 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
 
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    per_rank = (a.num_samples + world - 1) // world
+    first = rank * per_rank
+    n_local = max(0, min(per_rank, a.num_samples - first))
     if a.ckpt:
         model = tinyedm.EDM.load_from_checkpoint(a.ckpt, load_ema=a.load_ema)
     else:
@@ -44,14 +52,15 @@ def main():
     model.solver = tinyedm.DeterministicSolver(num_steps=a.num_steps)
     C = model.denoiser.in_channels
     H = 28 if C == 1 else 32
-    dm = RandomNoiseDataModule(a.batch_size, a.num_samples, image_shape=(C, H, H), num_classes=model.num_classes,
-                               seed=a.seed)
+    dm = RandomNoiseDataModule(a.batch_size, n_local, image_shape=(C, H, H), num_classes=model.num_classes,
+                               seed=a.seed + 1000003 * rank)
     mean = a.mean or [0.5] * C
     std = a.std or [0.25] * C        # pred*std*2 + mean with std 0.25: [-1,1] -> [0,1]
-    writer = PreditionWriter(a.out, "batch", mean, std)
+    writer = PreditionWriter(a.out, "batch", mean, std, first_index=first)
     trainer = tinyedm.Trainer(callbacks=[writer])
-    trainer.predict(model, datamodule=dm)
-    print(f"wrote {a.num_samples} images to {a.out}")
+    if n_local > 0:
+        trainer.predict(model, datamodule=dm, distributed=False)
+    print(f"[rank {rank}] wrote images {first}..{first + n_local - 1} to {a.out}")
 
 
 if __name__ == "__main__":

@@ -78,12 +78,12 @@ class GenerateCallback:
 
 class PreditionWriter:
     def __init__(self, output_dir: str, write_interval: Literal["batch", "epoch", "batch_and_epoch"], mean: Sequence,
-                 std: Sequence):
+                 std: Sequence, first_index: int = 0):
         self.output_dir = Path(output_dir)
         self.write_interval = write_interval
         self.mean, self.std = [float(v) for v in mean], [float(v) for v in std]
         self._mean_t = self._std_t = None
-        self._count = 0
+        self._count = first_index          # replicas write disjoint global index ranges
         self.output_dir.mkdir(parents=True, exist_ok=True)
 
     def setup(self, trainer, pl_module, stage: str = "predict"):

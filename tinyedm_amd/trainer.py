@@ -200,8 +200,12 @@ class Trainer:
 
     # ------------------------------------------------------------------ predict
     @torch.no_grad()
-    def predict(self, model, datamodule=None, dataloaders=None, ckpt_path=None):
-        self._setup_distributed(model)
+    def predict(self, model, datamodule=None, dataloaders=None, ckpt_path=None, distributed: bool = True):
+        """``distributed=False``: replicas-only sampling (no process group; each rank runs its own loader)."""
+        if distributed:
+            self._setup_distributed(model)
+        elif torch.cuda.is_available():
+            model.to(torch.device("cuda", torch.cuda.current_device()))
         model.trainer = self
         model.eval()
         self.datamodule = datamodule
