@@ -16,8 +16,12 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails in legacy mode); the driver
+# exports this already, keep it for hand launches.  Must be set before the HIP runtime initialises.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
