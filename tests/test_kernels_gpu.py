@@ -539,3 +539,20 @@ def test_step_level_kernels(ops):
     assert torch.allclose(dx.cpu(), dx_ref, atol=1e-6) and torch.allclose(x1.cpu(), x1_ref, atol=1e-6)
     out = ops.heun_correct(x.to(DEV), dx, x1, D1.to(DEV), t0, t1)
     assert torch.allclose(out.cpu(), x + (t1 - t0) * (0.5 * dx_ref + 0.5 * (x1_ref - D1) / t1), atol=1e-5)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 64, 64, 64, 64), (2, 33, 63, 64, 128), (1, 16, 100, 64, 64),
+                                             (1, 9, 126, 96, 64), (3, 5, 70, 64, 64)])
+def test_conv_wgrad_wide_images(ops, B, H, W, Cin, Cout):
+    """3x3 weight gradient on images wider than one 64-row stage (W 63..126: the 8-slot rolling window of
+    conv_wgrad2.hip, used by the 64x64 layers of the ImageNet / latent nets) vs an fp64 convolution backward."""
+    g = torch.Generator().manual_seed(W + Cin)
+    x = q(torch.randn(B, Cin, H, W, generator=g))
+    gy = q(torch.randn(B, Cout, H, W, generator=g))
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, padding=1).backward(gy.double())
+    ref = w.grad.permute(2, 3, 0, 1).reshape(9, Cout, Cin)
+    assert ops.WGRAD_VERSION == 2
+    slabs = ops.conv_wgrad(nhwc(x), nhwc(gy), 9)
+    got = slabs.double().sum(0).cpu()
+    assert rel(got, ref) <= 1e-5, f"wide wgrad rel {rel(got, ref):.3e}"

@@ -26,7 +26,16 @@ typedef __attribute__((address_space(3))) char lds_char;
 
 constexpr int KP = 64;                 // padded rows per stage
 constexpr int SUBB = KP * 64;          // bytes of one [64 rows][32 ch] sub-image stage
-constexpr int DYRING = 3, XSLOTS = 6;  // dY stages in flight; X: 4 ring slots + 2 mirrors
+// LEADS = X stages of lead-in before the split's first dY stage = how many 64-row stages the 3x3 halo (PW+1 rows) can
+// reach: 1 for W <= 62 (X ring of 4 slots + 2 mirrors, 3 dY stages), 2 for W <= 126 (ring of 8 + 4 mirrors, 4 dY
+// stages in both: compute stage t then keeps X stages t .. t+4 resident while X(t+5) is in flight).
+template <int LEADS>
+struct Ring {
+  static constexpr int XR = LEADS == 1 ? 4 : 8;       // ring slots
+  static constexpr int MIRR = LEADS == 1 ? 2 : 4;     // slots mirrored behind the ring (contiguous windows at the wrap)
+  static constexpr int XSLOTS = XR + MIRR;
+  static constexpr int DYRING = 3;
+};
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
   short4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(p0));
@@ -62,12 +71,13 @@ struct Geo {  // padded flat-K geometry (host-computed)
   long kbeg0, kend;
 };
 
-template <int TAPS>
+template <int TAPS, int LEADS = 1>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad2(const bf16* __restrict__ X, const bf16* __restrict__ dY,
                                                           float* __restrict__ slabs, const bf16* __restrict__ zeros,
                                                           int B, int H, int W, int Cin, int Cout, int tiles_ci, long L,
                                                           Geo g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int XR = Ring<LEADS>::XR, MIRR = Ring<LEADS>::MIRR, XSLOTS = Ring<LEADS>::XSLOTS, DYRING = Ring<LEADS>::DYRING;
   char* dYb = smem;                          // [DYRING][2 sub][64 rows][64 B]
   char* Xb = smem + DYRING * 2 * SUBB;       // [2 sub][XSLOTS][64 rows][64 B]
   const int PW = g.PW, PH = g.PH;
@@ -86,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad2(const bf16* __restrict__
 
   // ---- per-lane decode state of the padded row this lane stages: row = base + 16*wave + (lane>>2)
   const int drow = lane >> 2, dp = lane & 3;
-  long kp = ks0 - KP + wave * 16 + drow;  // rows of X stage 0 (one stage of lead-in before the split)
+  long kp = ks0 - LEADS * KP + wave * 16 + drow;  // rows of X stage 0 (LEADS stages of lead-in before the split)
   int sw, sh, sn;                         // (w, h, n) of kp  [TAPS==9]
   if (TAPS == 9) {
     const long R = kp / PW;
@@ -121,13 +131,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad2(const bf16* __restrict__
   auto issue_x = [&](int j) {
     bool valid;
     const long pix = pixel(valid);
-    const int slot = j & 3;
+    const int slot = j & (XR - 1);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       const int ci = ci0 + sub * 32;
       const bf16* src = (valid && ci < Cin) ? X + pix * Cin + ci + dp * 8 : zeros;
       dma16(src, Xb + sub * (XSLOTS * SUBB) + slot * SUBB + wave * 1024);
-      if (TAPS == 9 && slot < 2) dma16(src, Xb + sub * (XSLOTS * SUBB) + (4 + slot) * SUBB + wave * 1024);
+      if (TAPS == 9 && slot < MIRR) dma16(src, Xb + sub * (XSLOTS * SUBB) + (XR + slot) * SUBB + wave * 1024);
     }
   };
   auto issue_dy = [&](int t) {
@@ -154,39 +164,55 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad2(const bf16* __restrict__
   const bool wave_active = (co0 + cb * 32 < Cout) && (ci0 + ib * 32 < Cin);
 
   if (nst > 0) {
-    // ---- prologue, issue order X(0) X(1) X(2) dY(0) dY(1): dY stage t shares its rows with X stage t+1
-    issue_x(0);
-    advance();
-    issue_x(1);
-    // remember the state of stage-1 rows for dY(0): re-derive by issuing dY(0) before advancing further is not
-    // possible (order!), so keep a copy of the decode state
-    const long kp1 = kp;
-    const int w1 = sw, h1 = sh, n1 = sn;
-    advance();
-    issue_x(2);
-    const long kp2 = kp;
-    const int w2 = sw, h2 = sh, n2 = sn;
-    kp = kp1; sw = w1; sh = h1; sn = n1;
+    // ---- prologue, issue order X(0) .. X(2*LEADS), dY(0), dY(1): dY stage t shares its rows with X stage t+LEADS,
+    // so the decode states of X stages LEADS and LEADS+1 are kept for the two dY issues (issue ORDER fixes the waits)
+    long kpa = 0, kpb = 0;
+    int wa = 0, ha = 0, na = 0, wb = 0, hb = 0, nb = 0;
+#pragma unroll
+    for (int j = 0; j <= 2 * LEADS; ++j) {
+      if (j > 0) advance();
+      if (j == LEADS) { kpa = kp; wa = sw; ha = sh; na = sn; }
+      if (j == LEADS + 1) { kpb = kp; wb = sw; hb = sh; nb = sn; }
+      issue_x(j);
+    }
+    const long kpl = kp;
+    const int wl = sw, hl = sh, nl = sn;
+    kp = kpa; sw = wa; sh = ha; sn = na;
     issue_dy(0);
-    kp = kp2; sw = w2; sh = h2; sn = n2;
-    if (nst > 1) issue_dy(1);
+    if (nst > 1) {
+      kp = kpb; sw = wb; sh = hb; sn = nb;
+      issue_dy(1);
+    }
+    kp = kpl; sw = wl; sh = hl; sn = nl;
   }
-
   for (int t = 0; t < nst; ++t) {
-    // ---- retire dY(t) and X(t+2); dY(t+1) (2 DMAs per wave, issued last) may stay in flight
+    // ---- retire dY(t) and X(t+2*LEADS); dY(t+1) (2 DMAs per wave, issued last) may stay in flight
     if (t + 1 < nst) wait_vmcnt<2>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    // ---- issue X(t+3) then dY(t+2): the same padded rows
-    if (t + 3 <= nst + 1) {
+    // ---- issue X(t+2*LEADS+1) then dY(t+2).  dY(t+2) has the rows of X(t+2+LEADS): the stage just issued when
+    // LEADS == 1, the one issued a stage earlier (= the state before this advance) when LEADS == 2.
+    if (t + 2 <= nst) {
+      const long kpp = kp;
+      const int wp = sw, hp = sh, np_ = sn;
       advance();
-      issue_x(t + 3);
-      if (t + 2 < nst) issue_dy(t + 2);
+      issue_x(t + 2 * LEADS + 1);
+      if (t + 2 < nst) {
+        if (LEADS == 2) {
+          const long kpn = kp;
+          const int wn = sw, hn = sh, nn = sn;
+          kp = kpp; sw = wp; sh = hp; sn = np_;
+          issue_dy(t + 2);
+          kp = kpn; sw = wn; sh = hn; sn = nn;
+        } else {
+          issue_dy(t + 2);
+        }
+      }
     }
     // ---- 36 (or 4) MFMAs over this stage
     if (TAPS == 9 && wave_active) {
-      const int slot = (t + 1) & 3;
-      const int base_row = (slot == 0 ? 4 : slot) * KP;
+      const int slot = (t + LEADS) & (XR - 1);                        // X stage t+LEADS is the centre of the window
+      const int base_row = (slot < LEADS ? slot + XR : slot) * KP;    // mirrored position when the window would wrap
       const unsigned a_u = (unsigned)(uintptr_t)(lds_char*)dYb + (t % DYRING) * (2 * SUBB) + cb * SUBB + krow_l * 64 + chan_b;
       const unsigned b_u = (unsigned)(uintptr_t)(lds_char*)Xb + ib * (XSLOTS * SUBB) + (base_row + krow_l) * 64 + chan_b;
       unsigned tb[9];
@@ -224,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad2(const bf16* __restrict__
 #undef MM3
     }
     if (TAPS != 9 && wave_active) {
-      const int slot = (t + 1) & 3;
+      const int slot = (t + LEADS) & (XR - 1);
       const int base_row = slot * KP;
       const char* abase = dYb + (t % DYRING) * (2 * SUBB) + cb * SUBB + krow_l * 64 + chan_b;
       const char* bbase = Xb + ib * (XSLOTS * SUBB) + (base_row + krow_l) * 64 + chan_b;
@@ -261,12 +287,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad2(const bf16* __restrict__
 
 bf16* g_zero_page_w = nullptr;
 
-Geo make_geo(int B, int H, int W, int taps) {
+Geo make_geo(int B, int H, int W, int taps, int leads) {
   Geo g;
   if (taps == 9) {
     g.PW = W + 1;
     g.PH = H + 1;
-    g.lead_rows = 2 + (KP + g.PW - 1) / g.PW;
+    g.lead_rows = 2 + (leads * KP + g.PW - 1) / g.PW;
     g.kmult = (g.lead_rows + g.PH - 1) / g.PH;
     g.kbeg0 = (long)(g.lead_rows - 1) * g.PW + 1;
     g.kend = ((long)g.lead_rows + (long)B * g.PH) * g.PW;
@@ -293,37 +319,28 @@ extern "C" int edm_conv_wgrad_v2(const void* X, const void* dY, float* slabs, in
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && (long)B * (H + 1) * (W + 1) < (1L << 30), "conv_wgrad_v2: bad B/H/W");
   EDM_REQUIRE(Cin > 0 && Cin % 32 == 0 && Cout > 0 && Cout % 32 == 0, "conv_wgrad_v2: Cin, Cout must be multiples of 32");
   EDM_REQUIRE(nsplit == edm_conv_wgrad_nsplit(B, H, W, Cin, Cout, taps), "conv_wgrad_v2: nsplit mismatch");
-  if (taps == 9 && W + 2 > KP) return EDM_ERR_UNSUPPORTED;
+  if (taps == 9 && W + 2 > 2 * KP) return EDM_ERR_UNSUPPORTED;
   if (!g_zero_page_w) {
     if (hipMalloc((void**)&g_zero_page_w, 256) != hipSuccess || hipMemset(g_zero_page_w, 0, 256) != hipSuccess) {
       edm_set_error("conv_wgrad_v2: cannot allocate the zero page");
       return EDM_ERR_LAUNCH;
     }
   }
-  const Geo g = make_geo(B, H, W, taps);
+  const int leads = (taps == 9 && W + 2 > KP) ? 2 : 1;   // 3x3 halo of PW+1 rows: within one 64-row stage, or two
+  const Geo g = make_geo(B, H, W, taps, leads);
   long L = (g.kend - g.kbeg0 + nsplit - 1) / nsplit;
   L = (L + KP - 1) / KP * KP;
   const int tiles_co = (Cout + 63) / 64, tiles_ci = (Cin + 63) / 64;
-  const size_t lds = (size_t)DYRING * 2 * SUBB + (size_t)2 * XSLOTS * SUBB;
-  if (taps == 9) {
-    auto kern = k_conv_wgrad2<9>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
+  auto launch = [&](auto kern, size_t lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(tiles_co * tiles_ci, nsplit), dim3(256), lds, st, (const bf16*)X, (const bf16*)dY,
                        slabs, (const bf16*)g_zero_page_w, B, H, W, Cin, Cout, tiles_ci, L, g);
-  } else {
-    auto kern = k_conv_wgrad2<1>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(tiles_co * tiles_ci, nsplit), dim3(256), lds, st, (const bf16*)X, (const bf16*)dY,
-                       slabs, (const bf16*)g_zero_page_w, B, H, W, Cin, Cout, tiles_ci, L, g);
-  }
+  };
+  const size_t lds1 = (size_t)Ring<1>::DYRING * 2 * SUBB + (size_t)2 * Ring<1>::XSLOTS * SUBB;
+  const size_t lds2 = (size_t)Ring<2>::DYRING * 2 * SUBB + (size_t)2 * Ring<2>::XSLOTS * SUBB;
+  if (taps == 1) launch(k_conv_wgrad2<1, 1>, lds1);
+  else if (leads == 1) launch(k_conv_wgrad2<9, 1>, lds1);
+  else launch(k_conv_wgrad2<9, 2>, lds2);
   EDM_CHECK_LAUNCH("conv_wgrad_v2");
   return EDM_OK;
 }

@@ -490,7 +490,7 @@ def conv_wgrad(x, dy, taps):
     with _prof("conv3x3_wgrad" if taps == 9 else "conv1x1_wgrad", 2.0 * npix * Cin * Cout * taps,
                2.0 * npix * (Cin + Cout) + 4.0 * slabs.numel()):
         # 3x3: LDS-DMA rolling-window kernel; 1x1: the register-staged kernel is (slightly) faster (r01 microbench)
-        fn = "edm_conv_wgrad_v2" if (WGRAD_VERSION == 2 and taps == 9 and W <= 62) else "edm_conv_wgrad"
+        fn = "edm_conv_wgrad_v2" if (WGRAD_VERSION == 2 and taps == 9 and W <= 126) else "edm_conv_wgrad"
         _lib.call(fn, _p(x), _p(dy), _p(slabs), B, H, W, Cin, Cout, taps, S, _stream())
     return slabs
 
