@@ -52,7 +52,7 @@ def pmc_traffic(kernel):
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as f:
             ks = json.load(f)["kernels"]
-        rec = ks.get(kernel + "<5, 0>") or ks.get(kernel)
+        rec = ks.get(kernel + "<5, 0, 4>") or ks.get(kernel + "<5, 0>") or ks.get(kernel)
         return None if rec is None else round(rec["hbm_gb_per_launch"], 4)
     except (OSError, ValueError, KeyError):
         return None
@@ -266,7 +266,7 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "conditional": bool(args.conditional), "final_loss": final_loss},
             "roofline": {
-                "bound": "mfma", "kernel": "k_conv3x3_v4<5,0> (3x3 implicit-GEMM conv of the 32x32 layers: forward, incl. fused modulation "
+                "bound": "mfma", "kernel": "k_conv3x3_v4<5,0,4> (3x3 implicit-GEMM conv of the 32x32 layers: forward, incl. fused modulation "
                                            "epilogue, and plain dgrad)",
                 "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,

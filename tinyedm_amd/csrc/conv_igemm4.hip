@@ -23,7 +23,8 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int BM = 512, BN = 128, KC = 32, TAPS = 9;
 constexpr int ROWB = KC * 2;      // 64-byte LDS rows
-constexpr int WTILE = BN * ROWB;  // 8 KiB weight tile
+// NI = 32-channel blocks per wave: 4 -> 512x128 workgroup tile (BN above); 2 -> 512x64, for layers too small to give
+// every CU a 512x128 tile (the 16x16 layers at batch 128: 64 pixel tiles x 2 channel tiles = 128 workgroups).
 constexpr int WRING = 6, D = WRING - 1;
 constexpr int ZERO_PAGE = 4096;
 
@@ -57,8 +58,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define LGKM_WAIT(n)                                       \
   asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory");  \
   __builtin_amdgcn_sched_barrier(0)
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
 
-template <int NX, int EPI = 0>
+template <int NX, int EPI = 0, int NI = 4>
 __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ X, const bf16* __restrict__ Wp,
                                                          bf16* __restrict__ Y, const bf16* __restrict__ R,
                                                          const char* __restrict__ zeros, float alpha, float beta,
@@ -66,6 +72,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
                                                          int tiles_n, ModEpilogue mod) {
   constexpr int XROWS = NX * 8 * 16;  // LDS rows per slab buffer; rows >= xrows are zero rows
   constexpr int XBYTES = XROWS * ROWB;
+  constexpr int BNW = 32 * NI;        // output channels per workgroup
+  constexpr int WTILE = BNW * ROWB;   // 8 KiB (NI = 4) or 4 KiB weight tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Xb = smem;
   char* const Wb = smem + 2 * XBYTES;
@@ -74,7 +82,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
   const int xcd = id & 7, k = id >> 3;
   const int tn = k % tiles_n, tm = (k / tiles_n) * 8 + xcd;
   if (tm >= tiles_m) return;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * BM, n0 = tn * BNW;
   const int HALO = W + 1;
   const int xrows = BM + 2 * HALO;  // < XROWS (host-checked): row XROWS-1 is always a zero row
 
@@ -85,9 +93,13 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
 
   // ---- DMA sources (per lane, computed once; they then advance by constants)
   // weight tile (chunk, tap): rows n0 + 16*wave + drow (clamped: rows >= Cout feed discarded outputs)
+  // NI = 2: the tile has 64 rows, every wave still issues ONE instruction per tile (uniform vmcnt) with its lower
+  // 32 lanes = 8 rows
+  constexpr int WROWS = NI == 4 ? 16 : 8;          // weight-tile rows per wave instruction
+  const bool w_lane = NI == 4 || lane < 32;
   const char* wsrc;
   {
-    const int row = wave * 16 + drow;
+    const int row = wave * WROWS + (drow & (WROWS - 1));
     const int co = min(n0 + row, Cout - 1);
     const int c = dp ^ ((row >> 2) & 3);
     wsrc = reinterpret_cast<const char*>(Wp + (long)co * Cin + c * 8);
@@ -130,9 +142,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
   const unsigned wb_off = (unsigned)(uintptr_t)(lds_char*)Wb;
   const unsigned ap[2] = {wb_off + l31 * ROWB + (((0 + lhi) ^ a_sw) << 4), wb_off + l31 * ROWB + (((2 + lhi) ^ a_sw) << 4)};
 
-  f32x16 acc[4][2];
+  f32x16 acc[NI][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -144,16 +156,17 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
 #pragma unroll
   for (int i = 0; i < NX; ++i) dma16(xsrc[i], Xb + (wave + 8 * i) * 1024);
 #pragma unroll
-  for (int d = 0; d < D; ++d) dma16(wsrc + d * tap_stride, Wb + d * WTILE + wave * 1024);
+  for (int d = 0; d < D; ++d)
+    if (w_lane) dma16(wsrc + d * tap_stride, Wb + d * WTILE + wave * (WROWS * ROWB));
 
   // Fragment pipeline: the 16 MFMAs of a step run as two halves (k-step 0 / k-step 1, 8 MFMAs each) and the 6 reads
   // of the NEXT half are in flight while the current half computes, so the LDS pipe and the matrix pipe overlap
   // inside one wave instead of alternating (all 8 waves of the group are barrier-aligned, so they would otherwise
   // all read, then all compute).  The barrier at the top of step u therefore retires tile u+1 as well as tile u.
-  u32x4 fa[2][4], fb[2][2];
+  u32x4 fa[2][NI], fb[2][2];
   auto mfma_half = [&](int set) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
       acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][i]),
                                                          __builtin_bit_cast(bf16x8, fb[set][0]), acc[i][0], 0, 0, 0);
       acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][i]),
@@ -171,8 +184,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
     LDS_RD128(fb[set][1], o1, (cpar) * XBYTES);                                           \
     LDS_RD128(fa[set][0], ap[ks], (slot) * WTILE + 0 * 32 * ROWB);                        \
     LDS_RD128(fa[set][1], ap[ks], (slot) * WTILE + 1 * 32 * ROWB);                        \
-    LDS_RD128(fa[set][2], ap[ks], (slot) * WTILE + 2 * 32 * ROWB);                        \
-    LDS_RD128(fa[set][3], ap[ks], (slot) * WTILE + 3 * 32 * ROWB);                        \
+    if constexpr (NI == 4) {                                                              \
+      LDS_RD128(fa[set][2], ap[ks], (slot) * WTILE + 2 * 32 * ROWB);                      \
+      LDS_RD128(fa[set][3], ap[ks], (slot) * WTILE + 3 * 32 * ROWB);                      \
+    }                                                                                     \
   }
 
   for (int chunk2 = 0; chunk2 < nchunks; chunk2 += 2) {
@@ -200,8 +215,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
         constexpr int tq = tap + D;                       // tap index of tile t+D, maybe in the next chunk
         constexpr int cq = cpar + (tq >= TAPS ? 1 : 0);   // chunk offset from chunk2 (0, 1 or 2)
         constexpr int tapq = tq >= TAPS ? tq - TAPS : tq;
-        if (chunk2 + cq < nchunks)
-          dma16(wsrc + (long)(chunk2 + cq) * (KC * 2) + tapq * tap_stride, Wb + ((u + D) % WRING) * WTILE + wave * 1024);
+        if (chunk2 + cq < nchunks && w_lane)
+          dma16(wsrc + (long)(chunk2 + cq) * (KC * 2) + tapq * tap_stride,
+                Wb + ((u + D) % WRING) * WTILE + wave * (WROWS * ROWB));
       }
       if (tap == 0 && more_chunks) {
 #pragma unroll
@@ -211,14 +227,14 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
       // ---- 2 x 8 MFMAs; all addresses = register + immediate
       if (u == 0 && chunk2 == 0) READ_HALF(0, 0, 0, 0, 0);  // pipeline fill (first step of the kernel only)
       READ_HALF(1, 1, tap, cpar, u % WRING);
-      LGKM_WAIT(6);
+      lgkm_wait<2 + NI>();
       mfma_half(0);
       __builtin_amdgcn_sched_barrier(0);
       if (more_chunks || tap + 1 < TAPS) {
         READ_HALF(0, 0, (tap + 1) % TAPS, (u + 1) / TAPS % 2, (u + 1) % WRING);
-        LGKM_WAIT(6);
+        lgkm_wait<2 + NI>();
       } else {
-        LGKM_WAIT(0);
+        lgkm_wait<0>();
       }
       mfma_half(1);
       __builtin_amdgcn_sched_barrier(0);
@@ -229,19 +245,19 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
   // ---- epilogue: transposed through wave-private LDS so that residual reads and stores are whole rows
   // (common.h: store_tile_transposed; direct stores from the MFMA layout cost 1.7x the HBM write bytes)
   __builtin_amdgcn_s_barrier();  // every wave is done with the slab / weight ring
-  store_tile_transposed<4, 2, EPI>(acc, smem + wave * (32 * (4 * 64 + 16)), Y, R, alpha, beta, (long)m0 + wave * 64, Npix,
-                                   n0, Cout, mod);
+  store_tile_transposed<NI, 2, EPI>(acc, smem + wave * (32 * (NI * 64 + 16)), Y, R, alpha, beta, (long)m0 + wave * 64, Npix,
+                                    n0, Cout, mod);
 }
 
 char* g_zero_page4 = nullptr;
 
-template <int NX, int EPI = 0>
+template <int NX, int EPI = 0, int NI = 4>
 void launch4(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int Npix, int H, int W,
              int Cin, int Cout, const ModEpilogue& mod, hipStream_t st) {
-  const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + BN - 1) / BN;
-  const size_t lds = (size_t)2 * NX * 8 * 16 * ROWB + WRING * WTILE;
+  const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + 32 * NI - 1) / (32 * NI);
+  const size_t lds = (size_t)2 * NX * 8 * 16 * ROWB + WRING * (32 * NI * ROWB);
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
-  auto kern = k_conv3x3_v4<NX, EPI>;
+  auto kern = k_conv3x3_v4<NX, EPI, NI>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -252,6 +268,12 @@ void launch4(const void* X, const void* Wp, void* Y, const void* R, float alpha,
 }
 
 }  // namespace
+
+// the static-schedule kernel pays off when it can give every CU a tile: >= 512 tiles of 512x128, or >= 256 of 512x64
+bool edm_conv_v4_worthwhile(long npix, int Cout) {
+  const long tm = (npix + BM - 1) / BM;
+  return tm * ((Cout + 127) / 128) >= 512 || tm * ((Cout + 63) / 64) >= 256;
+}
 
 // 3x3 only.  Same contract as edm_conv_igemm; returns EDM_ERR_UNSUPPORTED (-3) for shapes it does not cover
 // (taps != 9, Cin % 64 != 0, Cin > 2048, W > 64, fewer than 9*Cin/32 >= 18 tiles ...).
@@ -269,14 +291,18 @@ int edm_conv_igemm_v4_ex(const void* X, const void* Wp, void* Y, const void* R, 
   }
   const int Npix = B * H * W;
   const int xrows = BM + 2 * (W + 1);
-  if (mod.mode == 1) {  // backward epilogues: their own instantiations (keep the common kernels free of their registers)
-    if (xrows < 5 * 128) launch4<5, 1>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st);
-    else launch4<6, 1>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st);
-  } else if (mod.mode == 2) {
-    if (xrows < 5 * 128) launch4<5, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st);
-    else launch4<6, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st);
-  } else if (xrows < 5 * 128) launch4<5>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st);
-  else launch4<6>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st);
+  // 512x128 workgroup tiles when that still gives every CU two of them, else 512x64 (small feature maps)
+  const long tiles4 = (long)((Npix + BM - 1) / BM) * ((Cout + 127) / 128);
+  const bool wide = tiles4 >= 512;
+#define L4(NXV, EPIV)                                                                                   \
+  (wide ? launch4<NXV, EPIV, 4>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)               \
+        : launch4<NXV, EPIV, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st))
+  // backward epilogues: their own instantiations (keep the common kernels free of their registers)
+  const bool nx5 = xrows < 5 * 128;
+  if (mod.mode == 1) { if (nx5) L4(5, 1); else L4(6, 1); }
+  else if (mod.mode == 2) { if (nx5) L4(5, 2); else L4(6, 2); }
+  else { if (nx5) L4(5, 0); else L4(6, 0); }
+#undef L4
   EDM_CHECK_LAUNCH("conv_igemm_v4");
   return EDM_OK;
 }
@@ -302,8 +328,7 @@ extern "C" int edm_conv3x3_mod(const void* X, const void* Wp, void* Y, void* Y2,
               "conv3x3_mod: bad args");
   ModEpilogue mod{lin, gain, (bf16*)Y2, lin_stride, H * W, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), sub, step,
                   nullptr, nullptr, nullptr, 0.f, 0};
-  const long tiles3 = (((long)B * H * W + BM - 1) / BM) * ((Cout + BN - 1) / BN);
-  if (tiles3 >= 512) {
+  if (edm_conv_v4_worthwhile((long)B * H * W, Cout)) {
     const int rc = edm_conv_igemm_v4_ex(X, Wp, Y, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
     if (rc != EDM_ERR_UNSUPPORTED) return rc;
   }
@@ -326,8 +351,7 @@ extern "C" int edm_conv3x3_modbwd(const void* dY, const void* Wd, float alpha, c
   if ((H * W) % 32 != 0) return EDM_ERR_UNSUPPORTED;
   ModEpilogue mod{lin, gain, (bf16*)GR, lin_stride, H * W, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), sub, step,
                   (const bf16*)U, gm, nullptr, 0.f, 1};
-  const long tiles3 = (((long)B * H * W + BM - 1) / BM) * ((Cout + BN - 1) / BN);
-  if (tiles3 >= 512) {
+  if (edm_conv_v4_worthwhile((long)B * H * W, Cout)) {
     const int rc = edm_conv_igemm_v4_ex(dY, Wd, nullptr, nullptr, alpha, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
     if (rc != EDM_ERR_UNSUPPORTED) return rc;
   }
@@ -344,8 +368,7 @@ extern "C" int edm_conv3x3_silubwd(const void* dY, const void* Wd, const void* X
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0, "conv3x3_silubwd: bad args");
   ModEpilogue mod{nullptr, nullptr, (bf16*)GX, 0, H * W, 0.f, 0u, 0u, 0u, 0u, (const bf16*)Xpre, nullptr, (const bf16*)ADD,
                   add_scale, 2};
-  const long tiles3 = (((long)B * H * W + BM - 1) / BM) * ((Cout + BN - 1) / BN);
-  if (tiles3 >= 512) {
+  if (edm_conv_v4_worthwhile((long)B * H * W, Cout)) {
     const int rc = edm_conv_igemm_v4_ex(dY, Wd, nullptr, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
     if (rc != EDM_ERR_UNSUPPORTED) return rc;
   }

@@ -365,12 +365,23 @@ def _igemm_entry(npix, W, Cout, taps, Cin=0):
     # per-shape choice from the r01 microbenchmarks (tools/microbench_conv.py): the LDS-DMA tall-tile kernels only pay
     # off when they still give every CU >= 2 tiles; small feature maps keep the 128x128 register-staged kernel.
     if taps == 9:
-        tiles3 = ((npix + 511) // 512) * ((Cout + 127) // 128)
+        tm = (npix + 511) // 512
+        tiles3 = tm * ((Cout + 127) // 128)
+        v4_ok = Cin % 64 == 0 and Cin <= 2016 and W <= 64
         if tiles3 >= 512:
-            return "edm_conv_igemm_v4" if (Cin % 64 == 0 and Cin <= 2016 and W <= 64) else "edm_conv_igemm_v3"
+            return "edm_conv_igemm_v4" if v4_ok else "edm_conv_igemm_v3"
+        if v4_ok and tm * ((Cout + 63) // 64) >= 256:     # 512x64 tiles of the same kernel (16x16 layers at batch 128)
+            return "edm_conv_igemm_v4"
         return "edm_conv_igemm"
     tiles2 = ((npix + 255) // 256) * ((Cout + 127) // 128)
     return "edm_conv_igemm_v2" if tiles2 >= 1024 else "edm_conv_igemm"
+
+
+def _v4_suffix(entry, npix, Cout):
+    """profile-key suffix naming the kernel instantiation: _v4 = 512x128 tiles, _v4s = 512x64 tiles (small maps)"""
+    if entry != "edm_conv_igemm_v4":
+        return entry[len("edm_conv_igemm"):]
+    return "_v4" if ((npix + 511) // 512) * ((Cout + 127) // 128) >= 512 else "_v4s"
 
 
 def conv_igemm(x, wp, taps, residual=None, alpha=1.0, beta=0.0):
@@ -386,7 +397,7 @@ def conv_igemm(x, wp, taps, residual=None, alpha=1.0, beta=0.0):
     npix = B * H * W
     entry = _igemm_entry(npix, W, Cout, taps, Cin)
     # profile key names the kernel generation that runs ("conv3x3_igemm_v4", "conv1x1_igemm", ...)
-    pname = ("conv3x3_igemm" if taps == 9 else "conv1x1_igemm") + entry[len("edm_conv_igemm"):]
+    pname = ("conv3x3_igemm" if taps == 9 else "conv1x1_igemm") + _v4_suffix(entry, npix, Cout)
     with _prof(pname, 2.0 * npix * Cin * Cout * taps,
                2.0 * (npix * (Cin + Cout * (2 if residual is not None else 1)) + wp.numel())):
         _lib.call(entry, _p(x), _p(wp), _p(y), _p(residual), float(alpha), float(beta), B, H, W, Cin, Cout, taps, _stream())
@@ -410,7 +421,7 @@ def conv3x3_mod(x, wp, lin, gain, pdrop, seed, sub, step, want_u=True):
     a2 = torch.empty(B, H, W, Cout, device=x.device, dtype=bf16)
     npix = B * H * W
     entry = _igemm_entry(npix, W, Cout, 9, Cin)
-    pname = "conv3x3_igemm" + ("_v4" if entry == "edm_conv_igemm_v4" else "")
+    pname = "conv3x3_igemm" + (_v4_suffix(entry, npix, Cout) if entry == "edm_conv_igemm_v4" else "")
     with _prof(pname, 2.0 * npix * Cin * Cout * 9, 2.0 * (npix * (Cin + Cout * (2 if want_u else 1)) + wp.numel())):
         _lib.call("edm_conv3x3_mod", _p(x), _p(wp), _p(u), _p(a2), _p(lin), ls, _p(gain), float(pdrop), int(seed),
                   int(sub), int(step), B, H, W, Cin, Cout, _stream())
@@ -437,7 +448,7 @@ def conv3x3_modbwd(gout, wd, alpha, r1, lin, gain, pdrop, seed, sub, step, glin_
     ggain = zeros_f32((), r1.device) if ggain_out is None else _chk(ggain_out, f32, "ggain_out", ())
     npix = B * H * W
     entry = _igemm_entry(npix, W, Cout, 9, Cin)
-    pname = "conv3x3_igemm" + ("_v4" if entry == "edm_conv_igemm_v4" else "") + "_modbwd"   # own kernel instantiation
+    pname = "conv3x3_igemm" + (_v4_suffix(entry, npix, Cout) if entry == "edm_conv_igemm_v4" else "") + "_modbwd"
     with _prof(pname, 2.0 * npix * Cin * Cout * 9, 2.0 * (npix * (Cin + 2 * Cout) + wd.numel())):
         _lib.call("edm_conv3x3_modbwd", _p(gout), _p(wd), float(alpha), _p(r1), _p(lin), ls, _p(gain), _p(gr), _p(gm),
                   float(pdrop), int(seed), int(sub), int(step), B, H, W, Cin, Cout, _stream())
@@ -459,7 +470,7 @@ def conv3x3_silubwd(g, wd, xpre, gextra=None, extra_scale=1.0):
     gx = torch.empty_like(xpre)
     npix = B * H * W
     entry = _igemm_entry(npix, W, Cout, 9, Cin)
-    pname = "conv3x3_igemm" + ("_v4" if entry == "edm_conv_igemm_v4" else "") + "_silubwd"  # own kernel instantiation
+    pname = "conv3x3_igemm" + (_v4_suffix(entry, npix, Cout) if entry == "edm_conv_igemm_v4" else "") + "_silubwd"
     with _prof(pname, 2.0 * npix * Cin * Cout * 9,
                2.0 * (npix * (Cin + Cout * (3 if gextra is not None else 2)) + wd.numel())):
         _lib.call("edm_conv3x3_silubwd", _p(g), _p(wd), _p(xpre), _p(gextra), float(extra_scale), _p(gx), B, H, W, Cin,
