@@ -152,7 +152,7 @@ class Trainer:
                     if self.scheduler_interval == "step":
                         self.lr_scheduler.step()
                     if self.global_rank == 0 and self.global_step % self.log_every_n_steps == 0:
-                        print(f"[fit] epoch {epoch} step {self.global_step} loss {float(loss):.4f} "
+                        print(f"[fit] epoch {epoch} step {self.global_step} loss {float(loss.detach()):.4f} "
                               f"{imgs / (time.time() - t0):.1f} img/s", flush=True)
                     if 0 < self.max_steps <= self.global_step:
                         done = True
