@@ -324,3 +324,14 @@ def test_three_optimizer_steps_track_the_oracle(tiny):
     e_h = torch.cat([ema_h[k].detach().cpu().flatten() for k in ema_h if ema_h[k].numel() > 1 and k in ema])
     e_o = torch.cat([ema[k].flatten() for k in ema_h if ema_h[k].numel() > 1 and k in ema])
     assert rel(e_h, e_o) <= 2e-3
+
+
+def test_training_actually_learns_a_toy_distribution():
+    """200 optimizer steps of the full HIP path (Philox Diffuser, dropout off, fused Adam+EMA, LR ramp) on ten smooth
+    class patterns: the sigma-weighted loss starts near 1 (gain_out = 0) and must fall well below it."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from learn_check import run
+    ls = run(steps=200)
+    first, last = sum(ls[:20]) / 20, sum(ls[-20:]) / 20
+    assert all(np.isfinite(ls)) and last < 0.35 * first, (first, last)
