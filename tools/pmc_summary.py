@@ -10,7 +10,7 @@ agg = collections.OrderedDict()
 for r in rows:
     if flt not in r["Kernel_Name"]:
         continue
-    name = r["Kernel_Name"].split("(")[0].replace("void (anonymous namespace)::", "")
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     k = (name, r["Grid_Size"], r["Dispatch_Id"])
     agg.setdefault(k, {})[r["Counter_Name"]] = float(r["Counter_Value"])
     agg[k]["_dur"] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
