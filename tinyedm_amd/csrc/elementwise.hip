@@ -823,7 +823,7 @@ extern "C" int edm_conv_out_bwd(const void* x, const float* w_hat, const float* 
     EDM_REQUIRE(CL <= 256, "conv_out_bwd: C=%d too large", C);
     int block = (256 / CL) * CL, PS = block / CL;
     while (PS > 1 && (size_t)PS * Co * C * sizeof(float) > 48 * 1024) { --PS; block = PS * CL; }
-    const int PIXW = 1024;
+    const int PIXW = 256;   // r01 sweep at the CIFAR-10 size (us): 1024 -> 167, 512 -> 93, 256 -> 72, 128 -> 80, 32 -> 841
     hipLaunchKernelGGL(k_conv_out_bwd_w, dim3(cdiv(npix, PIXW)), dim3(block), (size_t)PS * Co * C * sizeof(float), st,
                        (const bf16*)x, dD, Fraw, gain_out, sigma, sigma_stride, sigma_data, gw_hat, ggain, HW, C, Co,
                        npix, PIXW);
