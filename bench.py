@@ -224,7 +224,7 @@ def main():
     ap.add_argument("--no-sampler", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=20, help="timed CPU-oracle steps (~0.5 s each on 16 threads)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
