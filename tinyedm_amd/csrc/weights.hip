@@ -288,6 +288,32 @@ __global__ __launch_bounds__(1024) void k_wgrad_finish(const float* __restrict__
   const long slab_stride = (long)taps * O * Ipad;
   if ((I & 3) == 0 && (Ipad & 3) == 0) {
     const int I4 = I >> 2, E4 = taps * I4;
+    if (S <= 3) {
+      // few slabs, long rows (the wide layers of the ImageNet nets: one work item per pass would have a single load
+      // in flight): four vectors per thread per trip, all their loads issued together
+      const int items = E4;  // G == 1 here (host: 2G <= S fails for S <= 1; S in 2..3 gives G <= 1 when E4 >= 512)
+      for (int idx0 = threadIdx.x; idx0 < items * G; idx0 += 4 * blockDim.x) {
+        f32x4 acc4[4];
+        int e4s[4], sgs[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = idx0 + u * blockDim.x;
+          const bool ok = idx < items * G;
+          const int sg = ok ? idx / E4 : 0, e4 = ok ? idx - sg * E4 : 0;
+          e4s[u] = ok ? e4 : -1;
+          sgs[u] = sg;
+          const int t = e4 / I4, i = (e4 - t * I4) * 4;
+          const float* sp = slabs + ((long)t * O + r) * Ipad + i;
+          f32x4 a = {0.f, 0.f, 0.f, 0.f};
+          if (ok)
+            for (int sl = sg; sl < S; sl += G) a += *reinterpret_cast<const f32x4*>(sp + (long)sl * slab_stride);
+          acc4[u] = a;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (e4s[u] >= 0) *reinterpret_cast<f32x4*>(part + (long)sgs[u] * n + e4s[u] * 4) = acc4[u];
+      }
+    } else
     for (int idx = threadIdx.x; idx < E4 * G; idx += blockDim.x) {
       const int sg = idx / E4, e4 = idx - sg * E4;
       const int t = e4 / I4, i = (e4 - t * I4) * 4;
