@@ -3,8 +3,10 @@
  * The reference (YichengDWu/tinyedm) has no native code: every entry point below replaces an ATen op
  * call site of its Python hot path (cited as file:line relative to /root/reference/src/tinyedm) or the
  * autograd backward of one.  Conventions:
- *   - plain pointers + sizes only; every pointer is DEVICE memory owned by the caller; no allocation,
- *     no host sync; work is enqueued on `stream` (graph-capturable).
+ *   - plain pointers + sizes only; every pointer is DEVICE memory owned by the caller (the one exception,
+ *     edm_wgrad3_group's descriptor array, is HOST memory read during the call); compute entry points do no
+ *     allocation and no host sync: work is enqueued on `stream` and is graph-capturable from the first call.
+ *     The only allocating call is edm_init(device), made once per device before anything else.
  *   - activations: NHWC bf16, i.e. a row-major [pixels = B*H*W][channels] matrix of 16-bit brain floats.
  *   - per-(sample,channel) / parameter-side quantities: fp32.
  *   - return 0 on success, <0 on error (edm_last_error() holds the message, thread-local).
@@ -19,6 +21,18 @@ typedef struct ihipStream_t* edm_stream_t; /* hipStream_t */
 
 int edm_version(void);
 const char* edm_last_error(void);
+/* per-device constants (a 4 KiB page of zeros the LDS-DMA kernels point padding rows at): allocate once per device,
+ * outside any stream capture; idempotent and thread-safe.  Every kernel that needs the page fails with -1 until then. */
+int edm_init(int device);
+/* Per-step scalars of a hipGraph-captured training step.  By-value arguments are frozen into a graph at capture time;
+ * entry points with a `dyn` parameter read these fields from DEVICE memory instead when dyn != NULL, so the host can
+ * rewrite the 48-byte record (one small async copy) before every replay: step/seed feed the Philox streams of dropout
+ * and the Diffuser (reference: torch RNG state advancing between steps), lr comes from the LambdaLR schedule
+ * (edm.py:305-320), ema_beta from ema.py:137-140, bc1 = 1-b1^t and bc2sqrt = sqrt(1-b2^t) are Adam's bias corrections. */
+typedef struct {
+  unsigned step, seed_lo, seed_hi, reserved;
+  float lr, ema_beta, grad_scale, bc1, bc2sqrt, pad[3];
+} edm_step_params;
 
 /* ---------------------------------------------------------------- convolution (networks.py:35-37: F.conv2d) */
 /* Y[p,co] = alpha * sum_{tap,ci} X[p+off(tap),ci] * Wp[tap,co,ci] + beta * R[p,co].  taps in {1,9}; "same" padding.
@@ -36,27 +50,18 @@ int edm_conv_igemm_v3(const void* X, const void* Wp, void* Y, const void* R, flo
  * masks folded into addresses, incremental DMA pointers); -3 for shapes it does not cover (taps != 9, Cin % 64 != 0) */
 int edm_conv_igemm_v4(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
                       int W, int Cin, int Cout, int taps, edm_stream_t stream);
-/* diagnostic (tools/ only): in-kernel shader clock of the v3 kernel (dbg[0] cycles, dbg[1] 100 MHz ticks, dbg[2] WGs) */
-int edm_conv_igemm_v3_clock(const void* X, const void* Wp, void* Y, int B, int H, int W, int Cin, int Cout,
-                            unsigned long long* dbg, edm_stream_t stream);
-/* diagnostic (tools/ only): s_memtime stamps per loop segment of the v2 kernel, summed over waves into dbg[0..5] */
-int edm_conv_igemm_v2_stamp(const void* X, const void* Wp, void* Y, int B, int H, int W, int Cin, int Cout,
-                            unsigned long long* dbg, edm_stream_t stream);
-/* diagnostic (tools/ only): timing-only ablations of the v2 kernel (bit0 no MFMA, bit1 no DMA, bit2 no reads, bit3 no barrier) */
-int edm_conv_igemm_v2_ablate(const void* X, const void* Wp, void* Y, int B, int H, int W, int Cin, int Cout, int mode,
-                             edm_stream_t stream);
 /* first 3x3 conv of a block with the embedding modulation fused into its epilogue (networks.py:253-260 / 317-324):
  * Y = conv3x3(X) (bf16, may be NULL in eval), Y2 = dropout(mp_silu(Y * (lin[b,:]*gain + 1))) -- bit-identical to
  * edm_mod_silu_drop_fwd applied to Y (same Philox counters), so edm_mod_silu_drop_bwd serves as its backward. */
 int edm_conv3x3_mod(const void* X, const void* Wp, void* Y, void* Y2, const float* lin, long lin_stride,
                     const float* gain, float pdrop, unsigned long long seed, unsigned sub, unsigned step, int B, int H,
-                    int W, int Cin, int Cout, edm_stream_t stream);
+                    int W, int Cin, int Cout, const void* dyn, edm_stream_t stream);
 /* backward counterpart: dgrad of the block's second 3x3 conv (ga = alpha*conv3x3(dY, Wd), never written) with the
  * modulation backward in the epilogue: GR = ga*keep*mp_silu'(u*m)*m, gm[b,c] += sum_px ga*keep*mp_silu'(u*m)*u (gm
  * zero-filled [B][Cout] fp32); finish with edm_mod_finish.  -3 when H*W % 32 != 0 (use the separate kernels). */
 int edm_conv3x3_modbwd(const void* dY, const void* Wd, float alpha, const void* U, const float* lin, long lin_stride,
                        const float* gain, void* GR, float* gm, float pdrop, unsigned long long seed, unsigned sub,
-                       unsigned step, int B, int H, int W, int Cin, int Cout, edm_stream_t stream);
+                       unsigned step, int B, int H, int W, int Cin, int Cout, const void* dyn, edm_stream_t stream);
 /* dgrad of a block's first 3x3 conv with the mp_silu backward of the block input in its epilogue
  * (g = conv3x3(dY, Wd) never written): GX = mp_silu'(Xpre)*g + add_scale*ADD (ADD may be NULL). */
 int edm_conv3x3_silubwd(const void* dY, const void* Wd, const void* Xpre, const void* ADD, float add_scale, void* GX,
@@ -75,6 +80,24 @@ int edm_conv_wgrad_v2(const void* X, const void* dY, float* slabs, int B, int H,
 int edm_conv_wgrad_1x1_nsplit(long npix, int Cin, int Cout);
 int edm_conv_wgrad_1x1(const void* X, const void* dY, float* slabs, long npix, int Cin, int Cout, int nsplit,
                        edm_stream_t stream);
+/* third generation, 3x3 layers, a GROUP of layers per call (autograd wgrad of networks.py:35-37 + the projection of
+ * networks.py:32-36's normalisation): the reduction dimension of all layers is laid end to end and cut into equal
+ * ranges, one per workgroup (128x64x9 tile, one wave per SIMD); partial tiles go to `workspace`; a second launch sums
+ * each weight row's partials, projects through w_hat = w/(eps + |w|/sqrt(n))/sqrt(n) and writes (accumulate=0) or
+ * accumulates (1) grad.  `items` is a HOST array read during the call; <= 16 layers, all with W <= 62 or all with
+ * 62 < W <= 126; Cin, Cout % 32 == 0.  workspace >= edm_wgrad3_workspace(items, n) bytes (-1 on bad arguments). */
+typedef struct {
+  const void* X;    /* bf16 [B*H*W][Cin]  layer input */
+  const void* dY;   /* bf16 [B*H*W][Cout] gradient of the layer output */
+  const float* w;   /* fp32 master weight [Cout][I][3][3] */
+  float* grad;      /* fp32 gradient of w, same layout */
+  const int* perm;  /* packed output row -> master row, or NULL */
+  int B, H, W, Cin, Cout, I; /* I <= Cin: input channels of w (X may be zero-padded to Cin) */
+  float scale;      /* gradient scale folded in before the projection */
+  int accumulate;
+} edm_wgrad3_item;
+long edm_wgrad3_workspace(const edm_wgrad3_item* items, int n);
+int edm_wgrad3_group(const edm_wgrad3_item* items, int n, void* workspace, long workspace_bytes, edm_stream_t stream);
 
 /* ---------------------------------------------------------------- weights (networks.py:17-19, 32-36, 55-59) */
 /* forced weight normalisation (in place when normalize_inplace) + effective weight w/(eps+|w|/sqrt(n))/sqrt(n),
@@ -110,10 +133,11 @@ int edm_silu_bwd(const void* x, const void* ga, const void* gextra, float extra_
 int edm_axpby(const void* a, float alpha, const void* b, float beta, void* out, long n, edm_stream_t stream);
 /* a = dropout(mp_silu(r * (lin*gain + 1)))  (networks.py:255-260 / 319-324); Philox mask from (seed, sub, step) */
 int edm_mod_silu_drop_fwd(const void* r, const float* lin, long lin_stride, const float* gain, void* a, int B, int HW,
-                          int C, float pdrop, unsigned long long seed, unsigned sub, unsigned step, edm_stream_t stream);
+                          int C, float pdrop, unsigned long long seed, unsigned sub, unsigned step, const void* dyn,
+                          edm_stream_t stream);
 int edm_mod_silu_drop_bwd(const void* r, const float* lin, long lin_stride, const float* gain, const void* ga, void* gr,
                           float* gm, float* glin, long glin_stride, float* ggain, int B, int HW, int C, float pdrop,
-                          unsigned long long seed, unsigned sub, unsigned step, edm_stream_t stream);
+                          unsigned long long seed, unsigned sub, unsigned step, const void* dyn, edm_stream_t stream);
 int edm_dropout_mask(unsigned char* mask, long n, float pdrop, unsigned long long seed, unsigned sub, unsigned step,
                      edm_stream_t stream);
 /* 2x2 average pool / nearest-exact x2 (networks.py:80, 72); H,W = OUTPUT dims; scale folds the backward factors */
@@ -163,13 +187,18 @@ int edm_embed_combine_bwd(const float* gout, const float* pre, const long long* 
 
 /* ---------------------------------------------------------------- step level (edm.py:84-93, 212; metric.py:8-18; edm.py:251; ema.py:137-140; solvers.py:49-57) */
 int edm_diffuse(const float* clean, float* noisy, float* sigma, float P_mean, float P_std, int B, long CHW,
-                unsigned long long seed, unsigned step, edm_stream_t stream);
+                unsigned long long seed, unsigned step, const void* dyn, edm_stream_t stream);
 int edm_diffuse_given(const float* clean, const float* eps, const float* noise, float* noisy, float* sigma,
                       float P_mean, float P_std, int B, long CHW, edm_stream_t stream);
+/* weight = (sigma^2+sd^2)/(sigma*sd)^2 (edm.py:212) unless weight_override; acc_sum/acc_total (nullable): the metric's
+ * epoch state (metric.py:38-49) accumulated in the same pass */
 int edm_weighted_mse(const float* D, const float* clean, const float* sigma, const float* weight_override,
-                     float sigma_data, float* loss, float* dD, int B, long CHW, edm_stream_t stream);
-int edm_adam_ema(float* theta, const float* grad, float* m, float* v, float* ema, long n, float lr, float b1,
-                 float b2, float eps, int step, float ema_beta, float grad_scale, edm_stream_t stream);
+                     float sigma_data, float* loss, float* dD, int B, long CHW, float* acc_sum, long long* acc_total,
+                     edm_stream_t stream);
+/* zero_grad != 0: the gradient arena is cleared in the same pass (optimizer.zero_grad()) */
+int edm_adam_ema(float* theta, float* grad, float* m, float* v, float* ema, long n, float lr, float b1, float b2,
+                 float eps, int step, float ema_beta, float grad_scale, const void* dyn, int zero_grad,
+                 edm_stream_t stream);
 int edm_heun_euler(const float* x, const float* D, float t0, float t1, float* dx, float* x1, long n,
                    edm_stream_t stream);
 int edm_heun_correct(const float* x, const float* dx, const float* x1, const float* D1, float t0, float t1, float* out,

@@ -8,6 +8,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+TESTS = os.path.join(ROOT, "tests")
+if TESTS not in sys.path:
+    sys.path.insert(0, TESTS)
 
 
 def pytest_configure(config):
@@ -17,3 +20,8 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionfinish(session, exitstatus):
+    import parity_log
+    parity_log.dump()

@@ -1,0 +1,31 @@
+"""Collects the parity error every GPU test measured (test -> worst rel-L2, its limit) so the margins are visible:
+written at session end to gpurun_out/parity_r02.json (copied into profiles/ for the record)."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_records = {}
+
+
+def record(name: str, err: float, limit: float) -> None:
+    prev = _records.get(name)
+    if prev is None or err > prev["err"]:
+        _records[name] = {"err": float(err), "limit": float(limit), "margin": float(limit) / max(float(err), 1e-30)}
+
+
+def dump() -> None:
+    if not _records:
+        return
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, "parity_r02.json")
+        old = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                old = json.load(f)
+        old.update(_records)
+        with open(path, "w") as f:
+            json.dump(dict(sorted(old.items())), f, indent=1)
+    except OSError:
+        pass

@@ -16,14 +16,16 @@ U, U64 = ctypes.c_uint, ctypes.c_ulonglong
 SIGNATURES = {
     "edm_version": [],
     "edm_last_error": [],
+    # runtime.hip
+    "edm_init": [I],
     # elementwise.hip
     "edm_pixelnorm_silu_fwd": [P, P, P, P, L, I, P],
     "edm_pixelnorm_silu_bwd": [P, P, P, F, P, P, L, I, P],
     "edm_silu_fwd": [P, P, L, P],
     "edm_silu_bwd": [P, P, P, F, P, L, P],
     "edm_axpby": [P, F, P, F, P, L, P],
-    "edm_mod_silu_drop_fwd": [P, P, L, P, P, I, I, I, F, U64, U, U, P],
-    "edm_mod_silu_drop_bwd": [P, P, L, P, P, P, P, P, L, P, I, I, I, F, U64, U, U, P],
+    "edm_mod_silu_drop_fwd": [P, P, L, P, P, I, I, I, F, U64, U, U, P, P],
+    "edm_mod_silu_drop_bwd": [P, P, L, P, P, P, P, P, L, P, I, I, I, F, U64, U, U, P, P],
     "edm_dropout_mask": [P, L, F, U64, U, U, P],
     "edm_pool2": [P, P, I, I, I, I, F, P],
     "edm_up2": [P, P, I, I, I, I, F, P],
@@ -42,18 +44,18 @@ SIGNATURES = {
     "edm_conv_igemm_v2": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_v3": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_v4": [P, P, P, P, F, F, I, I, I, I, I, I, P],
-    "edm_conv3x3_mod": [P, P, P, P, P, L, P, F, U64, U, U, I, I, I, I, I, P],
-    "edm_conv3x3_modbwd": [P, P, F, P, P, L, P, P, P, F, U64, U, U, I, I, I, I, I, P],
+    "edm_conv3x3_mod": [P, P, P, P, P, L, P, F, U64, U, U, I, I, I, I, I, P, P],
+    "edm_conv3x3_modbwd": [P, P, F, P, P, L, P, P, P, F, U64, U, U, I, I, I, I, I, P, P],
     "edm_conv3x3_silubwd": [P, P, P, P, F, P, I, I, I, I, I, P],
     "edm_mod_finish": [P, P, L, P, P, L, P, I, I, P],
-    "edm_conv_igemm_v3_clock": [P, P, P, I, I, I, I, I, P, P],
-    "edm_conv_igemm_v2_stamp": [P, P, P, I, I, I, I, I, P, P],
-    "edm_conv_igemm_v2_ablate": [P, P, P, I, I, I, I, I, I, P],
     "edm_conv_wgrad_nsplit": [I, I, I, I, I, I],
     "edm_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, P],
     "edm_conv_wgrad_v2": [P, P, P, I, I, I, I, I, I, I, P],
     "edm_conv_wgrad_1x1_nsplit": [L, I, I],
     "edm_conv_wgrad_1x1": [P, P, P, L, I, I, I, P],
+    # conv_wgrad3.hip (items = host array of WGrad3Item)
+    "edm_wgrad3_workspace": [P, I],
+    "edm_wgrad3_group": [P, I, P, L, P],
     # attention.hip
     "edm_attention_fwd": [P, P, I, I, I, I, P],
     "edm_attention_bwd": [P, P, P, P, I, I, I, I, P],
@@ -65,10 +67,10 @@ SIGNATURES = {
     "edm_embed_combine_fwd": [P, P, P, F, I, P, P, I, I, P],
     "edm_embed_combine_bwd": [P, P, P, F, I, P, P, I, I, P],
     # optim.hip
-    "edm_diffuse": [P, P, P, F, F, I, L, U64, U, P],
+    "edm_diffuse": [P, P, P, F, F, I, L, U64, U, P, P],
     "edm_diffuse_given": [P, P, P, P, P, F, F, I, L, P],
-    "edm_weighted_mse": [P, P, P, P, F, P, P, I, L, P],
-    "edm_adam_ema": [P, P, P, P, P, L, F, F, F, F, I, F, F, P],
+    "edm_weighted_mse": [P, P, P, P, F, P, P, I, L, P, P, P],
+    "edm_adam_ema": [P, P, P, P, P, L, F, F, F, F, I, F, F, P, I, P],
     "edm_heun_euler": [P, P, F, F, P, P, L, P],
     "edm_heun_correct": [P, P, P, P, F, F, P, L, P],
     "edm_scale_f32": [P, F, P, L, P],
@@ -81,14 +83,26 @@ SIGNATURES = {
     "edm_denormalize_u8": [P, P, L, F, F, P],
     "edm_prediction_to_u8_nhwc": [P, P, I, I, I, I, P, P, P],
 }
-_RET = {"edm_last_error": ctypes.c_char_p}
-_NO_STATUS = {"edm_version", "edm_last_error", "edm_conv_wgrad_nsplit", "edm_conv_wgrad_1x1_nsplit"}
+# include/tinyedm_hip_diag.h: tools-only entry points, bound on demand by call()
+DIAG_SIGNATURES = {
+    "edm_conv_igemm_v3_clock": [P, P, P, I, I, I, I, I, P, P],
+    "edm_conv_igemm_v2_stamp": [P, P, P, I, I, I, I, I, P, P],
+    "edm_conv_igemm_v2_ablate": [P, P, P, I, I, I, I, I, I, P],
+}
+_RET = {"edm_last_error": ctypes.c_char_p, "edm_wgrad3_workspace": ctypes.c_long}
+_NO_STATUS = {"edm_version", "edm_last_error", "edm_conv_wgrad_nsplit", "edm_conv_wgrad_1x1_nsplit", "edm_wgrad3_workspace"}
 
 _lib = None
 
 
 class HipKernelError(RuntimeError):
     pass
+
+
+class WGrad3Item(ctypes.Structure):
+    """edm_wgrad3_item (include/tinyedm_hip.h): one 3x3 layer of a grouped weight-gradient launch."""
+    _fields_ = [("X", P), ("dY", P), ("w", P), ("grad", P), ("perm", P), ("B", I), ("H", I), ("W", I), ("Cin", I),
+                ("Cout", I), ("I", I), ("scale", F), ("accumulate", I)]
 
 
 def lib() -> ctypes.CDLL:
@@ -100,7 +114,7 @@ def lib() -> ctypes.CDLL:
                 f"tinyedm_amd: {LIB_PATH} is missing -- build it with `python -m tinyedm_amd.build` "
                 "(there is no CPU fallback for the HIP hot path)")
         h = ctypes.CDLL(LIB_PATH)
-        for name, args in SIGNATURES.items():
+        for name, args in {**SIGNATURES, **DIAG_SIGNATURES}.items():
             fn = getattr(h, name)  # AttributeError here = header/library out of sync
             fn.argtypes = args
             fn.restype = _RET.get(name, ctypes.c_int)
@@ -118,3 +132,14 @@ def call(name: str, *args):
         msg = h.edm_last_error()
         raise HipKernelError(f"{name} failed (status {rc}): {msg.decode() if msg else '?'}")
     return rc
+
+
+_inited_devices = set()
+
+
+def init_device(index: int) -> None:
+    """edm_init(device) once per device: allocates the library's per-device constants (the zero page) outside any
+    launch function, so that every compute entry point is allocation-free and capturable from its first call."""
+    if index not in _inited_devices:
+        call("edm_init", int(index))
+        _inited_devices.add(index)

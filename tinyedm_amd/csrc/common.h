@@ -18,6 +18,11 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define EDM_ERR_UNSUPPORTED (-3)
 
 extern "C" void edm_set_error(const char* fmt, ...);
+// per-device page of zeros (runtime.hip): allocated by edm_init(device), never inside a launch function
+extern "C" const void* edm_zero_page(void);
+#define EDM_ZERO_PAGE(var, name)          \
+  const void* var = edm_zero_page();      \
+  EDM_REQUIRE(var, name ": edm_init(device) has not been called for the current device")
 
 #define EDM_REQUIRE(cond, ...)            \
   do {                                    \
@@ -100,6 +105,14 @@ __device__ __forceinline__ bool keep_elem(uint32_t r, float p) { return u32_to_u
 // Backward form (U != nullptr): the kernel is the dgrad of the block's SECOND conv, its bf16 result ga is consumed in
 // the epilogue instead of being written: Y2 = gr = ga*keep*mp_silu'(u*m)*m and gm[b,c] += sum_px ga*keep*silu'(u*m)*u
 // (same arithmetic as k_mod_silu_drop_bwd; needs HW % 32 == 0 so that a 32-pixel block never straddles images).
+// Per-step scalars of a captured training step.  A by-value kernel argument is frozen into a hipGraph at capture
+// time; the values below change on every step, so the host rewrites this 48-byte DEVICE record before each (re)play
+// and kernels given a non-null `dyn` pointer read step/seed (Philox streams of dropout and the Diffuser) or
+// lr / ema_beta / grad_scale / bias corrections (fused Adam) from it instead of from their by-value arguments.
+struct StepParams {  // mirrored by include/tinyedm_hip.h (edm_step_params) and tinyedm_amd/graph.py
+  uint32_t step, seed_lo, seed_hi, reserved;
+  float lr, ema_beta, grad_scale, bc1, bc2sqrt, pad[3];
+};
 struct ModEpilogue {
   const float* lin;   // [B][lin_stride] fp32 embed-linear output
   const float* gain;  // device scalar
@@ -113,7 +126,15 @@ struct ModEpilogue {
   const bf16* ADD;    // silu backward: optional extra gradient, Y2 = mp_silu'(U)*g + add_scale*ADD
   float add_scale;
   int mode;           // 0: none / forward modulation (Y2 set), 1: modulation backward, 2: mp_silu backward
+  const StepParams* dyn;  // non-null: step / seed of the Philox stream come from device memory (captured steps)
 };
+__device__ __forceinline__ void apply_dyn(ModEpilogue& m) {
+  if (m.dyn) {
+    m.step = m.dyn->step;
+    m.seed_lo = m.dyn->seed_lo;
+    m.seed_hi = m.dyn->seed_hi;
+  }
+}
 // mode 2 on 8 channels: gx = mp_silu'(x)*g + s*ge  (k_silu_bwd's arithmetic; g = the conv result rounded to bf16)
 __device__ __forceinline__ u32x4 silu_bwd8(const u32x4& graw, const u32x4& xraw, const bf16* __restrict__ add, float s) {
   const bf16x8 gv = __builtin_bit_cast(bf16x8, graw), xv = __builtin_bit_cast(bf16x8, xraw);

@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ 
                                                          bf16* __restrict__ Y, const bf16* __restrict__ R,
                                                          float alpha, float beta, int Npix, int H, int W, int Cin,
                                                          int Cout, int tiles_m, int tiles_n, ModEpilogue mod) {
+  apply_dyn(mod);
   constexpr int BM = 64 * NJ, BN = 128;
   constexpr int ROWB = Cfg<KC>::ROWB, CPR = Cfg<KC>::CPR;
   constexpr int WL = BN * CPR / 256;  // W loads per thread

@@ -231,8 +231,6 @@ __global__ __launch_bounds__(512, 4) void k_conv_igemm2(const bf16* __restrict__
                               n0 + wm * 64, Cout);
 }
 
-bf16* g_zero_page = nullptr;
-
 template <int TAPS, int NX>
 void launch2(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int Npix, int H, int W,
              int Cin, int Cout, hipStream_t st) {
@@ -247,7 +245,7 @@ void launch2(const void* X, const void* Wp, void* Y, const void* R, float alpha,
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const bf16*)X, (const bf16*)Wp, (bf16*)Y, (const bf16*)R,
-                     (const bf16*)g_zero_page, alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n,
+                     (const bf16*)edm_zero_page(), alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n,
                      (unsigned long long*)nullptr);
 }
 
@@ -257,14 +255,14 @@ void launch2(const void* X, const void* Wp, void* Y, const void* R, float alpha,
 // Segments: 0 vmcnt wait, 1 barrier, 2 DMA issue, 3 fragment reads landed, 4 MFMA issue.
 extern "C" int edm_conv_igemm_v2_stamp(const void* X, const void* Wp, void* Y, int B, int H, int W, int Cin, int Cout,
                                        unsigned long long* dbg, hipStream_t st) {
-  EDM_REQUIRE(X && Wp && Y && dbg && g_zero_page && W <= 32, "conv_igemm_v2_stamp: bad args (run the product kernel once first)");
+  EDM_REQUIRE(X && Wp && Y && dbg && edm_zero_page() && W <= 32, "conv_igemm_v2_stamp: bad args (run the product kernel once first)");
   const int Npix = B * H * W;
   const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + BN - 1) / BN;
   const size_t lds = (size_t)2 * 3 * 8 * 16 * ROWB + WRING * WTILE;
   auto kern = k_conv_igemm2<9, 3, true>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(kern, dim3(((tiles_m + 7) / 8) * 8 * tiles_n), dim3(512), lds, st, (const bf16*)X, (const bf16*)Wp,
-                     (bf16*)Y, (const bf16*)nullptr, (const bf16*)g_zero_page, 1.f, 0.f, Npix, H, W, Cin, Cout, tiles_m,
+                     (bf16*)Y, (const bf16*)nullptr, (const bf16*)edm_zero_page(), 1.f, 0.f, Npix, H, W, Cin, Cout, tiles_m,
                      tiles_n, dbg);
   EDM_CHECK_LAUNCH("conv_igemm_v2_stamp");
   return EDM_OK;
@@ -279,12 +277,12 @@ static void launch_abl(const void* X, const void* Wp, void* Y, int Npix, int H, 
   auto kern = k_conv_igemm2<9, 3, false, ABL>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(kern, dim3(((tiles_m + 7) / 8) * 8 * tiles_n), dim3(512), lds, st, (const bf16*)X, (const bf16*)Wp,
-                     (bf16*)Y, (const bf16*)nullptr, (const bf16*)g_zero_page, 1.f, 0.f, Npix, H, W, Cin, Cout, tiles_m,
+                     (bf16*)Y, (const bf16*)nullptr, (const bf16*)edm_zero_page(), 1.f, 0.f, Npix, H, W, Cin, Cout, tiles_m,
                      tiles_n, (unsigned long long*)nullptr);
 }
 extern "C" int edm_conv_igemm_v2_ablate(const void* X, const void* Wp, void* Y, int B, int H, int W, int Cin, int Cout,
                                         int mode, hipStream_t st) {
-  EDM_REQUIRE(X && Wp && Y && g_zero_page && W <= 32, "conv_igemm_v2_ablate: bad args");
+  EDM_REQUIRE(X && Wp && Y && edm_zero_page() && W <= 32, "conv_igemm_v2_ablate: bad args");
   const int Npix = B * H * W;
   switch (mode) {
     case 0: launch_abl<0>(X, Wp, Y, Npix, H, W, Cin, Cout, st); break;
@@ -309,14 +307,8 @@ extern "C" int edm_conv_igemm_v2(const void* X, const void* Wp, void* Y, const v
   EDM_REQUIRE(taps == 1 || taps == 9, "conv_igemm_v2: taps must be 1 or 9");
   EDM_REQUIRE(Cin > 0 && Cin % 32 == 0 && Cout > 0 && Cout % 8 == 0, "conv_igemm_v2: Cin %% 32, Cout %% 8 required");
   if (taps == 9 && W > 64) return EDM_ERR_UNSUPPORTED;
-  if (!g_zero_page) {
-    // one 256-byte zero page per process: the source of every out-of-range DMA lane (allocated once, outside any
-    // stream capture: the first call of a process must not happen under hipGraph capture)
-    if (hipMalloc((void**)&g_zero_page, 256) != hipSuccess || hipMemset(g_zero_page, 0, 256) != hipSuccess) {
-      edm_set_error("conv_igemm_v2: cannot allocate the zero page");
-      return EDM_ERR_LAUNCH;
-    }
-  }
+  EDM_ZERO_PAGE(zero_page_, "conv_igemm_v2");
+  (void)zero_page_;
   const int Npix = B * H * W;
   if (taps == 1) {
     launch2<1, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st);

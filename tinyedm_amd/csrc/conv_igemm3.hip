@@ -243,8 +243,6 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm3(const bf16* __restrict__
   }
 }
 
-bf16* g_zero_page3 = nullptr;
-
 template <int TAPS, int NX>
 void launch3(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int Npix, int H, int W,
              int Cin, int Cout, hipStream_t st) {
@@ -259,7 +257,7 @@ void launch3(const void* X, const void* Wp, void* Y, const void* R, float alpha,
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const bf16*)X, (const bf16*)Wp, (bf16*)Y, (const bf16*)R,
-                     (const bf16*)g_zero_page3, alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n,
+                     (const bf16*)edm_zero_page(), alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n,
                      (unsigned long long*)nullptr);
 }
 
@@ -269,14 +267,14 @@ void launch3(const void* X, const void* Wp, void* Y, const void* R, float alpha,
 // dbg[1] 100 MHz ticks, dbg[2] workgroups.
 extern "C" int edm_conv_igemm_v3_clock(const void* X, const void* Wp, void* Y, int B, int H, int W, int Cin, int Cout,
                                        unsigned long long* dbg, hipStream_t st) {
-  EDM_REQUIRE(X && Wp && Y && dbg && g_zero_page3 && W <= 32, "conv_igemm_v3_clock: bad args");
+  EDM_REQUIRE(X && Wp && Y && dbg && edm_zero_page() && W <= 32, "conv_igemm_v3_clock: bad args");
   const int Npix = B * H * W;
   const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + BN - 1) / BN;
   const size_t lds = (size_t)2 * 5 * 8 * 16 * ROWB + WRING * WTILE;
   auto kern = k_conv_igemm3<9, 5, true>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(kern, dim3(((tiles_m + 7) / 8) * 8 * tiles_n), dim3(512), lds, st, (const bf16*)X, (const bf16*)Wp,
-                     (bf16*)Y, (const bf16*)nullptr, (const bf16*)g_zero_page3, 1.f, 0.f, Npix, H, W, Cin, Cout, tiles_m,
+                     (bf16*)Y, (const bf16*)nullptr, (const bf16*)edm_zero_page(), 1.f, 0.f, Npix, H, W, Cin, Cout, tiles_m,
                      tiles_n, dbg);
   EDM_CHECK_LAUNCH("conv_igemm_v3_clock");
   return EDM_OK;
@@ -290,12 +288,8 @@ extern "C" int edm_conv_igemm_v3(const void* X, const void* Wp, void* Y, const v
   EDM_REQUIRE(taps == 1 || taps == 9, "conv_igemm_v3: taps must be 1 or 9");
   EDM_REQUIRE(Cin > 0 && Cin % 32 == 0 && Cout > 0 && Cout % 8 == 0, "conv_igemm_v3: Cin %% 32, Cout %% 8 required");
   if (taps == 9 && W > 64) return EDM_ERR_UNSUPPORTED;
-  if (!g_zero_page3) {
-    if (hipMalloc((void**)&g_zero_page3, 256) != hipSuccess || hipMemset(g_zero_page3, 0, 256) != hipSuccess) {
-      edm_set_error("conv_igemm_v3: cannot allocate the zero page");
-      return EDM_ERR_LAUNCH;
-    }
-  }
+  EDM_ZERO_PAGE(zero_page_, "conv_igemm_v3");
+  (void)zero_page_;
   const int Npix = B * H * W;
   if (taps == 1) {
     launch3<1, 4>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st);

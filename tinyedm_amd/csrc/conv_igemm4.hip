@@ -70,6 +70,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
                                                          const char* __restrict__ zeros, float alpha, float beta,
                                                          int Npix, int H, int W, int Cin, int Cout, int tiles_m,
                                                          int tiles_n, ModEpilogue mod) {
+  apply_dyn(mod);
   constexpr int XROWS = NX * 8 * 16;  // LDS rows per slab buffer; rows >= xrows are zero rows
   constexpr int XBYTES = XROWS * ROWB;
   constexpr int BNW = 32 * NI;        // output channels per workgroup
@@ -249,8 +250,6 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
                                     n0, Cout, mod);
 }
 
-char* g_zero_page4 = nullptr;
-
 template <int NX, int EPI = 0, int NI = 4>
 void launch4(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int Npix, int H, int W,
              int Cin, int Cout, const ModEpilogue& mod, hipStream_t st) {
@@ -264,7 +263,7 @@ void launch4(const void* X, const void* Wp, void* Y, const void* R, float alpha,
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const bf16*)X, (const bf16*)Wp, (bf16*)Y, (const bf16*)R,
-                     (const char*)g_zero_page4, alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n, mod);
+                     (const char*)edm_zero_page(), alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n, mod);
 }
 
 }  // namespace
@@ -283,12 +282,8 @@ int edm_conv_igemm_v4_ex(const void* X, const void* Wp, void* Y, const void* R, 
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && (long)B * H * W < (1L << 31), "conv_igemm_v4: bad B/H/W");
   EDM_REQUIRE(Cout > 0 && Cout % 8 == 0, "conv_igemm_v4: Cout %% 8 required");
   if (taps != 9 || Cin <= 0 || Cin % 64 != 0 || Cin * 2 + 64 > ZERO_PAGE || W > 64) return EDM_ERR_UNSUPPORTED;
-  if (!g_zero_page4) {
-    if (hipMalloc((void**)&g_zero_page4, ZERO_PAGE) != hipSuccess || hipMemset(g_zero_page4, 0, ZERO_PAGE) != hipSuccess) {
-      edm_set_error("conv_igemm_v4: cannot allocate the zero page");
-      return EDM_ERR_LAUNCH;
-    }
-  }
+  EDM_ZERO_PAGE(zero_page_, "conv_igemm_v4");
+  (void)zero_page_;
   const int Npix = B * H * W;
   const int xrows = BM + 2 * (W + 1);
   // 512x128 workgroup tiles when that still gives every CU two of them, else 512x64 (small feature maps)
@@ -322,12 +317,12 @@ int edm_conv_igemm_v1_ex(const void* X, const void* Wp, void* Y, const void* R, 
 // Picks the static-schedule kernel for layers with >= 512 tall tiles and the 128x128-tile kernel otherwise.
 extern "C" int edm_conv3x3_mod(const void* X, const void* Wp, void* Y, void* Y2, const float* lin, long lin_stride,
                                const float* gain, float pdrop, unsigned long long seed, unsigned sub, unsigned step,
-                               int B, int H, int W, int Cin, int Cout, hipStream_t st) {
+                               int B, int H, int W, int Cin, int Cout, const void* dyn, hipStream_t st) {
   EDM_REQUIRE(X && Wp && Y2 && lin && gain, "conv3x3_mod: null pointer");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0 && lin_stride >= Cout && pdrop >= 0.f && pdrop < 1.f,
               "conv3x3_mod: bad args");
   ModEpilogue mod{lin, gain, (bf16*)Y2, lin_stride, H * W, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), sub, step,
-                  nullptr, nullptr, nullptr, 0.f, 0};
+                  nullptr, nullptr, nullptr, 0.f, 0, (const StepParams*)dyn};
   if (edm_conv_v4_worthwhile((long)B * H * W, Cout)) {
     const int rc = edm_conv_igemm_v4_ex(X, Wp, Y, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
     if (rc != EDM_ERR_UNSUPPORTED) return rc;
@@ -344,13 +339,13 @@ extern "C" int edm_conv3x3_mod(const void* X, const void* Wp, void* Y, void* Y2,
 extern "C" int edm_conv3x3_modbwd(const void* dY, const void* Wd, float alpha, const void* U, const float* lin,
                                   long lin_stride, const float* gain, void* GR, float* gm, float pdrop,
                                   unsigned long long seed, unsigned sub, unsigned step, int B, int H, int W, int Cin,
-                                  int Cout, hipStream_t st) {
+                                  int Cout, const void* dyn, hipStream_t st) {
   EDM_REQUIRE(dY && Wd && U && lin && gain && GR && gm, "conv3x3_modbwd: null pointer");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0 && lin_stride >= Cout && pdrop >= 0.f && pdrop < 1.f,
               "conv3x3_modbwd: bad args");
   if ((H * W) % 32 != 0) return EDM_ERR_UNSUPPORTED;
   ModEpilogue mod{lin, gain, (bf16*)GR, lin_stride, H * W, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), sub, step,
-                  (const bf16*)U, gm, nullptr, 0.f, 1};
+                  (const bf16*)U, gm, nullptr, 0.f, 1, (const StepParams*)dyn};
   if (edm_conv_v4_worthwhile((long)B * H * W, Cout)) {
     const int rc = edm_conv_igemm_v4_ex(dY, Wd, nullptr, nullptr, alpha, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
     if (rc != EDM_ERR_UNSUPPORTED) return rc;
@@ -367,7 +362,7 @@ extern "C" int edm_conv3x3_silubwd(const void* dY, const void* Wd, const void* X
   EDM_REQUIRE(dY && Wd && Xpre && GX, "conv3x3_silubwd: null pointer");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0, "conv3x3_silubwd: bad args");
   ModEpilogue mod{nullptr, nullptr, (bf16*)GX, 0, H * W, 0.f, 0u, 0u, 0u, 0u, (const bf16*)Xpre, nullptr, (const bf16*)ADD,
-                  add_scale, 2};
+                  add_scale, 2, nullptr};
   if (edm_conv_v4_worthwhile((long)B * H * W, Cout)) {
     const int rc = edm_conv_igemm_v4_ex(dY, Wd, nullptr, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
     if (rc != EDM_ERR_UNSUPPORTED) return rc;

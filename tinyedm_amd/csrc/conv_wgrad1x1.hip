@@ -159,8 +159,6 @@ __global__ __launch_bounds__(512, 1) void k_wgrad1x1(const bf16* __restrict__ X,
     }
 }
 
-bf16* g_zero_page_1 = nullptr;
-
 }  // namespace
 
 // Number of split-K slabs edm_conv_wgrad_1x1 writes for this shape (sizes the workspace [S][Cout][Cin] fp32).
@@ -182,12 +180,8 @@ extern "C" int edm_conv_wgrad_1x1(const void* X, const void* dY, float* slabs, l
   EDM_REQUIRE(npix > 0 && npix < (1L << 31), "conv_wgrad_1x1: bad pixel count");
   EDM_REQUIRE(Cin > 0 && Cin % 32 == 0 && Cout > 0 && Cout % 32 == 0, "conv_wgrad_1x1: Cin, Cout must be multiples of 32");
   EDM_REQUIRE(nsplit == edm_conv_wgrad_1x1_nsplit(npix, Cin, Cout), "conv_wgrad_1x1: nsplit mismatch");
-  if (!g_zero_page_1) {
-    if (hipMalloc((void**)&g_zero_page_1, 256) != hipSuccess || hipMemset(g_zero_page_1, 0, 256) != hipSuccess) {
-      edm_set_error("conv_wgrad_1x1: cannot allocate the zero page");
-      return EDM_ERR_LAUNCH;
-    }
-  }
+  EDM_ZERO_PAGE(zero_page_, "conv_wgrad_1x1");
+  (void)zero_page_;
   long L = (npix + nsplit - 1) / nsplit;
   L = (L + KP - 1) / KP * KP;
   const int tiles_co = (Cout + TCO - 1) / TCO, tiles_ci = (Cin + TCI - 1) / TCI;
@@ -197,7 +191,7 @@ extern "C" int edm_conv_wgrad_1x1(const void* X, const void* dY, float* slabs, l
     attr_set = true;
   }
   hipLaunchKernelGGL(k_wgrad1x1, dim3(tiles_co * tiles_ci, nsplit), dim3(512), (size_t)RING * STAGE, st, (const bf16*)X,
-                     (const bf16*)dY, slabs, (const bf16*)g_zero_page_1, npix, Cin, Cout, tiles_ci, L);
+                     (const bf16*)dY, slabs, (const bf16*)edm_zero_page(), npix, Cin, Cout, tiles_ci, L);
   EDM_CHECK_LAUNCH("conv_wgrad_1x1");
   return EDM_OK;
 }

@@ -285,8 +285,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad2(const bf16* __restrict__
   (void)HALOX;
 }
 
-bf16* g_zero_page_w = nullptr;
-
 Geo make_geo(int B, int H, int W, int taps, int leads) {
   Geo g;
   if (taps == 9) {
@@ -320,12 +318,8 @@ extern "C" int edm_conv_wgrad_v2(const void* X, const void* dY, float* slabs, in
   EDM_REQUIRE(Cin > 0 && Cin % 32 == 0 && Cout > 0 && Cout % 32 == 0, "conv_wgrad_v2: Cin, Cout must be multiples of 32");
   EDM_REQUIRE(nsplit == edm_conv_wgrad_nsplit(B, H, W, Cin, Cout, taps), "conv_wgrad_v2: nsplit mismatch");
   if (taps == 9 && W + 2 > 2 * KP) return EDM_ERR_UNSUPPORTED;
-  if (!g_zero_page_w) {
-    if (hipMalloc((void**)&g_zero_page_w, 256) != hipSuccess || hipMemset(g_zero_page_w, 0, 256) != hipSuccess) {
-      edm_set_error("conv_wgrad_v2: cannot allocate the zero page");
-      return EDM_ERR_LAUNCH;
-    }
-  }
+  EDM_ZERO_PAGE(zero_page_, "conv_wgrad_v2");
+  (void)zero_page_;
   const int leads = (taps == 9 && W + 2 > KP) ? 2 : 1;   // 3x3 halo of PW+1 rows: within one 64-row stage, or two
   const Geo g = make_geo(B, H, W, taps, leads);
   long L = (g.kend - g.kbeg0 + nsplit - 1) / nsplit;
@@ -337,7 +331,7 @@ extern "C" int edm_conv_wgrad_v2(const void* X, const void* dY, float* slabs, in
       attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(tiles_co * tiles_ci, nsplit), dim3(256), lds, st, (const bf16*)X, (const bf16*)dY,
-                       slabs, (const bf16*)g_zero_page_w, B, H, W, Cin, Cout, tiles_ci, L, g);
+                       slabs, (const bf16*)edm_zero_page(), B, H, W, Cin, Cout, tiles_ci, L, g);
   };
   const size_t lds1 = (size_t)Ring<1>::DYRING * 2 * SUBB + (size_t)2 * Ring<1>::XSLOTS * SUBB;
   const size_t lds2 = (size_t)Ring<2>::DYRING * 2 * SUBB + (size_t)2 * Ring<2>::XSLOTS * SUBB;

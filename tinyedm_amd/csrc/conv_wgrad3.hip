@@ -1,0 +1,493 @@
+// Weight gradients of the 3x3 convolutions, third generation: a GROUP of layers per launch.
+//
+//   dWp[tap, co, ci] = sum_p dY[p, co] * X[p + off(tap), ci]     (autograd wgrad of F.conv2d, networks.py:35-37)
+//
+// Same math as conv_wgrad2.hip ("zero-padded flat K", LDS-DMA staging, rolling X window, transposing LDS reads);
+// what changed, and why (r01 profile: 43 launches x 81 us + 115 finish launches, 4.2 GB of split-K slab traffic):
+//  * workgroup tile 128(co) x 64(ci) x 9 taps, ONE wave per SIMD with the whole 512-register file: a wave owns
+//    64(co) x 32(ci) x 9 taps = 18 accumulator blocks, so a k-step is 2 dY + 9 X fragments for 18 MFMAs
+//    (1.2 transposing reads per MFMA instead of 2.2: the LDS pipe was busier than the matrix pipe);
+//  * the reduction dimension of ALL layers of the group is laid end to end ("stream-K"): workgroup w takes the
+//    stages [w*q, (w+1)*q) of that sequence, keeps its accumulators across consecutive stages of one tile and
+//    flushes a partial tile only when it crosses a tile boundary or its range ends.  Partial-tile traffic is
+//    (workgroups + tiles) x 288 KiB per LAUNCH instead of per layer, small layers no longer get a launch (and a
+//    quarter-filled chip) each, and a partial's position is static: slot(w, tile) = w + tile;
+//  * `k_wgrad3_finish` (one launch per group, one workgroup per weight row) sums a row's partials, applies the
+//    weight-normalisation projection and accumulates into the gradient arena.
+#include "common.h"
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+
+constexpr int KP = 64;                 // padded pixel rows per stage
+constexpr int SUBB = KP * 64;          // bytes of one [64 rows][32 ch] sub-image
+constexpr int TCO = 128, TCI = 64;     // workgroup tile
+constexpr int TILE_FLOATS = 9 * TCO * TCI;
+constexpr int MAXL = 16;               // layers per group (kernel-argument table)
+constexpr int DYRING = 3;
+
+template <int LEADS>
+struct Ring {  // as conv_wgrad2.hip: LEADS = 64-row stages the 3x3 halo (W + 2 rows) can reach
+  static constexpr int XR = LEADS == 1 ? 4 : 8;
+  static constexpr int MIRR = LEADS == 1 ? 2 : 4;
+  static constexpr int XSLOTS = XR + MIRR;
+  static constexpr size_t LDS = (size_t)DYRING * 4 * SUBB + (size_t)2 * XSLOTS * SUBB;
+};
+
+struct W3Layer {
+  const bf16* X;
+  const bf16* dY;
+  int B, H, W, Cin, Cout;
+  int PW, PH, lead_rows, kmult;
+  int tiles_ci, ntiles, nst, tile0;
+  long stage0, kbeg0, kend;
+};
+struct W3Group {
+  W3Layer L[MAXL];
+  int nlayers, nwg;
+  long total, q;
+  float* work;
+  const bf16* zeros;
+};
+
+__device__ __forceinline__ void dma16(const void* src, char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_dst, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+#define TR_RD(dst, base, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "i"(imm))
+#define LGKM_WAIT(n)                                       \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory");  \
+  __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ bf16x8 frag_of(const u32x2_t& lo, const u32x2_t& hi) {
+  u32x4 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int LEADS>
+__global__ __launch_bounds__(256, 1) void k_wgrad3(const W3Group g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int XR = Ring<LEADS>::XR, MIRR = Ring<LEADS>::MIRR, XSLOTS = Ring<LEADS>::XSLOTS;
+  char* dYb = smem;                          // [DYRING][4 sub][64 rows][64 B]
+  char* Xb = smem + DYRING * 4 * SUBB;       // [2 sub][XSLOTS][64 rows][64 B]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cb = wave & 1, ib = wave >> 1;   // this wave's 64(co) x 32(ci) block of the tile
+  const int drow = lane >> 2, dp = lane & 3;
+  const int krow_l = 8 * (lane >> 5) + ((lane & 15) >> 2);
+  const int chan_b = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  long pos = (long)blockIdx.x * g.q;
+  const long pend = (pos + g.q < g.total) ? pos + g.q : g.total;
+  int li = 0;
+  while (li + 1 < g.nlayers && pos >= g.L[li + 1].stage0) ++li;
+
+  while (pos < pend) {
+    // ---- one segment: `nst` consecutive stages of tile `tl` of layer `li`, starting at stage st0 of the tile
+    const bf16* __restrict__ X = g.L[li].X;
+    const bf16* __restrict__ dY = g.L[li].dY;
+    const int B = g.L[li].B, H = g.L[li].H, W = g.L[li].W, Cin = g.L[li].Cin, Cout = g.L[li].Cout;
+    const int PW = g.L[li].PW, PH = g.L[li].PH;
+    const long rel = pos - g.L[li].stage0;
+    const int tl = (int)(rel / g.L[li].nst);
+    const int st0 = (int)(rel - (long)tl * g.L[li].nst);
+    int nst = g.L[li].nst - st0;
+    if ((long)nst > pend - pos) nst = (int)(pend - pos);
+    const int tco = tl / g.L[li].tiles_ci, tci = tl - tco * g.L[li].tiles_ci;
+    const int co0 = tco * TCO, ci0 = tci * TCI;
+    const long ks0 = g.L[li].kbeg0 + (long)st0 * KP;
+    const long ks1 = (ks0 + (long)nst * KP < g.L[li].kend) ? ks0 + (long)nst * KP : g.L[li].kend;
+    float* __restrict__ out = g.work + (long)(blockIdx.x + g.L[li].tile0 + tl) * TILE_FLOATS;
+
+    // per-lane decode state of the padded row this lane stages: row = base + 16*wave + (lane>>2)
+    long kp = ks0 - LEADS * KP + wave * 16 + drow;
+    int sw, sh, sn;
+    {
+      const long R = kp / PW;
+      sw = (int)(kp - R * PW);
+      const long r2 = R - g.L[li].lead_rows + (long)g.L[li].kmult * PH;
+      sn = (int)(r2 / PH) - g.L[li].kmult;
+      sh = (int)(r2 % PH);
+    }
+    const int adv_w = KP % PW, adv_h = KP / PW;
+    auto advance = [&]() {
+      kp += KP;
+      sw += adv_w;
+      sh += adv_h;
+      if (sw >= PW) { sw -= PW; sh += 1; }
+      while (sh >= PH) { sh -= PH; sn += 1; }
+    };
+    auto pixel = [&](bool& valid) -> long {
+      valid = sn >= 0 && sn < B && sh < H && sw < W;
+      return ((long)sn * H + sh) * W + sw;
+    };
+    auto issue_x = [&](int j) {
+      bool valid;
+      const long pix = pixel(valid);
+      const int slot = j & (XR - 1);
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        const int ci = ci0 + sub * 32;
+        const bf16* src = (valid && ci < Cin) ? X + pix * Cin + ci + dp * 8 : g.zeros;
+        dma16(src, Xb + sub * (XSLOTS * SUBB) + slot * SUBB + wave * 1024);
+        if (slot < MIRR) dma16(src, Xb + sub * (XSLOTS * SUBB) + (XR + slot) * SUBB + wave * 1024);
+      }
+    };
+    auto issue_dy = [&](int t) {
+      bool valid;
+      const long pix = pixel(valid);
+      valid = valid && kp < ks1;
+      const int buf = t % DYRING;
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        const int co = co0 + sub * 32;
+        const bf16* src = (valid && co < Cout) ? dY + pix * Cout + co + dp * 8 : g.zeros;
+        dma16(src, dYb + buf * (4 * SUBB) + sub * SUBB + wave * 1024);
+      }
+    };
+
+    f32x16 acc[2][8], accv[2];   // taps 0..7 (AGPRs) and tap 8 (VGPRs, see MMV)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accv[i][r] = 0.f;
+    }
+
+    {
+      // prologue, issue order X(0) .. X(2*LEADS), dY(0), dY(1): dY stage t shares its rows with X stage t+LEADS
+      long kpa = 0, kpb = 0;
+      int wa = 0, ha = 0, na = 0, wb = 0, hb = 0, nb = 0;
+#pragma unroll
+      for (int j = 0; j <= 2 * LEADS; ++j) {
+        if (j > 0) advance();
+        if (j == LEADS) { kpa = kp; wa = sw; ha = sh; na = sn; }
+        if (j == LEADS + 1) { kpb = kp; wb = sw; hb = sh; nb = sn; }
+        issue_x(j);
+      }
+      const long kpl = kp;
+      const int wl = sw, hl = sh, nl = sn;
+      kp = kpa; sw = wa; sh = ha; sn = na;
+      issue_dy(0);
+      if (nst > 1) {
+        kp = kpb; sw = wb; sh = hb; sn = nb;
+        issue_dy(1);
+      }
+      kp = kpl; sw = wl; sh = hl; sn = nl;
+    }
+    for (int t = 0; t < nst; ++t) {
+      // retire dY(t) and X(t+2*LEADS); dY(t+1) (4 DMAs per wave, issued last) may stay in flight
+      if (t + 1 < nst) wait_vmcnt<4>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (t + 2 <= nst) {
+        const long kpp = kp;
+        const int wp = sw, hp = sh, np_ = sn;
+        advance();
+        issue_x(t + 2 * LEADS + 1);
+        if (t + 2 < nst) {
+          if (LEADS == 2) {
+            const long kpn = kp;
+            const int wn = sw, hn = sh, nn = sn;
+            kp = kpp; sw = wp; sh = hp; sn = np_;
+            issue_dy(t + 2);
+            kp = kpn; sw = wn; sh = hn; sn = nn;
+          } else {
+            issue_dy(t + 2);
+          }
+        }
+      }
+      {
+        const int slot = (t + LEADS) & (XR - 1);                        // X stage t+LEADS is the centre of the window
+        const int base_row = (slot < LEADS ? slot + XR : slot) * KP;    // mirrored position when the window would wrap
+        const unsigned a_u = (unsigned)(uintptr_t)(lds_char*)dYb + (t % DYRING) * (4 * SUBB) + (cb * 2) * SUBB + krow_l * 64 + chan_b;
+        const unsigned b_u = (unsigned)(uintptr_t)(lds_char*)Xb + ib * (XSLOTS * SUBB) + (base_row + krow_l) * 64 + chan_b;
+        unsigned tb[9];
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) tb[tp] = b_u + ((tp / 3 - 1) * PW + (tp % 3 - 1)) * 64;
+        u32x2_t A[2][2][2], Bf[2][3][2];
+        // item (k-step ks, tap group gg): 6 MFMAs; its X fragments are read one item ahead, the dY fragments of
+        // k-step ks+1 during item (ks, 2).  At most 12 LDS reads are outstanding (lgkmcnt is a 4-bit counter).
+#define RD_A(ks)                                                                                     \
+  TR_RD(A[(ks) & 1][0][0], a_u, (ks) * 1024);        TR_RD(A[(ks) & 1][0][1], a_u, (ks) * 1024 + 256);        \
+  TR_RD(A[(ks) & 1][1][0], a_u, SUBB + (ks) * 1024); TR_RD(A[(ks) & 1][1][1], a_u, SUBB + (ks) * 1024 + 256)
+#define RD_B(set, ks, gg)                                                                                   \
+  TR_RD(Bf[set][0][0], tb[3 * (gg) + 0], (ks) * 1024); TR_RD(Bf[set][0][1], tb[3 * (gg) + 0], (ks) * 1024 + 256); \
+  TR_RD(Bf[set][1][0], tb[3 * (gg) + 1], (ks) * 1024); TR_RD(Bf[set][1][1], tb[3 * (gg) + 1], (ks) * 1024 + 256); \
+  TR_RD(Bf[set][2][0], tb[3 * (gg) + 2], (ks) * 1024); TR_RD(Bf[set][2][1], tb[3 * (gg) + 2], (ks) * 1024 + 256)
+#define MM1(i, set, ks, gg, j)                                                                         \
+  acc[i][3 * (gg) + (j)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                    \
+      frag_of(A[(ks) & 1][i][0], A[(ks) & 1][i][1]), frag_of(Bf[set][j][0], Bf[set][j][1]), acc[i][3 * (gg) + (j)], 0, 0, 0)
+// tap 8 accumulates in ARCHITECTURAL VGPRs: hipcc allocates builtin-MFMA accumulators to the 256 AGPRs only (16
+// blocks), the 17th and 18th block would spill; an asm MFMA with "+v" operands keeps them in v[] (the register file
+// is unified, 288 accumulator registers + ~120 others fit).  Same-register C/D chains need no wait states.
+#define MMV(i, set, ks)                                                                                  \
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"                                                 \
+               : "+v"(accv[i])                                                                           \
+               : "v"(frag_of(A[(ks) & 1][i][0], A[(ks) & 1][i][1])), "v"(frag_of(Bf[set][2][0], Bf[set][2][1])))
+#define MM6(set, ks, gg)                                                                   \
+  MM1(0, set, ks, gg, 0); MM1(1, set, ks, gg, 0); MM1(0, set, ks, gg, 1); MM1(1, set, ks, gg, 1); \
+  MM1(0, set, ks, gg, 2); MM1(1, set, ks, gg, 2)
+#define MM6V(set, ks)                                                                      \
+  MM1(0, set, ks, 2, 0); MM1(1, set, ks, 2, 0); MM1(0, set, ks, 2, 1); MM1(1, set, ks, 2, 1); \
+  MMV(0, set, ks); MMV(1, set, ks)
+        RD_A(0); RD_B(0, 0, 0); LGKM_WAIT(6);
+        RD_B(1, 0, 1); LGKM_WAIT(6); MM6(0, 0, 0);
+        RD_B(0, 0, 2); LGKM_WAIT(6); MM6(1, 0, 1);
+        RD_A(1); LGKM_WAIT(4); RD_B(1, 1, 0); MM6V(0, 0);
+        RD_B(0, 1, 1); LGKM_WAIT(6); MM6(1, 1, 0);
+        RD_B(1, 1, 2); LGKM_WAIT(6); MM6(0, 1, 1);
+        RD_A(2); LGKM_WAIT(4); RD_B(0, 2, 0); MM6V(1, 1);
+        RD_B(1, 2, 1); LGKM_WAIT(6); MM6(0, 2, 0);
+        RD_B(0, 2, 2); LGKM_WAIT(6); MM6(1, 2, 1);
+        RD_A(3); LGKM_WAIT(4); RD_B(1, 3, 0); MM6V(0, 2);
+        RD_B(0, 3, 1); LGKM_WAIT(6); MM6(1, 3, 0);
+        RD_B(1, 3, 2); LGKM_WAIT(6); MM6(0, 3, 1);
+        LGKM_WAIT(0); MM6V(1, 3);
+#undef RD_A
+#undef RD_B
+#undef MM1
+#undef MM6
+#undef MM6V
+#undef MMV
+      }
+    }
+    // ---- flush the partial tile: [tap][128 co][64 ci] fp32, always whole (inactive blocks hold zeros).
+    // The asm MFMAs are invisible to hipcc's hazard recogniser: pad their write -> VMEM-read distance by hand.
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        float* base = out + ((long)tp * TCO + cb * 64 + i * 32) * TCI + ib * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          base[((r & 3) + 8 * (r >> 2) + 4 * lhi) * TCI] = (tp < 8) ? acc[i][tp < 8 ? tp : 0][r] : accv[i][r];
+      }
+    pos += nst;
+    if (pos >= g.L[li].stage0 + (long)g.L[li].ntiles * g.L[li].nst) ++li;
+    // every wave must be past its LDS reads before the next segment's prologue overwrites the rings
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
+// ---- finish: one workgroup per packed weight row.  grad[mo, i, t] (=|+=) projection(scale * sum of the row's
+// partial tiles) through w_hat = w / (d sqrt(n)) -- the arithmetic of k_wgrad_finish (weights.hip).
+struct F3Layer {
+  const float* w;
+  float* grad;
+  const int* perm;
+  int O, I, Cin, tiles_ci, nst, tile0, row0;
+  float scale;
+  int accumulate;
+  long stage0;
+};
+struct F3Group {
+  F3Layer L[MAXL];
+  int nlayers;
+  long q;
+  const float* work;
+};
+
+__device__ __forceinline__ float block_sum_f(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+  return s;
+}
+
+__global__ __launch_bounds__(256) void k_wgrad3_finish(const F3Group g) {
+  extern __shared__ __attribute__((aligned(16))) float gsm[];  // [n] gradient row in master order (i*9 + t)
+  __shared__ float red[8];
+  int li = 0;
+  while (li + 1 < g.nlayers && (int)blockIdx.x >= g.L[li + 1].row0) ++li;
+  const int r = blockIdx.x - g.L[li].row0;
+  const int I = g.L[li].I, tiles_ci = g.L[li].tiles_ci, nst = g.L[li].nst;
+  const int n = I * 9;
+  const int mo = g.L[li].perm ? g.L[li].perm[r] : r;
+  const float* __restrict__ row = g.L[li].w + (long)mo * n;
+  const int tco = r / TCO, rl = r - tco * TCO;
+  const float scale = g.L[li].scale;
+  // work items: (ci tile, tap, float4 of the 64 ci) -> 16 per (tile, tap)
+  const int items = tiles_ci * 9 * 16;
+  for (int idx = threadIdx.x; idx < items; idx += blockDim.x) {
+    const int c4 = idx & 15, tt = idx >> 4;
+    const int tp = tt % 9, tci = tt / 9;
+    const int tl = tco * tiles_ci + tci;
+    const long s0 = g.L[li].stage0 + (long)tl * nst;
+    const int w_lo = (int)(s0 / g.q), w_hi = (int)((s0 + nst - 1) / g.q);
+    const float* p = g.work + (long)(w_lo + g.L[li].tile0 + tl) * TILE_FLOATS + ((long)tp * TCO + rl) * TCI + c4 * 4;
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    for (int w = w_lo + 1; w <= w_hi; ++w) {
+      p += TILE_FLOATS;
+      a += *reinterpret_cast<const f32x4*>(p);
+    }
+    const int i0 = tci * TCI + c4 * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i0 + j < I) gsm[(i0 + j) * 9 + tp] = a[j] * scale;
+  }
+  __syncthreads();
+  float dot = 0.f, ss = 0.f;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    const float wv = row[e];
+    dot += gsm[e] * wv;
+    ss += wv * wv;
+  }
+  dot = block_sum_f(dot, red);
+  ss = block_sum_f(ss, red);
+  const float rn = sqrtf(ss);
+  const float sqn = sqrtf((float)n);
+  const float d = NORM_EPS + rn / sqn;
+  const float c0 = 1.0f / (d * sqn);
+  const float c1 = rn > 0.f ? dot / (d * rn * sqn) : 0.f;
+  float* __restrict__ outp = g.L[li].grad + (long)mo * n;
+  const int accumulate = g.L[li].accumulate;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    const float v = c0 * (gsm[e] - row[e] * c1);
+    outp[e] = accumulate ? outp[e] + v : v;
+  }
+}
+
+struct Plan {
+  W3Group wg;
+  F3Group fg;
+  int leads, rows_total, ntiles_total, max_n;
+  long work_floats;
+};
+
+}  // namespace
+
+// One layer of a group (plain C struct, mirrored by tinyedm_amd/ops.py).
+extern "C" {
+typedef struct {
+  const void* X;       // bf16 [B*H*W][Cin]   the layer's input
+  const void* dY;      // bf16 [B*H*W][Cout]  gradient of its output
+  const float* w;      // fp32 master weight [Cout][I][3][3]
+  float* grad;         // fp32 gradient, same layout
+  const int* perm;     // packed row -> master row (NULL = identity)
+  int B, H, W, Cin, Cout, I;   // I <= Cin: real input channels of the master weight (Cin may be zero-padded)
+  float scale;
+  int accumulate;      // 0: grad = ..., 1: grad += ...
+} edm_wgrad3_item;
+}
+
+
+namespace {
+
+int make_plan(const edm_wgrad3_item* it, int n, Plan& P) {
+  EDM_REQUIRE(it && n > 0 && n <= MAXL, "wgrad3: need 1..%d layers per group, got %d", MAXL, n);
+  P.leads = 0;
+  long stage = 0;
+  int tile = 0, row = 0;
+  P.max_n = 0;
+  for (int k = 0; k < n; ++k) {
+    const edm_wgrad3_item& a = it[k];
+    EDM_REQUIRE(a.X && a.dY && a.w && a.grad, "wgrad3: null pointer in layer %d", k);
+    EDM_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && (long)a.B * (a.H + 1) * (a.W + 1) < (1L << 30), "wgrad3: bad B/H/W");
+    EDM_REQUIRE(a.Cin > 0 && a.Cin % 32 == 0 && a.Cout > 0 && a.Cout % 32 == 0 && a.I > 0 && a.I <= a.Cin,
+                "wgrad3: Cin=%d Cout=%d must be multiples of 32 (I=%d <= Cin)", a.Cin, a.Cout, a.I);
+    EDM_REQUIRE(a.W + 2 <= 2 * KP, "wgrad3: W=%d > %d unsupported", a.W, 2 * KP - 2);
+    EDM_REQUIRE((long)a.I * 9 * 4 <= 64 * 1024, "wgrad3: fan_in %d too large for the LDS row buffer", a.I * 9);
+    const int leads = (a.W + 2 > KP) ? 2 : 1;
+    EDM_REQUIRE(P.leads == 0 || P.leads == leads, "wgrad3: layers of one group must share the halo class (W <= 62 or W > 62)");
+    P.leads = leads;
+    W3Layer& L = P.wg.L[k];
+    L.X = (const bf16*)a.X;
+    L.dY = (const bf16*)a.dY;
+    L.B = a.B; L.H = a.H; L.W = a.W; L.Cin = a.Cin; L.Cout = a.Cout;
+    L.PW = a.W + 1;
+    L.PH = a.H + 1;
+    L.lead_rows = 2 + (leads * KP + L.PW - 1) / L.PW;
+    L.kmult = (L.lead_rows + L.PH - 1) / L.PH;
+    L.kbeg0 = (long)(L.lead_rows - 1) * L.PW + 1;
+    L.kend = ((long)L.lead_rows + (long)a.B * L.PH) * L.PW;
+    L.tiles_ci = (a.Cin + TCI - 1) / TCI;
+    L.ntiles = ((a.Cout + TCO - 1) / TCO) * L.tiles_ci;
+    L.nst = (int)((L.kend - L.kbeg0 + KP - 1) / KP);
+    L.tile0 = tile;
+    L.stage0 = stage;
+    F3Layer& F = P.fg.L[k];
+    F.w = a.w; F.grad = a.grad; F.perm = a.perm;
+    F.O = a.Cout; F.I = a.I; F.Cin = a.Cin; F.tiles_ci = L.tiles_ci; F.nst = L.nst; F.tile0 = tile; F.row0 = row;
+    F.scale = a.scale; F.accumulate = a.accumulate; F.stage0 = stage;
+    stage += (long)L.ntiles * L.nst;
+    tile += L.ntiles;
+    row += a.Cout;
+    if (a.I * 9 > P.max_n) P.max_n = a.I * 9;
+  }
+  constexpr int NCU = 256, QMIN = 8;     // MI355X: one workgroup per CU; at least QMIN stages per workgroup
+  long q = (stage + NCU - 1) / NCU;
+  if (q < QMIN) q = QMIN;
+  const int nwg = (int)((stage + q - 1) / q);
+  P.wg.nlayers = P.fg.nlayers = n;
+  P.wg.nwg = nwg;
+  P.wg.total = stage;
+  P.wg.q = P.fg.q = q;
+  P.rows_total = row;
+  P.ntiles_total = tile;
+  P.work_floats = (long)(nwg + tile) * TILE_FLOATS;
+  return EDM_OK;
+}
+
+}  // namespace
+
+// Bytes of workspace edm_wgrad3_group needs for this group (fp32 partial tiles; fully overwritten before being read).
+extern "C" long edm_wgrad3_workspace(const edm_wgrad3_item* items, int n) {
+  Plan P;
+  if (make_plan(items, n, P) != EDM_OK) return -1;
+  return P.work_floats * 4;
+}
+
+// Weight gradients of up to 16 3x3 layers: one stream-K launch + one finish launch.  `items` is HOST memory (read
+// during the call only); workspace is device memory of at least edm_wgrad3_workspace(items, n) bytes.
+extern "C" int edm_wgrad3_group(const edm_wgrad3_item* items, int n, void* workspace, long workspace_bytes,
+                                hipStream_t st) {
+  Plan P;
+  const int rc = make_plan(items, n, P);
+  if (rc != EDM_OK) return rc;
+  EDM_REQUIRE(workspace && workspace_bytes >= P.work_floats * 4, "wgrad3: workspace too small (%ld < %ld bytes)",
+              workspace_bytes, P.work_floats * 4);
+  const bf16* zeros = (const bf16*)edm_zero_page();
+  EDM_REQUIRE(zeros, "wgrad3: edm_init() has not been called on this device");
+  P.wg.work = (float*)workspace;
+  P.wg.zeros = zeros;
+  P.fg.work = (const float*)workspace;
+  static bool set1 = false, set2 = false, setf = false;
+  if (P.leads == 1) {
+    if (!set1) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      set1 = true;
+    }
+    hipLaunchKernelGGL(k_wgrad3<1>, dim3(P.wg.nwg), dim3(256), Ring<1>::LDS, st, P.wg);
+  } else {
+    if (!set2) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      set2 = true;
+    }
+    hipLaunchKernelGGL(k_wgrad3<2>, dim3(P.wg.nwg), dim3(256), Ring<2>::LDS, st, P.wg);
+  }
+  EDM_CHECK_LAUNCH("wgrad3");
+  if (!setf) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3_finish), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    setf = true;
+  }
+  hipLaunchKernelGGL(k_wgrad3_finish, dim3(P.rows_total), dim3(256), (size_t)P.max_n * 4, st, P.fg);
+  EDM_CHECK_LAUNCH("wgrad3_finish");
+  return EDM_OK;
+}

@@ -225,7 +225,9 @@ extern "C" int edm_axpby(const void* a, float alpha, const void* b, float beta, 
 
 __global__ void k_mod_silu_drop_fwd(const bf16* __restrict__ r, const float* __restrict__ lin,
                                     const float* __restrict__ gain, bf16* __restrict__ a, int HW, int C, long n8,
-                                    long lin_stride, float pdrop, uint32_t seed_lo, uint32_t seed_hi, uint32_t sub, uint32_t step) {
+                                    long lin_stride, float pdrop, uint32_t seed_lo, uint32_t seed_hi, uint32_t sub, uint32_t step,
+                                    const StepParams* __restrict__ dyn) {
+  if (dyn) { step = dyn->step; seed_lo = dyn->seed_lo; seed_hi = dyn->seed_hi; }
   const int CL = C >> 3;
   const float g = *gain;
   const float keep_scale = pdrop > 0.f ? 1.0f / (1.0f - pdrop) : 1.0f;
@@ -258,8 +260,10 @@ __global__ void k_mod_silu_drop_fwd(const bf16* __restrict__ r, const float* __r
 __global__ void k_mod_silu_drop_bwd(const bf16* __restrict__ r, const float* __restrict__ lin,
                                     const float* __restrict__ gain, const bf16* __restrict__ ga,
                                     bf16* __restrict__ gr, float* __restrict__ gm, int HW, int C, int PIXW,
-                                    long lin_stride, float pdrop, uint32_t seed_lo, uint32_t seed_hi, uint32_t sub, uint32_t step) {
+                                    long lin_stride, float pdrop, uint32_t seed_lo, uint32_t seed_hi, uint32_t sub, uint32_t step,
+                                    const StepParams* __restrict__ dyn) {
   extern __shared__ __attribute__((aligned(16))) float red[];
+  if (dyn) { step = dyn->step; seed_lo = dyn->seed_lo; seed_hi = dyn->seed_hi; }
   const int CL = C >> 3;
   const int PS = blockDim.x / CL;
   const int c8 = threadIdx.x % CL, ps = threadIdx.x / CL;
@@ -326,12 +330,13 @@ static int block_for_chunks(int CL) { return (256 / CL) * CL; }
 // lin: row b starts at lin + b*lin_stride (lin_stride >= C: a column slice of the batched embed-linear output)
 extern "C" int edm_mod_silu_drop_fwd(const void* r, const float* lin, long lin_stride, const float* gain, void* a, int B,
                                      int HW, int C, float pdrop, unsigned long long seed, unsigned sub, unsigned step,
-                                     hipStream_t st) {
+                                     const void* dyn, hipStream_t st) {
   EDM_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && C > 0 && pdrop >= 0.f && pdrop < 1.f && lin_stride >= C,
               "mod_silu_drop_fwd: bad args");
   long n8 = (long)B * HW * C / 8;
   hipLaunchKernelGGL(k_mod_silu_drop_fwd, dim3(grid_for(n8, 256)), dim3(256), 0, st, (const bf16*)r, lin, gain,
-                     (bf16*)a, HW, C, n8, lin_stride, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), sub, step);
+                     (bf16*)a, HW, C, n8, lin_stride, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), sub, step,
+                     (const StepParams*)dyn);
   EDM_CHECK_LAUNCH("mod_silu_drop_fwd");
   return EDM_OK;
 }
@@ -340,14 +345,14 @@ extern "C" int edm_mod_silu_drop_fwd(const void* r, const float* lin, long lin_s
 extern "C" int edm_mod_silu_drop_bwd(const void* r, const float* lin, long lin_stride, const float* gain,
                                      const void* ga, void* gr, float* gm, float* glin, long glin_stride, float* ggain,
                                      int B, int HW, int C, float pdrop, unsigned long long seed, unsigned sub,
-                                     unsigned step, hipStream_t st) {
+                                     unsigned step, const void* dyn, hipStream_t st) {
   EDM_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && C > 0 && C <= 1024 && lin_stride >= C && glin_stride >= C,
               "mod_silu_drop_bwd: bad args");
   int CL = C / 8, block = block_for_chunks(CL), PS = block / CL;
   int PIXW = HW >= 256 ? 128 : HW;
   hipLaunchKernelGGL(k_mod_silu_drop_bwd, dim3(B, cdiv(HW, PIXW)), dim3(block), PS * C * sizeof(float), st,
                      (const bf16*)r, lin, gain, (const bf16*)ga, (bf16*)gr, gm, HW, C, PIXW, lin_stride, pdrop,
-                     (uint32_t)seed, (uint32_t)(seed >> 32), sub, step);
+                     (uint32_t)seed, (uint32_t)(seed >> 32), sub, step, (const StepParams*)dyn);
   EDM_CHECK_LAUNCH("mod_silu_drop_bwd");
   hipLaunchKernelGGL(k_mod_finish, dim3(grid_for((long)B * C, 256, 64)), dim3(256), 0, st, gm, lin, gain, glin,
                      ggain, (long)B * C, C, lin_stride, glin_stride);

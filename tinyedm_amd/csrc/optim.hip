@@ -19,7 +19,8 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, fl
 // sigma_b = exp(P_mean + P_std*eps_b);  noisy = clean + sigma_b * n      (4 elements per thread)
 __global__ void k_diffuse(const float* __restrict__ clean, float* __restrict__ noisy, float* __restrict__ sigma,
                           float P_mean, float P_std, int B, long CHW, uint32_t seed_lo, uint32_t seed_hi,
-                          uint32_t step) {
+                          uint32_t step, const StepParams* __restrict__ dyn) {
+  if (dyn) { step = dyn->step; seed_lo = dyn->seed_lo ^ 0xD1FF05E5u; seed_hi = dyn->seed_hi; }
   const long n4 = ((long)B * CHW + 3) / 4;
   const long total = (long)B * CHW;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -59,7 +60,7 @@ __global__ void k_diffuse_given(const float* __restrict__ clean, const float* __
 // loss += sum_b mean_j w_b (D-x)^2 / B ;  dD = 2 w_b (D-x) / (CHW*B)   [w_b optional override]
 __global__ void k_loss(const float* __restrict__ Dn, const float* __restrict__ clean, const float* __restrict__ sigma,
                        const float* __restrict__ wext, float sd, float* __restrict__ loss, float* __restrict__ dD, int B,
-                       long CHW) {
+                       long CHW, float* __restrict__ acc_sum, long long* __restrict__ acc_total) {
   const long total = (long)B * CHW;
   const float inv = 1.0f / ((float)CHW * (float)B);
   float part = 0.f;
@@ -81,20 +82,30 @@ __global__ void k_loss(const float* __restrict__ Dn, const float* __restrict__ c
   part = wave_sum(part);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv);
+  if (threadIdx.x == 0) {
+    const float p = red[0] + red[1] + red[2] + red[3];
+    atomicAdd(loss, p * inv);
+    // epoch state of the metric (metric.py:38-49): sum_i mean_j w_i d_ij^2 and the sample count
+    if (acc_sum) atomicAdd(acc_sum, p / (float)CHW);
+    if (acc_total && blockIdx.x == 0) *acc_total += B;
+  }
 }
 
 struct AdamArgs {
   float lr, b1, b2, eps, bc1, bc2sqrt, ema_beta, grad_scale;
 };
 // fused multi-tensor Adam + EMA over the flat arenas: 5 streams read, 4 written, one pass
-__global__ void k_adam_ema(float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,
-                           float* __restrict__ v, float* __restrict__ ema, long n4, long n, AdamArgs a) {
+// zero_grad: the gradient arena is cleared in the same pass (saves the separate fill of optimizer.zero_grad()).
+__global__ void k_adam_ema(float* __restrict__ theta, float* __restrict__ grad, float* __restrict__ m,
+                           float* __restrict__ v, float* __restrict__ ema, long n4, long n, AdamArgs a,
+                           const StepParams* __restrict__ dyn, int zero_grad) {
+  if (dyn) { a.lr = dyn->lr; a.ema_beta = dyn->ema_beta; a.grad_scale = dyn->grad_scale; a.bc1 = dyn->bc1; a.bc2sqrt = dyn->bc2sqrt; }
   const float step_size = a.lr / a.bc1;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     if (i * 4 + 3 < n) {
       f32x4 t = *reinterpret_cast<f32x4*>(theta + i * 4);
       f32x4 g = *reinterpret_cast<const f32x4*>(grad + i * 4);
+      if (zero_grad) *reinterpret_cast<f32x4*>(grad + i * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 mm = *reinterpret_cast<f32x4*>(m + i * 4);
       f32x4 vv = *reinterpret_cast<f32x4*>(v + i * 4);
       f32x4 ee;
@@ -120,6 +131,7 @@ __global__ void k_adam_ema(float* __restrict__ theta, const float* __restrict__ 
         m[e] = mj;
         v[e] = vj;
         theta[e] = tj;
+        if (zero_grad) grad[e] = 0.f;
         if (ema) ema[e] = a.ema_beta * ema[e] + (1.f - a.ema_beta) * tj;
       }
     }
@@ -155,11 +167,13 @@ inline int grid_for(long work, int block) {
 
 }  // namespace
 
+// dyn (nullable, device edm_step_params): step and seed come from it; the Diffuser's stream is the network seed with
+// its low word XORed by 0xD1FF05E5 (what tinyedm_amd.Diffuser passes by value otherwise).
 extern "C" int edm_diffuse(const float* clean, float* noisy, float* sigma, float P_mean, float P_std, int B, long CHW,
-                           unsigned long long seed, unsigned step, hipStream_t st) {
+                           unsigned long long seed, unsigned step, const void* dyn, hipStream_t st) {
   EDM_REQUIRE(clean && noisy && sigma && B > 0 && CHW > 0, "diffuse: bad args");
   hipLaunchKernelGGL(k_diffuse, dim3(grid_for((long)B * CHW / 4 + 1, 256)), dim3(256), 0, st, clean, noisy, sigma,
-                     P_mean, P_std, B, CHW, (uint32_t)seed, (uint32_t)(seed >> 32), step);
+                     P_mean, P_std, B, CHW, (uint32_t)seed, (uint32_t)(seed >> 32), step, (const StepParams*)dyn);
   EDM_CHECK_LAUNCH("diffuse");
   return EDM_OK;
 }
@@ -171,19 +185,23 @@ extern "C" int edm_diffuse_given(const float* clean, const float* eps, const flo
   EDM_CHECK_LAUNCH("diffuse_given");
   return EDM_OK;
 }
-// loss (device scalar) is accumulated (+=): caller zero-fills.  dD may be null (validation).
+// loss (device scalar) is accumulated (+=): caller zero-fills.  dD may be null (validation).  acc_sum / acc_total
+// (nullable device scalars): the metric's epoch state, sum_i mean_j w_i d_ij^2 and the number of samples, += in place.
 extern "C" int edm_weighted_mse(const float* D, const float* clean, const float* sigma, const float* weight_override,
-                                float sigma_data, float* loss, float* dD, int B, long CHW, hipStream_t st) {
+                                float sigma_data, float* loss, float* dD, int B, long CHW, float* acc_sum,
+                                long long* acc_total, hipStream_t st) {
   EDM_REQUIRE(D && clean && (sigma || weight_override) && loss && B > 0 && CHW > 0, "weighted_mse: bad args");
   const long blocks = ((long)B * CHW + 1023) / 1024;  // ~4 elements per thread, at most 256 workgroups
   hipLaunchKernelGGL(k_loss, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, st, D, clean, sigma,
-                     weight_override, sigma_data, loss, dD, B, CHW);
+                     weight_override, sigma_data, loss, dD, B, CHW, acc_sum, acc_total);
   EDM_CHECK_LAUNCH("weighted_mse");
   return EDM_OK;
 }
-// step is 1-based (bias corrections use it); ema may be null.
-extern "C" int edm_adam_ema(float* theta, const float* grad, float* m, float* v, float* ema, long n, float lr, float b1,
-                            float b2, float eps, int step, float ema_beta, float grad_scale, hipStream_t st) {
+// step is 1-based (bias corrections use it); ema may be null.  dyn (nullable, device edm_step_params) overrides lr,
+// ema_beta, grad_scale and the two bias corrections; zero_grad != 0 clears `grad` in the same pass.
+extern "C" int edm_adam_ema(float* theta, float* grad, float* m, float* v, float* ema, long n, float lr, float b1,
+                            float b2, float eps, int step, float ema_beta, float grad_scale, const void* dyn,
+                            int zero_grad, hipStream_t st) {
   EDM_REQUIRE(theta && grad && m && v && n > 0 && step >= 1, "adam_ema: bad args");
   EDM_REQUIRE(((uintptr_t)theta % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
                   ((uintptr_t)v % 16 == 0) && (!ema || (uintptr_t)ema % 16 == 0),
@@ -195,7 +213,8 @@ extern "C" int edm_adam_ema(float* theta, const float* grad, float* m, float* v,
   a.ema_beta = ema_beta;
   a.grad_scale = grad_scale;
   const long n4 = (n + 3) / 4;
-  hipLaunchKernelGGL(k_adam_ema, dim3(grid_for(n4, 256)), dim3(256), 0, st, theta, grad, m, v, ema, n4, n, a);
+  hipLaunchKernelGGL(k_adam_ema, dim3(grid_for(n4, 256)), dim3(256), 0, st, theta, grad, m, v, ema, n4, n, a,
+                     (const StepParams*)dyn, zero_grad);
   EDM_CHECK_LAUNCH("adam_ema");
   return EDM_OK;
 }

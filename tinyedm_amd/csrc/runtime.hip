@@ -1,0 +1,42 @@
+// Per-device state of the library: the zero page.
+//
+// Several kernels point LDS-DMA loads of padding rows / out-of-range channels at a page of zeros instead of
+// branching around them.  The page is allocated ONCE per device by edm_init() -- never lazily inside a launch
+// function, so every compute entry point stays allocation-free, sync-free and graph-capturable from its first
+// call (a cold call under stream capture used to hipMalloc) -- and is looked up per device, under a mutex.
+#include "common.h"
+#include <mutex>
+
+namespace {
+constexpr int MAX_DEV = 64;
+constexpr size_t ZERO_BYTES = 4096;   // >= the longest zero row any kernel reads (conv_igemm4: Cin*2 + 64 bytes)
+void* g_zero[MAX_DEV] = {};
+std::mutex g_mu;
+}  // namespace
+
+// Allocate the device-side constants of `device` (idempotent, thread-safe).  Must be called once per device before
+// the first kernel entry point, outside any stream capture; tinyedm_amd._lib does so when it binds the library.
+extern "C" int edm_init(int device) {
+  EDM_REQUIRE(device >= 0 && device < MAX_DEV, "edm_init: bad device %d", device);
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (g_zero[device]) return EDM_OK;
+  int prev = -1;
+  if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+  void* p = nullptr;
+  bool ok = hipSetDevice(device) == hipSuccess && hipMalloc(&p, ZERO_BYTES) == hipSuccess &&
+            hipMemset(p, 0, ZERO_BYTES) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+  if (prev >= 0) (void)hipSetDevice(prev);
+  if (!ok) {
+    edm_set_error("edm_init: cannot allocate the zero page on device %d", device);
+    return EDM_ERR_LAUNCH;
+  }
+  g_zero[device] = p;
+  return EDM_OK;
+}
+
+// The current device's zero page (4096 bytes), or NULL when edm_init() has not run for it.
+extern "C" const void* edm_zero_page(void) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  return g_zero[dev];
+}

@@ -63,8 +63,8 @@ class GradReducer:
 
     def _make_hook(self, idx):
         def hook(_param):
-            if not self.enabled or idx in self._fired:
-                return
+            if not self.enabled or idx in self._fired or getattr(_param, "_edm_deferred", False):
+                return              # deferred: the grouped weight-gradient launch has not been enqueued yet
             # A parameter is counted once per backward pass.  Weights whose gradient the HIP finish kernel writes
             # straight into the arena announce themselves through `_edm_hooks`, and autograd may ALSO run the
             # post-accumulate hook for the same parameter (it does so even though the Function returned no gradient

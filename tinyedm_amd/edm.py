@@ -36,7 +36,8 @@ class Diffuser(nn.Module):
         if not clean_image.is_cuda:
             raise RuntimeError("tinyedm_amd.Diffuser: input must be a GPU tensor (there is no CPU path)")
         x = clean_image.float().contiguous()
-        noisy, sigma = ops.diffuse(x, self.P_mean, self.P_std, networks.rng.seed ^ 0xD1FF05E5, networks.rng.step)
+        noisy, sigma = ops.diffuse(x, self.P_mean, self.P_std, networks.rng.seed ^ 0xD1FF05E5, networks.rng.step,
+                                   dyn=networks.rng.dyn)
         return noisy.to(clean_image.dtype), sigma.to(clean_image.dtype)
 
     def extra_repr(self) -> str:

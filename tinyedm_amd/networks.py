@@ -34,6 +34,7 @@ bf16, f32 = torch.bfloat16, torch.float32
 class _Rng:
     seed: int = 42
     step: int = 0
+    dyn = None      # device edm_step_params record: set by a captured training step (graph.py), overrides seed/step
 
 
 rng = _Rng()
@@ -115,42 +116,100 @@ class _WNBase(nn.Module):
 
 
 WGRAD_STREAM = os.environ.get("EDM_WGRAD_STREAM", "1") != "0"
-_join_pending = set()
+# 3x3 weight gradients: layers per grouped stream-K launch (csrc/conv_wgrad3.hip; 0 = previous per-layer kernels)
+W3_GROUP = max(0, min(16, int(os.environ.get("EDM_W3_GROUP", "12"))))
+_bwd_end_queued = set()     # devices whose end-of-backward callback is queued for the running backward pass
+_w3_pending = {}            # device index -> [(mod, x, dy, scale)] 3x3 layers waiting for their grouped launch
 
 
-def _queue_side_join(device):
-    """Make the stream that runs this backward pass wait for the side stream once the pass has finished."""
-    key = torch.device(device).index
-    if key in _join_pending:
+def _run_on_side(device, fn, tensors=()):
+    """Run fn() on the auxiliary stream, ordered after everything already enqueued on the current stream."""
+    if WGRAD_STREAM:
+        side = ops.side_stream(device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        for t in tensors:
+            t.record_stream(side)
+    else:
+        fn()
+
+
+def _flush_w3(key):
+    """Launch the pending 3x3 weight gradients of device `key` as one group (arena mode: results accumulate
+    straight into the gradient arena), then tell the data-parallel reducer that those gradients are final."""
+    items = _w3_pending.pop(key, None)
+    if not items:
         return
-    side = ops.side_stream(device)
+    dev = items[0][0].weight.device
+    args = [(x, dy, m.weight.data, m.weight.grad, m._perm, scale, True) for m, x, dy, scale in items]
+    keep = [t for _, x, dy, _ in items for t in (x, dy)]
+    _run_on_side(dev, lambda: ops.wgrad3_group(args), keep)
+    for m, _, _, _ in items:
+        m.weight._edm_deferred = False
+        for hook in getattr(m.weight, "_edm_hooks", ()):
+            hook(m.weight)
 
-    def join():
-        _join_pending.discard(key)
-        torch.cuda.current_stream(device).wait_stream(side)
 
+def _backward_end(key):
+    """End of a backward pass on device `key`: flush the last partial group, then make the stream that ran the
+    backward wait for the auxiliary stream (the optimizer reads what the weight-gradient kernels wrote)."""
+    _bwd_end_queued.discard(key)
+    _flush_w3(key)
+    if WGRAD_STREAM:
+        torch.cuda.current_stream(key).wait_stream(ops.side_stream(key))
+
+
+def _queue_backward_end(device):
+    key = torch.device(device).index
+    if key in _bwd_end_queued:
+        return
     try:
-        torch.autograd.Variable._execution_engine.queue_callback(join)
-        _join_pending.add(key)
-    except RuntimeError:      # not inside a backward pass: join right away
-        torch.cuda.current_stream(device).wait_stream(side)
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: _backward_end(key))
+        _bwd_end_queued.add(key)
+    except RuntimeError:      # not inside a backward pass: finish right away
+        _backward_end(key)
+
+
+def reset_backward_state():
+    """Forget deferred work of a backward pass that did not complete (an exception inside autograd leaves its
+    end-of-backward callback unrun).  Called at the start of every Denoiser forward."""
+    if _bwd_end_queued or _w3_pending:
+        _bwd_end_queued.clear()
+        for items in _w3_pending.values():
+            for m, _, _, _ in items:
+                m.weight._edm_deferred = False
+        _w3_pending.clear()
+        if WGRAD_STREAM:
+            for s in ops.side_streams():
+                torch.cuda.current_stream(s.device).wait_stream(s)
 
 
 def _wgrad(mod, x, dy, taps, scale=1.0):
-    """Weight gradient of a conv layer: split-K slabs + finish/projection.  In flat-arena mode the result is only
-    needed by the optimizer, so both kernels run on the side stream (EDM_WGRAD_STREAM=0 disables), off the critical
-    dgrad -> elementwise -> dgrad chain of the backward pass: the MFMA-bound wgrad overlaps the HBM-bound
-    elementwise kernels of the main stream (+7 % step throughput measured on the CIFAR-10 config)."""
+    """Weight gradient of a conv layer.  In flat-arena mode the result is only needed by the optimizer, so the
+    kernels run on the side stream (EDM_WGRAD_STREAM=0 disables), off the critical dgrad -> elementwise -> dgrad
+    chain of the backward pass, and 3x3 layers are collected into groups of W3_GROUP per launch."""
     w = mod.weight
-    if (WGRAD_STREAM and w.grad is not None and getattr(w, "_edm_direct", False)
-            and not torch.cuda.is_current_stream_capturing()):
-        side = ops.side_stream(w.device)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            mod.finish_grad(ops.conv_wgrad(x, dy, taps), scale=scale)
-        x.record_stream(side)
-        dy.record_stream(side)
-        _queue_side_join(w.device)
+    direct = w.grad is not None and getattr(w, "_edm_direct", False)
+    if taps == 9 and W3_GROUP and w.dim() == 4 and ops.wgrad3_supported(x, dy, w.shape[1]):
+        if direct:
+            key = w.device.index
+            pend = _w3_pending.setdefault(key, [])
+            if pend and (pend[0][1].shape[2] + 2 > 64) != (x.shape[2] + 2 > 64):
+                _flush_w3(key)                        # a group shares one halo class
+                pend = _w3_pending.setdefault(key, [])
+            pend.append((mod, x, dy, scale))
+            w._edm_deferred = True                    # autograd may run the parameter's hooks before the group is launched
+            if len(pend) >= W3_GROUP:
+                _flush_w3(key)
+            _queue_backward_end(w.device)
+            return None
+        g = torch.empty_like(w.data)
+        ops.wgrad3_group([(x, dy, w.data, g, mod._perm, scale, False)])
+        return g
+    if direct and not torch.cuda.is_current_stream_capturing():
+        _run_on_side(w.device, lambda: mod.finish_grad(ops.conv_wgrad(x, dy, taps), scale=scale), (x, dy))
+        _queue_backward_end(w.device)
         return None
     return mod.finish_grad(ops.conv_wgrad(x, dy, taps), scale=scale)
 
@@ -579,14 +638,15 @@ class _ResBlockFn(torch.autograd.Function):
         if ops.FUSE_MOD and ops.IGEMM_VERSION == 0:
             # modulation + mp_silu + dropout ride in the conv epilogue; the pre-activation r1 is only written when
             # a backward pass will need it
-            r1, a2 = ops.conv3x3_mod(s, wf1, lin, gain, pdrop, seed, sub, step, want_u=any(ctx.needs_input_grad))
+            r1, a2 = ops.conv3x3_mod(s, wf1, lin, gain, pdrop, seed, sub, step, want_u=any(ctx.needs_input_grad),
+                                     dyn=rng.dyn)
         else:
             r1 = ops.conv_igemm(s, wf1, taps)
-            a2 = ops.mod_silu_drop_fwd(r1, lin, gain, pdrop, seed, sub, step)
+            a2 = ops.mod_silu_drop_fwd(r1, lin, gain, pdrop, seed, sub, step, dyn=rng.dyn)
         a, b = _mp_coeffs(blk.add_factor)
         out = ops.conv_igemm(a2, wf2, taps, residual=xres, alpha=b, beta=a)
         ctx.blk, ctx.enc, ctx.has1 = blk, enc, has1
-        ctx.drop = (pdrop, seed, sub, step)
+        ctx.drop = (pdrop, seed, sub, step, rng.dyn)
         ctx.batched, ctx.glin_view = batched, glin_view
         ctx.has_token = token is not None
         ctx.save_for_backward(u, xres if enc else None, dsave, s, r1, lin, a2, None if batched else emb, gain, wd1, wd2,
@@ -597,7 +657,7 @@ class _ResBlockFn(torch.autograd.Function):
     def backward(ctx, gout):
         u, xn, dsave, s, r1, lin, a2, emb, gain, wd1, wd2, wd11, weh = ctx.saved_tensors
         blk, enc, has1 = ctx.blk, ctx.enc, ctx.has1
-        pdrop, seed, sub, step = ctx.drop
+        pdrop, seed, sub, step, dyn = ctx.drop
         gout = gout.contiguous()
         a, b = _mp_coeffs(blk.add_factor)
         # d loss / d lin goes (batched mode) into this block's column slice of the shared buffer; _EmbedAllFn.backward
@@ -610,11 +670,11 @@ class _ResBlockFn(torch.autograd.Function):
         if ops.FUSE_MOD and ops.IGEMM_VERSION == 0 and (gout.shape[1] * gout.shape[2]) % 32 == 0:
             # conv2's dgrad with the modulation backward in its epilogue: ga2 never touches HBM
             gr1, glin, ggain = ops.conv3x3_modbwd(gout, wd2, b, r1, lin, gain, pdrop, seed, sub, step, glin_out=glin_out,
-                                                     ggain_out=ggain_out)
+                                                     ggain_out=ggain_out, dyn=dyn)
         else:
             ga2 = ops.conv_igemm(gout, wd2, 9, alpha=b)
             gr1, glin, ggain = ops.mod_silu_drop_bwd(r1, lin, gain, ga2, pdrop, seed, sub, step, glin_out=glin_out,
-                                                        ggain_out=ggain_out)
+                                                        ggain_out=ggain_out, dyn=dyn)
         if gdirect:
             ggain = None
             for hook in getattr(gp, "_edm_hooks", ()):
@@ -953,6 +1013,7 @@ class Denoiser(nn.Module):
     def forward(self, noisy_image: Tensor, sigma: Tensor, embedding: Tensor):
         if not noisy_image.is_cuda:
             raise RuntimeError("tinyedm_amd.Denoiser: inputs must be GPU tensors (there is no CPU path)")
+        reset_backward_state()
         with torch.no_grad():
             self._prep_all()
         noisy = noisy_image.float().contiguous()

@@ -38,7 +38,10 @@ class _prof:
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    s = torch.cuda.current_stream()
+    if s.device_index not in _lib._inited_devices:
+        _lib.init_device(s.device_index)
+    return ctypes.c_void_p(s.cuda_stream)
 
 
 _SIDE_STREAMS = {}
@@ -172,17 +175,26 @@ def _lin_view(lin, B, C, name):
     return lin.stride(0)
 
 
-def mod_silu_drop_fwd(r, lin, gain, pdrop, seed, sub, step):
+def _dyn(dyn):
+    """device edm_step_params record (48 bytes) or None"""
+    if dyn is None:
+        return None
+    if not dyn.is_cuda or dyn.numel() * dyn.element_size() < 48 or not dyn.is_contiguous():
+        raise ValueError("dyn: expected a contiguous device buffer of >= 48 bytes (edm_step_params)")
+    return ctypes.c_void_p(dyn.data_ptr())
+
+
+def mod_silu_drop_fwd(r, lin, gain, pdrop, seed, sub, step, dyn=None):
     B, H, W, C = _nhwc(r, "r")
     ls = _lin_view(lin, B, C, "lin")
     _chk(gain, f32, "gain")
     a = torch.empty_like(r)
     _lib.call("edm_mod_silu_drop_fwd", _p(r), _p(lin), ls, _p(gain), _p(a), B, H * W, C, float(pdrop), int(seed), int(sub),
-              int(step), _stream())
+              int(step), _dyn(dyn), _stream())
     return a
 
 
-def mod_silu_drop_bwd(r, lin, gain, ga, pdrop, seed, sub, step, glin_out=None, ggain_out=None):
+def mod_silu_drop_bwd(r, lin, gain, ga, pdrop, seed, sub, step, glin_out=None, ggain_out=None, dyn=None):
     """glin_out: optional (B, C) strided fp32 view to receive d loss / d lin (else a fresh tensor);
     ggain_out: optional 0-dim fp32 tensor that d loss / d gain is ACCUMULATED into (else a fresh zero scalar)."""
     B, H, W, C = _nhwc(r, "r")
@@ -194,7 +206,7 @@ def mod_silu_drop_bwd(r, lin, gain, ga, pdrop, seed, sub, step, glin_out=None, g
     gs = _lin_view(glin, B, C, "glin")
     ggain = zeros_f32((), r.device) if ggain_out is None else _chk(ggain_out, f32, "ggain_out", ())
     _lib.call("edm_mod_silu_drop_bwd", _p(r), _p(lin), ls, _p(gain), _p(ga), _p(gr), _p(gm), _p(glin), gs, _p(ggain), B,
-              H * W, C, float(pdrop), int(seed), int(sub), int(step), _stream())
+              H * W, C, float(pdrop), int(seed), int(sub), int(step), _dyn(dyn), _stream())
     return gr, glin, ggain
 
 
@@ -407,7 +419,7 @@ def conv_igemm(x, wp, taps, residual=None, alpha=1.0, beta=0.0):
 FUSE_MOD = os.environ.get("EDM_FUSE_MOD", "1") != "0"
 
 
-def conv3x3_mod(x, wp, lin, gain, pdrop, seed, sub, step, want_u=True):
+def conv3x3_mod(x, wp, lin, gain, pdrop, seed, sub, step, want_u=True, dyn=None):
     """First 3x3 conv of a block with the modulation epilogue fused: returns (u, a2) with u = conv(x) (None when
     want_u is False) and a2 = dropout(mp_silu(u*(lin*gain+1))) -- same values as conv_igemm + mod_silu_drop_fwd."""
     B, H, W, Cin = _nhwc(x, "x")
@@ -424,11 +436,11 @@ def conv3x3_mod(x, wp, lin, gain, pdrop, seed, sub, step, want_u=True):
     pname = "conv3x3_igemm" + (_v4_suffix(entry, npix, Cout) if entry == "edm_conv_igemm_v4" else "")
     with _prof(pname, 2.0 * npix * Cin * Cout * 9, 2.0 * (npix * (Cin + Cout * (2 if want_u else 1)) + wp.numel())):
         _lib.call("edm_conv3x3_mod", _p(x), _p(wp), _p(u), _p(a2), _p(lin), ls, _p(gain), float(pdrop), int(seed),
-                  int(sub), int(step), B, H, W, Cin, Cout, _stream())
+                  int(sub), int(step), B, H, W, Cin, Cout, _dyn(dyn), _stream())
     return u, a2
 
 
-def conv3x3_modbwd(gout, wd, alpha, r1, lin, gain, pdrop, seed, sub, step, glin_out=None, ggain_out=None):
+def conv3x3_modbwd(gout, wd, alpha, r1, lin, gain, pdrop, seed, sub, step, glin_out=None, ggain_out=None, dyn=None):
     """dgrad of a block's second 3x3 conv with the modulation backward in its epilogue: returns (gr1, glin, ggain),
     the values conv_igemm(gout, wd, 9, alpha=alpha) followed by mod_silu_drop_bwd would give (H*W % 32 == 0)."""
     B, H, W, Cin = _nhwc(gout, "gout")
@@ -451,7 +463,7 @@ def conv3x3_modbwd(gout, wd, alpha, r1, lin, gain, pdrop, seed, sub, step, glin_
     pname = "conv3x3_igemm" + (_v4_suffix(entry, npix, Cout) if entry == "edm_conv_igemm_v4" else "") + "_modbwd"
     with _prof(pname, 2.0 * npix * Cin * Cout * 9, 2.0 * (npix * (Cin + 2 * Cout) + wd.numel())):
         _lib.call("edm_conv3x3_modbwd", _p(gout), _p(wd), float(alpha), _p(r1), _p(lin), ls, _p(gain), _p(gr), _p(gm),
-                  float(pdrop), int(seed), int(sub), int(step), B, H, W, Cin, Cout, _stream())
+                  float(pdrop), int(seed), int(sub), int(step), B, H, W, Cin, Cout, _dyn(dyn), _stream())
     _lib.call("edm_mod_finish", _p(gm), _p(lin), ls, _p(gain), _p(glin), gs, _p(ggain), B, Cout, _stream())
     return gr, glin, ggain
 
@@ -504,6 +516,55 @@ def conv_wgrad(x, dy, taps):
         fn = "edm_conv_wgrad_v2" if (WGRAD_VERSION == 2 and taps == 9 and W <= 126) else "edm_conv_wgrad"
         _lib.call(fn, _p(x), _p(dy), _p(slabs), B, H, W, Cin, Cout, taps, S, _stream())
     return slabs
+
+
+def wgrad3_supported(x, dy, I):
+    """shapes the grouped 3x3 weight-gradient path (csrc/conv_wgrad3.hip) covers"""
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[-1]
+    return Cin % 32 == 0 and Cout % 32 == 0 and W <= 126 and I * 9 * 4 <= 64 * 1024 and B * (H + 1) * (W + 1) < (1 << 30)
+
+
+def wgrad3_group(items):
+    """Weight gradients of up to 16 3x3 conv layers in ONE stream-K launch + ONE finish launch.
+    items: sequence of (x, dy, w, grad, perm, scale, accumulate) with x (B,H,W,Cin) / dy (B,H,W,Cout) NHWC bf16,
+    w the fp32 master weight (Cout, I, 3, 3) with I <= Cin, grad an fp32 tensor like w that receives (accumulate=0)
+    or accumulates (1) the projected gradient, perm the optional packed-row permutation (int32)."""
+    n = len(items)
+    if not 0 < n <= 16:
+        raise ValueError("wgrad3_group: 1..16 layers per group")
+    arr = (_lib.WGrad3Item * n)()
+    flops = nbytes = 0.0
+    halo = None
+    for k, (x, dy, w, grad, perm, scale, accumulate) in enumerate(items):
+        B, H, W, Cin = _nhwc(x, "x")
+        Bd, Hd, Wd, Cout = _nhwc(dy, "dy")
+        if (Bd, Hd, Wd) != (B, H, W):
+            raise ValueError("wgrad3_group: x/dy spatial mismatch")
+        _chk(w, f32, "w")
+        if w.dim() != 4 or w.shape[0] != Cout or tuple(w.shape[2:]) != (3, 3) or w.shape[1] > Cin:
+            raise ValueError(f"wgrad3_group: weight {tuple(w.shape)} does not match Cout={Cout}, Cin={Cin}")
+        _chk(grad, f32, "grad", w.shape)
+        if not wgrad3_supported(x, dy, w.shape[1]):
+            raise ValueError(f"wgrad3_group: unsupported shape x={tuple(x.shape)} dy={tuple(dy.shape)}")
+        if perm is not None:
+            _chk(perm, torch.int32, "perm", (Cout,))
+        h = W + 2 > 64
+        if halo is not None and h != halo:
+            raise ValueError("wgrad3_group: layers of one group must be all W <= 62 or all W > 62")
+        halo = h
+        arr[k] = _lib.WGrad3Item(x.data_ptr(), dy.data_ptr(), w.data_ptr(), grad.data_ptr(),
+                                 None if perm is None else perm.data_ptr(), B, H, W, Cin, Cout, w.shape[1], float(scale),
+                                 int(bool(accumulate)))
+        flops += 2.0 * B * H * W * Cin * Cout * 9
+        nbytes += 2.0 * B * H * W * (Cin + Cout) + 4.0 * w.numel()
+    nb = _lib.call("edm_wgrad3_workspace", ctypes.byref(arr), n)
+    if nb <= 0:
+        raise _lib.HipKernelError(f"edm_wgrad3_workspace failed: {_lib.lib().edm_last_error().decode()}")
+    work = torch.empty(nb // 4, device=items[0][0].device, dtype=f32)
+    with _prof("conv3x3_wgrad", flops, nbytes):
+        _lib.call("edm_wgrad3_group", ctypes.byref(arr), n, _p(work), nb, _stream())
+    return work
 
 
 # ------------------------------------------------------------------ weights
@@ -661,13 +722,13 @@ def embed_combine_bwd(gout, pre, labels, add_factor, wcls_shape):
 
 
 # ------------------------------------------------------------------ step-level kernels
-def diffuse(clean, P_mean, P_std, seed, step):
+def diffuse(clean, P_mean, P_std, seed, step, dyn=None):
     _chk(clean, f32, "clean")
     B = clean.shape[0]
     noisy = torch.empty_like(clean)
     sigma = torch.empty(B, device=clean.device, dtype=f32)
     _lib.call("edm_diffuse", _p(clean), _p(noisy), _p(sigma), float(P_mean), float(P_std), B, clean.numel() // B, int(seed),
-              int(step), _stream())
+              int(step), _dyn(dyn), _stream())
     return noisy, sigma
 
 
@@ -683,7 +744,8 @@ def diffuse_given(clean, eps, noise, P_mean, P_std):
     return noisy, sigma
 
 
-def weighted_mse(D, clean, sigma, sigma_data, weight=None, want_grad=True):
+def weighted_mse(D, clean, sigma, sigma_data, weight=None, want_grad=True, acc_sum=None, acc_total=None):
+    """acc_sum (fp32, 1 element) / acc_total (int64, 1 element): the metric's epoch state, accumulated in the same pass"""
     _chk(D, f32, "D")
     _chk(clean, f32, "clean", D.shape)
     B = D.shape[0]
@@ -693,12 +755,15 @@ def weighted_mse(D, clean, sigma, sigma_data, weight=None, want_grad=True):
         _chk(sigma, f32, "sigma", (B,))
     loss = zeros_f32((), D.device)
     dD = torch.empty_like(D) if want_grad else None
+    if acc_sum is not None:
+        _chk(acc_sum, f32, "acc_sum")
+        _chk(acc_total, torch.int64, "acc_total")
     _lib.call("edm_weighted_mse", _p(D), _p(clean), _p(sigma), _p(weight), float(sigma_data), _p(loss), _p(dD), B,
-              D.numel() // B, _stream())
+              D.numel() // B, _p(acc_sum), _p(acc_total), _stream())
     return loss, dD
 
 
-def adam_ema(theta, grad, m, v, ema, lr, b1, b2, eps, step, ema_beta, grad_scale=1.0):
+def adam_ema(theta, grad, m, v, ema, lr, b1, b2, eps, step, ema_beta, grad_scale=1.0, dyn=None, zero_grad=False):
     for t, nme in ((theta, "theta"), (grad, "grad"), (m, "m"), (v, "v")):
         _chk(t, f32, nme)
         if t.numel() != theta.numel():
@@ -706,7 +771,7 @@ def adam_ema(theta, grad, m, v, ema, lr, b1, b2, eps, step, ema_beta, grad_scale
     if ema is not None:
         _chk(ema, f32, "ema")
     _lib.call("edm_adam_ema", _p(theta), _p(grad), _p(m), _p(v), _p(ema), theta.numel(), float(lr), float(b1), float(b2),
-              float(eps), int(step), float(ema_beta), float(grad_scale), _stream())
+              float(eps), int(step), float(ema_beta), float(grad_scale), _dyn(dyn), int(bool(zero_grad)), _stream())
 
 
 def heun_euler(x, D, t0, t1):
