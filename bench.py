@@ -96,9 +96,21 @@ def train_bench(args, rank, world, device):
         opt.zero_grad()
         return loss
 
+    # One GPU: the whole step (fwd + bwd + Adam/EMA, side stream included) is replayed from a hipGraph; the
+    # per-step scalars come from a device record (tinyedm_amd/graph.py).  N > 1: the collective-bearing step stays
+    # eager (RCCL all-reduces issued from autograd hooks, overlapped with the backward pass).
+    eager_step = step
+    use_graph = world == 1 and not args.no_graph and not reducer.active
+    if use_graph:
+        from tinyedm_amd.graph import CapturedTrainStep
+        captured = CapturedTrainStep(model, opt)
+
+        def step(i):                            # noqa: F811
+            return captured(batch)
+
     opt.zero_grad()
-    note(f"model built, warmup {args.warmup} steps")
-    for i in range(args.warmup):
+    note(f"model built, warmup {args.warmup} steps" + (" (hipGraph-captured step)" if use_graph else ""))
+    for i in range(max(args.warmup, 3 if use_graph else 0)):
         loss = step(i)
     torch.cuda.synchronize()
     note(f"warmup done, timing {args.steps} steps")
@@ -133,7 +145,7 @@ def train_bench(args, rank, world, device):
         _nets.WGRAD_STREAM = saved and overlapped
         if rank == 0:
             ops.PROFILE = {}
-        step(args.warmup + args.steps + (0 if overlapped else 1))
+        eager_step(args.warmup + args.steps + (0 if overlapped else 1))
         torch.cuda.synchronize()
         _nets.WGRAD_STREAM = saved
         if rank == 0:
@@ -150,7 +162,7 @@ def train_bench(args, rank, world, device):
         for name, recs in over.items():
             if name in roof:
                 roof[name]["ms_overlapped"] = sum(s.elapsed_time(e) for s, e, _, _ in recs)
-    return model, B * world * args.steps / dt, dt / args.steps * 1e3, final_loss, roof
+    return model, B * world * args.steps / dt, dt / args.steps * 1e3, final_loss, roof, use_graph
 
 
 def sampler_bench(args, model, device):
@@ -222,6 +234,7 @@ def main():
     ap.add_argument("--sampler-batch", type=int, default=512)
     ap.add_argument("--sampler-iters", type=int, default=2)
     ap.add_argument("--no-sampler", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="time the eager Python step instead of the hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=20, help="timed CPU-oracle steps (~0.5 s each on 16 threads)")
@@ -239,15 +252,19 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    # EDM_FORCE_REDUCE=1 (tests/test_rccl_gpu.py): run the RCCL path -- process group, broadcast, hook-driven bucket
+    # all-reduces on the comm stream -- even with one rank, so a one-GPU box executes it
+    forced = os.environ.get("EDM_FORCE_REDUCE") == "1"
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if one_device:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    model, ips, ms, final_loss, roof = train_bench(args, rank, world, device)
+    model, ips, ms, final_loss, roof, used_graph = train_bench(args, rank, world, device)
     out = None
     if rank == 0:
         # dominant kernel: k_conv3x3_v4<5,0> (3x3 implicit GEMM of the 32x32 layers: forward convs, with the modulation
@@ -264,7 +281,10 @@ def main():
             "config": {"workload": "CIFAR-10 32x32 unconditional EDM2 U-Net (conf/cifar10.yaml, 35.6M params) "
                                    "full training step: diffuse+embed+denoiser fwd/bwd+loss+grad all-reduce+Adam+EMA",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}", "conditional": bool(args.conditional), "final_loss": final_loss},
+                       "parallelism": f"dp{world}", "conditional": bool(args.conditional), "final_loss": final_loss,
+                       "step_launch": "hipGraph replay" if used_graph else "eager",
+                       "collective": ("rccl all-reduce (forced, 1 rank)" if forced else "rccl bucketed all-reduce")
+                       if (world > 1 or forced) else "none"},
             "roofline": {
                 "bound": "mfma", "kernel": "k_conv3x3_v4<5,0,4> (3x3 implicit-GEMM conv of the 32x32 layers: forward, incl. fused modulation "
                                            "epilogue, and plain dgrad)",
@@ -290,7 +310,7 @@ def main():
             out["sampler"]["mfma_frac"] = round(out["sampler"]["img_per_s"] * 63 * FWD_GFLOP_PER_IMG / 1e3 / MFMA_PEAK_TFLOPS, 4)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -78,3 +78,48 @@ def test_bucketed_allreduce_matches_single_process():
         assert torch.allclose(theta, arena.theta)                       # broadcast from rank 0
         assert torch.allclose(g0, arena.grad, rtol=1e-5, atol=1e-6)
         assert torch.allclose(g1, arena.grad, rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------- bf16 transport
+def _worker_bf16(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tinyedm_amd.ddp import GradReducer
+    from tinyedm_amd.ema import FlatArena
+    res = {}
+    for transport in ("fp32", "bf16"):
+        model = _model()
+        arena = FlatArena(list(model.parameters()))
+        red = GradReducer(arena, bucket_bytes=2048, transport=transport)
+        red.broadcast_parameters()
+        red.broadcast_buffers(model)
+        g = torch.Generator().manual_seed(321)
+        X, Y = torch.randn(8, 16, generator=g), torch.randn(8, 4, generator=g)
+        arena.zero_grad()
+        torch.nn.functional.mse_loss(model(X[rank * 4:(rank + 1) * 4]), Y[rank * 4:(rank + 1) * 4]).backward()
+        scale = red.finish()
+        res[transport] = (arena.grad * scale).clone().numpy()
+    q.put((rank, res["fp32"], res["bf16"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_gradient_transport_is_equivalent_to_fp32_up_to_bf16_rounding():
+    """GradReducer(transport="bf16"): half the bytes on the wire; each element is rounded to bf16 before the sum and
+    the sum once more, so it equals the fp32 all-reduce to ~2^-8 relative (and is identical on every rank)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_bf16, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    f0, b0 = torch.from_numpy(res[0][1]), torch.from_numpy(res[0][2])
+    f1, b1 = torch.from_numpy(res[1][1]), torch.from_numpy(res[1][2])
+    assert torch.equal(f0, f1) and torch.equal(b0, b1)                    # replicas agree bit for bit
+    rel = ((b0 - f0).norm() / f0.norm()).item()
+    assert 0 < rel <= 2 ** -7, rel
+    assert (b0 - f0).abs().max() <= 2 ** -6 * f0.abs().max()

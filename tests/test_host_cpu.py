@@ -97,3 +97,98 @@ def test_qkv_permutation_is_a_bijection():
     assert sorted(p.tolist()) == list(range(768))
     # packed (head 1, k, dd 5) -> reference channel 1*192 + 5*3 + 1
     assert p[1 * 192 + 1 * 64 + 5].item() == 192 + 15 + 1
+
+
+# ---------------------------------------------------------------------------------------------- round 2: boundary
+def test_random_noise_datamodule_has_the_reference_signature():
+    """datamodules/random_datamodule.py:22-29: (batch_size, num_workers, image_size, num_samples, num_classes)"""
+    import inspect
+    from tinyedm_amd.datamodules import RandomNoiseDataModule
+    names = list(inspect.signature(RandomNoiseDataModule.__init__).parameters)[1:6]
+    assert names == ["batch_size", "num_workers", "image_size", "num_samples", "num_classes"]
+    dm = RandomNoiseDataModule(16, 8, 64, 100, 1000, in_channels=4)
+    assert dm.image_shape == (4, 64, 64) and dm.num_classes == 1000 and dm.num_samples == 100
+
+
+def test_generate_cli_flags_match_the_reference():
+    """generate.py:50-96: flag names (argparse would exit on an unknown one)"""
+    import io
+    import contextlib
+    from tinyedm_amd import generate as G
+    buf = io.StringIO()
+    with pytest.raises(SystemExit), contextlib.redirect_stdout(buf):
+        G.main(["--help"])
+    text = buf.getvalue()
+    for flag in ("--ckpt_path", "--load_ema", "--output_dir", "--num_samples", "--image_size", "--num_classes",
+                 "--batch_size", "--num_workers", "--num_steps"):
+        assert flag in text, flag
+    import tinyedm.generate                                   # the reference's module path
+    assert tinyedm.generate.generate is G.generate
+
+
+def test_epoch_order_shards_like_a_distributed_sampler():
+    """every rank used to iterate the same indices.  Shards are disjoint, cover the dataset, have equal
+    length on every rank and share one permutation per epoch."""
+    from tinyedm_amd.datamodules import _ResidentLoader, epoch_order, shard_len
+    n, world = 1003, 4
+    for epoch in (0, 1):
+        shards = [epoch_order(n, True, 42, epoch, r, world, "cpu") for r in range(world)]
+        assert all(len(s) == shard_len(n, world) == 251 for s in shards)
+        allidx = torch.cat(shards)
+        assert set(allidx.tolist()) == set(range(n))                      # covers the dataset
+        assert len(allidx) - len(set(allidx.tolist())) == world * 251 - n  # only the wrapped tail repeats
+        single = epoch_order(n, True, 42, epoch, 0, 1, "cpu")
+        assert torch.equal(torch.stack([s[:250] for s in shards], 1).flatten(), single[:1000])   # rank::world striding
+    assert not torch.equal(epoch_order(n, True, 42, 0, 0, 1, "cpu"), epoch_order(n, True, 42, 1, 0, 1, "cpu"))
+    assert torch.equal(epoch_order(10, False, 0, 0, 1, 2, "cpu"), torch.tensor([1, 3, 5, 7, 9]))
+    data = torch.zeros(1003, 3, 4, 4, dtype=torch.uint8)
+    lens = {len(_ResidentLoader(data, torch.zeros(1003), 32, True, False, 1, 0.5, 0.5, rank=r, world=4)) for r in range(4)}
+    assert lens == {(251 + 31) // 32}                                     # == ceil(ceil(N / world) / B) on every rank
+
+
+def test_model_checkpoint_keeps_top_k():
+    from tinyedm_amd.callbacks import ModelCheckpoint
+    import tempfile
+
+    class FakeTrainer:
+        global_rank, global_step, current_epoch = 0, 0, 0
+        callback_metrics = {}
+
+        def save_checkpoint(self, path, model=None):
+            open(path, "w").write("x")
+    with tempfile.TemporaryDirectory() as d:
+        cb = ModelCheckpoint(dirpath=d, monitor="val_loss", mode="min", save_top_k=2, save_last=True, every_n_epochs=2)
+        tr = FakeTrainer()
+        for epoch, loss in enumerate([5.0, 4.0, 3.0, 9.0, 8.0, 1.0, 7.0, 2.0]):
+            tr.current_epoch, tr.global_step = epoch, 10 * (epoch + 1)
+            tr.callback_metrics = {"val_loss": loss}
+            cb.on_validation_end(tr, None)
+        kept = sorted(os.listdir(d))
+        # epochs 1,3,5,7 are eligible (every 2): losses 4, 9, 1, 2 -> top-2 = epochs 5 and 7
+        assert kept == ["epoch=5-step=60.ckpt", "epoch=7-step=80.ckpt", "last.ckpt"], kept
+        assert cb.best_model_score == 1.0 and cb.best_model_path.endswith("epoch=5-step=60.ckpt")
+
+
+def test_reference_yaml_sections_instantiate():
+    """Every `_target_` of the shipped configs -- the same keys as the reference's YAMLs, including
+    `lightning.pytorch.callbacks.ModelCheckpoint` -- resolves; when the reference tree is present (build container
+    only) its own three YAMLs are loaded unchanged too."""
+    from tinyedm.config import compose, instantiate
+    import tinyedm
+    dirs = [os.path.join(ROOT, "experiments", "conf")]
+    ref = "/root/reference/experiments/conf"
+    if os.path.isdir(ref):
+        dirs.append(ref)
+    for d in dirs:
+        for name in sorted(f[:-5] for f in os.listdir(d) if f.endswith(".yaml")):
+            cfg = compose(name, d)
+            cbs = instantiate(cfg.callbacks)
+            kinds = {type(c).__name__ for c in cbs.values()}
+            assert "ModelCheckpoint" in kinds and kinds & {"GenerateCallback", "LatentsGenerateCallback"}, (d, name, kinds)
+            dm = instantiate(cfg.datamodule)
+            assert hasattr(dm, "train_dataloader") or hasattr(dm, "setup")
+            tr = tinyedm.Trainer(callbacks=list(cbs.values()), **cfg.trainer)
+            assert tr.max_epochs == cfg.trainer.max_epochs
+            if name != "imagenet":                       # 272.9 M parameters on the CPU: constructed in the GPU tests
+                model = instantiate(cfg.model)
+                assert isinstance(model, tinyedm.EDM) and model.hparams["_target_"] == "tinyedm.edm.EDM"

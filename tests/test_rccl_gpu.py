@@ -1,0 +1,107 @@
+"""The RCCL code path on ONE GPU: a one-rank "nccl" process group (RCCL on ROCm) with the reducer's hooks forced on
+(GradReducer(force=True) / EDM_FORCE_REDUCE=1), so the bucket all-reduces are launched from the weight-gradient
+hooks DURING the backward pass on the comm stream, behind the side stream of the weight-gradient kernels, exactly as
+with N ranks -- a sum over one rank must leave the gradients unchanged.  Also: broadcast of parameters and buffers,
+bf16 transport through RCCL, and bench.py / Trainer.fit end to end through init_process_group("nccl").
+The N > 1 scaling curve itself can only be measured by the driver on a multi-GPU node (reference:
+experiments/conf/cifar10.yaml:4-8 devices -1 / strategy auto = DDP over NCCL)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(port, q):
+    try:
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                          HSA_ENABLE_IPC_MODE_LEGACY="0")
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_graph_gpu import _build
+        from tinyedm_amd.ddp import GradReducer
+        import tinyedm_amd as T
+        g = torch.Generator().manual_seed(5)
+        x = (0.5 * torch.randn(8, 3, 16, 16, generator=g)).to(dev)
+        y = torch.randint(0, 10, (8,), generator=g).to(dev)
+        out = {}
+        for mode in ("plain", "fp32", "bf16"):
+            model, _ = _build()
+            base = model.configure_optimizers()["optimizer"]
+            red = GradReducer(base.arena, bucket_bytes=1 << 20, force=(mode != "plain"),
+                              transport="bf16" if mode == "bf16" else "fp32")
+            red.broadcast_parameters()
+            red.broadcast_buffers(model)
+            launched = []
+            orig = red._launch
+            red._launch = lambda b, _o=orig: (launched.append(b["lo"]), _o(b))[1]
+            base.zero_grad()
+            T.manual_seed(11)
+            loss = model.training_step((x, y), 0)
+            loss.backward()
+            during_backward = len(launched)
+            scale = red.finish()
+            torch.cuda.synchronize()
+            out[mode] = dict(grad=base.arena.grad.clone().cpu(), n_buckets=len(red.buckets), during=during_backward,
+                             total=len(launched), scale=scale, active=red.active)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put(("ok", out))
+    except Exception as e:          # noqa: BLE001
+        import traceback
+        q.put(("err", traceback.format_exc()))
+
+
+def test_forced_reduce_runs_rccl_allreduce_from_hooks_on_one_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(_free_port(), q))
+    p.start()
+    status, out = q.get(timeout=600)
+    p.join(120)
+    assert status == "ok", out
+    assert p.exitcode == 0
+    plain, f32, b16 = out["plain"], out["fp32"], out["bf16"]
+    assert not plain["active"] and plain["total"] == 0
+    assert f32["active"] and f32["n_buckets"] > 1 and f32["scale"] == 1.0
+    # every bucket was all-reduced, most of them from hooks while the backward pass was still running (overlap)
+    assert f32["total"] == f32["n_buckets"] and f32["during"] >= f32["n_buckets"] - 1, (f32["during"], f32["n_buckets"])
+    rel = ((f32["grad"] - plain["grad"]).norm() / plain["grad"].norm()).item()
+    assert rel <= 1e-5, rel                                           # sum over one rank: identity (fp32 atomics noise)
+    relb = ((b16["grad"] - plain["grad"]).norm() / plain["grad"].norm()).item()
+    assert 1e-5 < relb <= 2 ** -7, relb                               # bf16 wire format: one rounding per element
+
+
+def test_bench_and_fit_through_the_nccl_backend_on_one_gpu(tmp_path):
+    """bench.py with EDM_FORCE_REDUCE=1: init_process_group("nccl"), broadcast, hook-driven bucket all-reduces on
+    the comm stream every step (eager step: the collectives are issued from autograd hooks), one JSON line out."""
+    env = dict(os.environ, EDM_FORCE_REDUCE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--batch", "16",
+                        "--no-sampler", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["collective"] == "rccl all-reduce (forced, 1 rank)"
+    assert line["config"]["step_launch"] == "eager"

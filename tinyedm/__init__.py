@@ -6,7 +6,8 @@ import tinyedm_amd as _impl
 from tinyedm_amd import *  # noqa: F401,F403
 from tinyedm_amd import config, edm, ema, metric, networks, solvers, utils  # noqa: F401
 
-for _name in ("config", "edm", "ema", "metric", "networks", "solvers", "utils", "trainer", "datamodules", "callbacks"):
+for _name in ("config", "edm", "ema", "metric", "networks", "solvers", "utils", "trainer", "datamodules", "callbacks",
+              "generate", "graph"):
     try:
         _mod = __import__(f"tinyedm_amd.{_name}", fromlist=["_"])
     except ImportError:

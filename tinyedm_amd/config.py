@@ -85,7 +85,18 @@ def to_container(cfg) -> Any:
     return cfg
 
 
+# `_target_` paths of the reference's YAMLs that name classes of packages absent here (lightning): resolved to the
+# stand-ins of this build, so conf/*.yaml of the reference instantiate unchanged
+_ALIASES = {
+    "lightning.pytorch.callbacks.ModelCheckpoint": "tinyedm_amd.callbacks.ModelCheckpoint",
+    "lightning.pytorch.callbacks.model_checkpoint.ModelCheckpoint": "tinyedm_amd.callbacks.ModelCheckpoint",
+    "lightning.Trainer": "tinyedm_amd.trainer.Trainer",
+    "lightning.pytorch.Trainer": "tinyedm_amd.trainer.Trainer",
+}
+
+
 def _locate(target: str):
+    target = _ALIASES.get(target, target)
     mod, _, name = target.rpartition(".")
     parts = target.split(".")
     for i in range(len(parts) - 1, 0, -1):

@@ -67,10 +67,27 @@ class SyntheticImageDataModule:
 
 
 class RandomNoiseDataModule:
-    def __init__(self, batch_size: int, num_samples: int, image_shape=(3, 32, 32), num_classes: int | None = None,
-                 seed: int = 0, device: str | None = None):
-        self.batch_size, self.num_samples, self.image_shape = batch_size, num_samples, tuple(image_shape)
-        self.num_classes, self.seed, self.device = num_classes, seed, device
+    """datamodules/random_datamodule.py:21-45, same positional order (batch_size, num_workers, image_size,
+    num_samples, num_classes).  Extensions are keyword-only: `in_channels` (the reference hard-codes 3),
+    `image_shape` (overrides in_channels/image_size), `seed`, `device`.  num_workers is accepted and ignored."""
+
+    def __init__(self, batch_size: int, num_workers: int, image_size: int, num_samples: int,
+                 num_classes: int | None, *, in_channels: int = 3, image_shape=None, seed: int = 0,
+                 device: str | None = None):
+        self.batch_size, self.num_workers, self.image_size = batch_size, num_workers, image_size
+        self.num_samples, self._num_classes = num_samples, num_classes
+        self.image_shape = tuple(image_shape) if image_shape is not None else (in_channels, image_size, image_size)
+        self.seed, self.device = seed, device
+
+    @property
+    def num_classes(self):
+        return self._num_classes
+
+    def prepare_data(self):
+        pass
+
+    def setup(self, stage=None):
+        pass
 
     def predict_dataloader(self):
         dev = torch.device(self.device) if self.device else torch.device("cuda", torch.cuda.current_device())
@@ -132,29 +149,59 @@ def read_mnist(data_dir: str, train: bool):
     return x, y
 
 
-class _ResidentLoader:
-    """Batches gathered on the device from a resident uint8 dataset; shuffled per epoch with torch.randperm."""
+def _rank_world(rank=None, world=None):
+    """this process's (rank, world size): explicit arguments, else torch.distributed, else the launcher's env"""
+    if rank is not None and world is not None:
+        return int(rank), int(world)
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return torch.distributed.get_rank(), torch.distributed.get_world_size()
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
-    def __init__(self, data_u8, labels, batch_size, shuffle, flip, seed, mean, std):
+
+def shard_len(n: int, world: int) -> int:
+    """samples per rank: ceil(n / world) -- every rank runs the same number of steps (short shards wrap around)"""
+    return (n + world - 1) // world
+
+
+def epoch_order(n: int, shuffle: bool, seed: int, epoch: int, rank: int, world: int, device):
+    """Index tensor of the samples rank `rank` sees in epoch `epoch`: ONE permutation shared by all ranks (seeded by
+    (seed, epoch) only), padded by wrapping to a multiple of `world`, then strided rank::world -- the index sets of
+    the ranks are disjoint (up to the <= world-1 wrapped samples) and together cover the dataset, which is what
+    Lightning's DistributedSampler gives the reference's DataLoaders."""
+    if shuffle:
+        g = torch.Generator(device=device).manual_seed(seed * 1000003 + epoch)
+        order = torch.randperm(n, device=device, generator=g)
+    else:
+        order = torch.arange(n, device=device)
+    if world > 1:
+        total = shard_len(n, world) * world
+        if total > n:
+            order = torch.cat([order, order[: total - n]])
+        order = order[rank::world]
+    return order
+
+
+class _ResidentLoader:
+    """Batches gathered on the device from a resident uint8 dataset; shuffled per epoch with torch.randperm
+    (same permutation on every rank), each rank taking its `rank::world` share (DistributedSampler semantics)."""
+
+    def __init__(self, data_u8, labels, batch_size, shuffle, flip, seed, mean, std, rank=None, world=None):
         self.data, self.labels, self.batch_size = data_u8, labels, batch_size
         self.shuffle, self.flip, self.seed, self.mean, self.std = shuffle, flip, seed, mean, std
+        self.rank, self.world = _rank_world(rank, world)
         self.epoch = 0
 
     def __len__(self):
-        return (self.data.shape[0] + self.batch_size - 1) // self.batch_size
+        return (shard_len(self.data.shape[0], self.world) + self.batch_size - 1) // self.batch_size
 
     def __iter__(self):
         from . import ops
-        n, dev = self.data.shape[0], self.data.device
-        if self.shuffle:
-            g = torch.Generator(device=dev).manual_seed(self.seed * 1000003 + self.epoch)
-            order = torch.randperm(n, device=dev, generator=g)
-        else:
-            order = torch.arange(n, device=dev)
+        order = epoch_order(self.data.shape[0], self.shuffle, self.seed, self.epoch, self.rank, self.world,
+                            self.data.device)
         for bi in range(len(self)):
             idx = order[bi * self.batch_size:(bi + 1) * self.batch_size].contiguous()
             x = ops.u8_gather_normalize(self.data, idx, self.mean, self.std, flip=self.flip,
-                                        seed=self.seed, epoch=self.epoch * 65536 + bi)
+                                        seed=self.seed + 7919 * self.rank, epoch=self.epoch * 65536 + bi)
             yield x, self.labels[idx]
         self.epoch += 1
 
@@ -252,19 +299,15 @@ class MNISTDataModule(AbstractDataModule):
 
 
 class _LatentLoader:
-    def __init__(self, lat, lab, batch_size, shuffle, seed):
+    def __init__(self, lat, lab, batch_size, shuffle, seed, rank=None, world=None):
         self.lat, self.lab, self.batch_size, self.shuffle, self.seed, self.epoch = lat, lab, batch_size, shuffle, seed, 0
+        self.rank, self.world = _rank_world(rank, world)
 
     def __len__(self):
-        return (self.lat.shape[0] + self.batch_size - 1) // self.batch_size
+        return (shard_len(self.lat.shape[0], self.world) + self.batch_size - 1) // self.batch_size
 
     def __iter__(self):
-        n, dev = self.lat.shape[0], self.lat.device
-        if self.shuffle:
-            g = torch.Generator(device=dev).manual_seed(self.seed * 1000003 + self.epoch)
-            order = torch.randperm(n, device=dev, generator=g)
-        else:
-            order = torch.arange(n, device=dev)
+        order = epoch_order(self.lat.shape[0], self.shuffle, self.seed, self.epoch, self.rank, self.world, self.lat.device)
         for bi in range(len(self)):
             idx = order[bi * self.batch_size:(bi + 1) * self.batch_size]
             yield self.lat[idx], self.lab[idx]

@@ -10,6 +10,7 @@ ranks is folded into the fused optimizer kernel's ``grad_scale`` instead of a di
 """
 from __future__ import annotations
 
+import os
 from typing import List
 
 import torch
@@ -22,10 +23,21 @@ def _aux_streams():
 
 
 class GradReducer:
-    def __init__(self, arena, bucket_bytes: int = 32 << 20, process_group=None):
+    """`transport`: "fp32" (default) all-reduces the arena slices in place; "bf16" sends a bf16 copy of each bucket
+    (half the xGMI bytes; the sum of `world` bf16 values is then rounded to bf16 once more: ~2^-8 relative per
+    element) and writes the fp32 result back.  `force=True` (or EDM_FORCE_REDUCE=1) registers the hooks and runs the
+    collectives even in a one-rank group, so a single GPU exercises the whole comm-stream path through RCCL."""
+
+    def __init__(self, arena, bucket_bytes: int = 32 << 20, process_group=None, transport: str = None, force=None):
         self.arena = arena
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if force is None:
+            force = os.environ.get("EDM_FORCE_REDUCE") == "1"
+        self.active = self.world > 1 or (bool(force) and dist.is_initialized())
+        self.transport = transport or os.environ.get("EDM_GRAD_TRANSPORT", "fp32")
+        if self.transport not in ("fp32", "bf16"):
+            raise ValueError("GradReducer: transport must be 'fp32' or 'bf16'")
         self.enabled = True                      # False during non-final gradient-accumulation micro-batches
         self.is_cuda = arena.grad.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.is_cuda else None
@@ -47,7 +59,7 @@ class GradReducer:
             for idx in b["params"]:
                 self._bucket_of[idx] = b
         self._hooks = []
-        if self.world > 1:
+        if self.active:
             for idx, p in enumerate(arena.params):
                 hook = self._make_hook(idx)
                 self._hooks.append(p.register_post_accumulate_grad_hook(hook))
@@ -76,6 +88,13 @@ class GradReducer:
                 self._launch(b)
         return hook
 
+    def _reduce(self, b, view):
+        if self.transport == "bf16":
+            b["wire"] = view.to(torch.bfloat16)
+            b["work"] = dist.all_reduce(b["wire"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            b["work"] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def _launch(self, b):
         view = self.arena.grad[b["lo"]:b["hi"]]
         if self.is_cuda:
@@ -83,19 +102,28 @@ class GradReducer:
             for s in _aux_streams():          # gradients finished on the side stream (networks._wgrad)
                 self.comm_stream.wait_stream(s)
             with torch.cuda.stream(self.comm_stream):
-                b["work"] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._reduce(b, view)
         else:
-            b["work"] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._reduce(b, view)
 
     def finish(self) -> float:
         """Wait for every bucket (launching any whose hooks never fired, e.g. unused parameters) and
         return the scale (1/world) the optimizer must apply to the summed gradients."""
-        if self.world > 1:
+        if self.active:
             for b in self.buckets:
                 if b["work"] is None:
                     self._launch(b)
             for b in self.buckets:
-                b["work"].wait()
+                if self.is_cuda:
+                    with torch.cuda.stream(self.comm_stream):
+                        b["work"].wait()      # orders the comm stream behind the collective (no host block on RCCL)
+                        if self.transport == "bf16":
+                            self.arena.grad[b["lo"]:b["hi"]].copy_(b["wire"])
+                else:
+                    b["work"].wait()
+                    if self.transport == "bf16":
+                        self.arena.grad[b["lo"]:b["hi"]].copy_(b["wire"])
+                b["wire"] = None
             if self.is_cuda:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.reset()
@@ -103,5 +131,13 @@ class GradReducer:
 
     def broadcast_parameters(self, src: int = 0):
         """DDP's initial parameter broadcast: one collective over the parameter arena."""
-        if self.world > 1:
+        if self.active:
             dist.broadcast(self.arena.theta, src=src, group=self.group)
+
+    def broadcast_buffers(self, model, src: int = 0):
+        """DDP's initial buffer broadcast (the random `freqs` / `phases` of the Fourier embedding, networks.py:127-131):
+        ranks must not depend on equal seeds to agree on them."""
+        if self.active:
+            for name, buf in model.named_buffers():
+                if buf.numel() > 0 and buf.is_floating_point() and not name.endswith(("weighted_sum_squared_error",)):
+                    dist.broadcast(buf.data, src=src, group=self.group)

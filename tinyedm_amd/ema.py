@@ -95,16 +95,46 @@ class FusedAdam(torch.optim.Optimizer):
         bump_weight_epoch()
         return loss
 
+    @torch.no_grad()
+    def step_dyn(self, dyn: torch.Tensor, ema: Optional[torch.Tensor] = None):
+        """The same update with lr / bias corrections / ema_beta / grad_scale read from the device record `dyn`
+        (edm_step_params) and the gradient arena cleared in the same pass: the form a captured step replays
+        (graph.CapturedTrainStep owns the host-side counters)."""
+        g = self.param_groups[0]
+        self.arena.rebind_grads()
+        ops.adam_ema(self.arena.theta, self.arena.grad, self.m, self.v, ema, g["lr"], g["betas"][0], g["betas"][1],
+                     g["eps"], max(1, self.step_count), 0.0, 1.0, dyn=dyn, zero_grad=True)
+
     def state_dict(self):
         return {"m": self.m, "v": self.v, "step": self.step_count,
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
-        self.m.copy_(sd["m"])
-        self.v.copy_(sd["v"])
-        self.step_count = sd["step"]
+        """Accepts this class's own layout ({m, v, step}: flat arenas) or torch.optim.Adam's
+        ({state: {i: {step, exp_avg, exp_avg_sq}}, param_groups}: what the reference's checkpoints hold)."""
+        if "m" in sd:
+            self.m.copy_(sd["m"])
+            self.v.copy_(sd["v"])
+            self.step_count = int(sd["step"])
+        elif "state" in sd:
+            a = self.arena
+            if len(sd["state"]) not in (0, len(a.params)):
+                raise ValueError(f"optimizer state has {len(sd['state'])} entries, the model {len(a.params)} parameters")
+            steps = []
+            for i, (p, o) in enumerate(zip(a.params, a.offsets)):
+                st = sd["state"].get(i)
+                if st is None:
+                    continue
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state {i}: shape {tuple(st['exp_avg'].shape)} != parameter {tuple(p.shape)}")
+                self.m[o:o + p.numel()].view_as(p).copy_(st["exp_avg"])
+                self.v[o:o + p.numel()].view_as(p).copy_(st["exp_avg_sq"])
+                steps.append(int(st["step"]))
+            self.step_count = max(steps) if steps else 0
+        else:
+            raise KeyError("optimizer state dict has neither this build's {m, v, step} nor torch Adam's {state, param_groups}")
         for g, s in zip(self.param_groups, sd["param_groups"]):
-            g.update(s)
+            g.update({k: v for k, v in s.items() if k != "params"})
 
 
 class EMAOptimizer:

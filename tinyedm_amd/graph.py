@@ -1,0 +1,165 @@
+"""The whole training step as ONE hipGraph.
+
+An eager step enqueues ~400 kernels from Python (autograd.Function bodies + ctypes): ~10-14 ms of host time per
+step, i.e. the host, not the GPU, sets the step time once the kernels are fast.  Capturing
+`training_step -> backward -> (gradient all-reduce) -> fused Adam+EMA` into a hipGraph and replaying it removes that
+cost: a step is one input copy, one 48-byte parameter upload and one graph launch.  The side stream of the
+weight-gradient kernels is captured as a parallel branch of the graph.
+
+What changes between replays cannot be a by-value kernel argument (those are frozen at capture time), so the
+per-step scalars -- Philox step/seed of dropout and the Diffuser, learning rate, EMA beta, Adam bias corrections,
+1/world -- live in a device `edm_step_params` record (include/tinyedm_hip.h) that `StepParams.upload` rewrites from a
+pinned host ring before every replay; the kernels read it through their `dyn` argument.
+
+Reference call sites this replaces: the Lightning automatic-optimisation loop around `EDM.training_step`
+(edm.py:205-236), `optim.Adam(fused=True).step` (edm.py:251) and `EMAOptimizer.step` (ema.py:229-291).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import networks, ops
+from .ema import EMAOptimizer, FusedAdam
+
+
+class StepParams:
+    """Device `edm_step_params` record + a ring of pinned host copies (so the host never rewrites a slot whose
+    asynchronous upload has not executed yet)."""
+
+    WORDS = 12      # 48 bytes
+
+    def __init__(self, device, slots: int = 16):
+        self.dev = torch.zeros(self.WORDS, dtype=torch.int32, device=device)
+        self.host = torch.zeros(slots, self.WORDS, dtype=torch.int32).pin_memory()
+        self._u = self.host.numpy().view(np.uint32)
+        self._f = self.host.numpy().view(np.float32)
+        self._events = [None] * slots
+        self._i = 0
+
+    def upload(self, *, step: int, seed: int, lr: float, ema_beta: float, grad_scale: float, bc1: float, bc2sqrt: float):
+        k = self._i % len(self._events)
+        self._i += 1
+        if self._events[k] is not None:
+            self._events[k].synchronize()
+        u, f = self._u[k], self._f[k]
+        u[0] = step & 0xFFFFFFFF
+        u[1] = seed & 0xFFFFFFFF
+        u[2] = (seed >> 32) & 0xFFFFFFFF
+        f[4], f[5], f[6], f[7], f[8] = lr, ema_beta, grad_scale, bc1, bc2sqrt
+        self.dev.copy_(self.host[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._events[k] = ev
+
+
+class CapturedTrainStep:
+    """`loss = step(batch)`: one optimisation step of `model` (an EDM) under `optimizer` (FusedAdam, optionally inside
+    an EMAOptimizer), replayed from a hipGraph captured on the first call with a given batch shape.
+
+    `reducer` (GradReducer): world size 1 only -- the collective-bearing step of a multi-GPU run stays eager (its
+    RCCL calls are issued from autograd hooks).  Semantics equal the eager sequence
+        loss = model.training_step(batch, i); loss.backward(); optimizer.step(); optimizer.zero_grad()
+    including the host-side counters (Philox step, Adam step, EMA step, weight epoch)."""
+
+    WARMUP = 2
+
+    def __init__(self, model, optimizer, grad_scale: float = 1.0):
+        self.model = model
+        self.opt = optimizer
+        self.base = optimizer.optimizer if isinstance(optimizer, EMAOptimizer) else optimizer
+        if not isinstance(self.base, FusedAdam):
+            raise TypeError("CapturedTrainStep needs the flat-arena FusedAdam")
+        self.ema = optimizer if isinstance(optimizer, EMAOptimizer) else None
+        self.grad_scale = grad_scale
+        self.params = StepParams(self.base.arena.theta.device)
+        # warm-up steps and the capture run on ONE dedicated stream: autograd's AccumulateGrad nodes remember the
+        # stream they were created on, and a node left over from a default-stream step would pull the default
+        # stream into the capture (unjoined at capture end)
+        self.stream = torch.cuda.Stream(self.base.arena.theta.device)
+        self._graphs = {}
+        self._calls = 0
+
+    # ---- host-side bookkeeping identical to the eager path
+    def _upload(self):
+        g = self.base.param_groups[0]
+        t = self.base.step_count + 1
+        b1, b2 = g["betas"]
+        beta = 1.0          # ema = 1*ema + 0*theta: the step leaves the EMA untouched
+        if self.ema is not None and self.ema._should_update_at_step():
+            beta = (1 - 1 / (self.ema.current_step + 1)) ** (self.ema.gamma + 1)
+        self.params.upload(step=networks.rng.step, seed=networks.rng.seed, lr=float(g["lr"]), ema_beta=float(beta),
+                           grad_scale=float(self.grad_scale), bc1=1.0 - b1 ** t, bc2sqrt=math.sqrt(1.0 - b2 ** t))
+
+    def _advance(self):
+        self.base.step_count += 1
+        if self.ema is not None:
+            self.ema.current_step += 1
+        networks.rng.step += 1
+        networks.bump_weight_epoch()
+
+    def _snapshot(self):
+        return (self.base.step_count, self.ema.current_step if self.ema is not None else 0, networks.rng.step)
+
+    def _restore(self, snap):
+        self.base.step_count, cs, networks.rng.step = snap
+        if self.ema is not None:
+            self.ema.current_step = cs
+
+    def _eager(self, batch):
+        """one step through the ordinary Python path, driven by the same device parameter record"""
+        snap = self._snapshot()
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            loss = self.model.training_step(batch, 0)
+            loss.backward()
+            self.base.step_dyn(self.params.dev, ema=self.ema.ema_arena if self.ema is not None else None)
+            loss = loss.detach()        # drop the autograd graph (and with it the AccumulateGrad nodes) now
+        cur.wait_stream(self.stream)
+        self._restore(snap)
+        return loss
+
+    def __call__(self, batch):
+        x, y = batch
+        key = (tuple(x.shape), x.dtype, None if y is None else (tuple(y.shape), y.dtype))
+        self._upload()
+        networks.rng.dyn = self.params.dev
+        try:
+            ent = self._graphs.get(key)
+            if ent is None and self._calls < self.WARMUP:
+                loss = self._eager(batch)          # allocator / plan / stream warm-up before capturing
+            else:
+                if ent is None:
+                    ent = self._graphs[key] = self._capture(batch)
+                graph, sx, sy, loss = ent
+                sx.copy_(x, non_blocking=True)
+                if sy is not None:
+                    sy.copy_(y, non_blocking=True)
+                graph.replay()
+        finally:
+            networks.rng.dyn = None
+        self._calls += 1
+        self._advance()
+        return loss
+
+    def _capture(self, batch):
+        x, y = batch
+        sx = x.clone()
+        sy = None if y is None else y.clone()
+        snap = self._snapshot()
+        torch.cuda.synchronize()
+        ops.capture_begin()
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph, stream=self.stream):
+                loss = self.model.training_step((sx, sy), 0)
+                loss.backward()
+                self.base.step_dyn(self.params.dev, ema=self.ema.ema_arena if self.ema is not None else None)
+                loss = loss.detach()
+        finally:
+            ops.capture_end()
+            self._restore(snap)
+        return graph, sx, sy, loss

@@ -207,7 +207,7 @@ def _wgrad(mod, x, dy, taps, scale=1.0):
         g = torch.empty_like(w.data)
         ops.wgrad3_group([(x, dy, w.data, g, mod._perm, scale, False)])
         return g
-    if direct and not torch.cuda.is_current_stream_capturing():
+    if direct:
         _run_on_side(w.device, lambda: mod.finish_grad(ops.conv_wgrad(x, dy, taps), scale=scale), (x, dy))
         _queue_backward_end(w.device)
         return None

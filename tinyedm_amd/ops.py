@@ -68,8 +68,9 @@ class _ZeroPool:
     One training step needs ~110 such tensors; a `torch.zeros` each is a fill launch each.  The pool zeroes a
     16 MiB chunk with ONE fill and hands out disjoint 256-byte-aligned pieces; a chunk is never reused (pieces keep
     its storage alive), so lifetime rules are those of ordinary tensors.  Pieces are fresh tensors on the shared
-    storage, not views, so they do not share autograd version counters.  During stream capture every request is
-    a real `torch.zeros` (a captured graph must re-zero its accumulators on every replay)."""
+    storage, not views, so they do not share autograd version counters.  A captured graph must re-zero its
+    accumulators on every replay: `capture_begin()` / `capture_end()` drop the current chunk, so every chunk used
+    inside a capture is allocated -- and its ONE fill recorded -- inside that capture."""
     CHUNK = 1 << 22  # floats
 
     def __init__(self):
@@ -80,7 +81,7 @@ class _ZeroPool:
         for d in shape:
             n *= int(d)
         n_al = (n + 63) // 64 * 64
-        if n_al > self.CHUNK // 4 or torch.cuda.is_current_stream_capturing():
+        if n_al > self.CHUNK // 4:
             return torch.zeros(shape, device=device, dtype=f32)
         if self.buf is None or self.off + n_al > self.CHUNK or self.buf.device != device:
             self.buf, self.off = torch.zeros(self.CHUNK, device=device, dtype=f32), 0
@@ -94,6 +95,14 @@ _zero_pool = _ZeroPool()
 
 def zeros_f32(shape, device):
     return _zero_pool.take(tuple(shape), device)
+
+
+def capture_begin():
+    """call right before a stream capture starts (and capture_end() right after it ends)"""
+    _zero_pool.buf = None
+
+
+capture_end = capture_begin
 
 
 def _p(t: Optional[torch.Tensor]):

@@ -66,10 +66,21 @@ class DeterministicSolver:
                 self._loop(model, sx, sl, t_dev)
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = self._loop(model, sx, sl, t_dev)
+            ops.capture_begin()
+            try:
+                with torch.cuda.graph(g):
+                    out = self._loop(model, sx, sl, t_dev)
+            finally:
+                ops.capture_end()
             ent = self._graphs[key] = (g, sx, sl, out, t_dev)
         g, sx, sl, out, _ = ent
+        # the captured evaluations read the persistent eval-mode weight packs: refresh them (a no-op unless the
+        # master weights changed since the last solve: optimizer steps, EMA swap, load_state_dict) before replaying
+        if isinstance(model, torch.nn.Module):
+            from .networks import Denoiser
+            for m in model.modules():
+                if isinstance(m, Denoiser) and not m.training:
+                    m._prep_all()
         sx.copy_(x0)
         if sl is not None:
             sl.copy_(class_labels)

@@ -77,15 +77,30 @@ class Trainer:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.reducer: Optional[GradReducer] = None
         self.datamodule = None
+        self.callback_metrics: dict = {}
+        self._resume_skip = 0          # batches of the first epoch already consumed before the checkpoint was written
+        # one GPU, no gradient accumulation: the step is replayed from a hipGraph (EDM_GRAPH=0 keeps the eager loop)
+        self.use_graph = os.environ.get("EDM_GRAPH", "1") != "0"
 
     # ------------------------------------------------------------------ setup
     def _setup_distributed(self, model):
-        if self.world_size > 1 and not dist.is_initialized():
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-            dist.init_process_group(backend)
         if torch.cuda.is_available():
             torch.cuda.set_device(self.local_rank)
+        if self.world_size > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if torch.cuda.is_available():
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group("gloo")
+        if torch.cuda.is_available():
             model.to(torch.device("cuda", self.local_rank))
+        if self.world_size > 1:
+            # every rank built the model from the same seed; the Philox streams (Diffuser noise, dropout) must differ
+            # per rank or all ranks would noise their different shards with identical draws
+            from . import networks
+            if not getattr(self, "_rank_seeded", False):
+                networks.rng.seed = (networks.rng.seed + 0x9E3779B97F4A7C15 * self.global_rank) & 0xFFFFFFFFFFFFFFFF
+                self._rank_seeded = True
 
     def _call(self, hook: str, *args):
         for cb in self.callbacks:
@@ -114,6 +129,7 @@ class Trainer:
         if isinstance(base, FusedAdam):
             self.reducer = GradReducer(base.arena)
             self.reducer.broadcast_parameters()
+            self.reducer.broadcast_buffers(model)
 
     # ------------------------------------------------------------------ fit
     def fit(self, model, datamodule=None, train_dataloaders=None, val_dataloaders=None, ckpt_path=None):
@@ -123,6 +139,9 @@ class Trainer:
         if datamodule is not None and hasattr(datamodule, "setup"):
             datamodule.setup("fit")
         self._call("on_fit_start", model)
+        start_epoch = 0
+        if ckpt_path is not None:                 # resume (reference: experiments/train.py:30-33)
+            start_epoch = self.load_checkpoint(ckpt_path, model)
         self._call("on_train_start", model)
         train = train_dataloaders if train_dataloaders is not None else datamodule.train_dataloader()
         val = val_dataloaders
@@ -132,22 +151,39 @@ class Trainer:
         base = opt.optimizer if isinstance(opt, EMAOptimizer) else opt
         model.train()
         opt.zero_grad()
-        done = False
+        captured = None
+        if (self.use_graph and self.world_size == 1 and self.accumulate_grad_batches == 1 and isinstance(base, FusedAdam)
+                and torch.cuda.is_available()):
+            from .graph import CapturedTrainStep
+            captured = CapturedTrainStep(model, opt)
+        done = 0 < self.max_steps <= self.global_step
         t0, imgs = time.time(), 0
-        for epoch in range(self.max_epochs):
+        for epoch in range(start_epoch, self.max_epochs):
+            if done:
+                break
             self.current_epoch = epoch
+            if hasattr(train, "epoch"):
+                train.epoch = epoch               # resident loaders: the shuffle is a function of (seed, epoch)
             for bi, batch in enumerate(train):
+                if self._resume_skip > 0:         # mid-epoch checkpoint: these batches were consumed before it
+                    self._resume_skip -= 1
+                    continue
+                self._batch_in_epoch = bi + 1
                 batch = _to_device(batch, model.device)
                 last_micro = (bi + 1) % self.accumulate_grad_batches == 0
-                if self.reducer is not None:
-                    self.reducer.enabled = last_micro
-                loss = model.training_step(batch, bi)
-                (loss / self.accumulate_grad_batches).backward()
                 imgs += batch[0].shape[0] * self.world_size
+                if captured is not None:
+                    loss = captured(batch)
+                else:
+                    if self.reducer is not None:
+                        self.reducer.enabled = last_micro
+                    loss = model.training_step(batch, bi)
+                    (loss / self.accumulate_grad_batches).backward()
+                    if last_micro:
+                        base.grad_scale = self.reducer.finish() if self.reducer is not None else 1.0
+                        opt.step()
+                        opt.zero_grad()
                 if last_micro:
-                    base.grad_scale = self.reducer.finish() if self.reducer is not None else 1.0
-                    opt.step()
-                    opt.zero_grad()
                     self.global_step += 1
                     if self.scheduler_interval == "step":
                         self.lr_scheduler.step()
@@ -157,13 +193,17 @@ class Trainer:
                     if 0 < self.max_steps <= self.global_step:
                         done = True
                         break
+            self._batch_in_epoch = 0
             if self.scheduler_interval == "epoch":
                 self.lr_scheduler.step()
+            if hasattr(model, "train_mse") and int(model.train_mse.total) > 0:
+                self.callback_metrics["train_loss"] = float(model.train_mse.compute())
+                model.train_mse.reset()
+            self._epoch_complete = True
             self._call("on_train_epoch_end", model)
             if val is not None and (epoch + 1) % self.check_val_every_n_epoch == 0:
                 self.validate(model, val)
-            if done:
-                break
+            self._epoch_complete = False
         self._call("on_fit_end", model)
 
     @torch.no_grad()
@@ -174,29 +214,58 @@ class Trainer:
             model.val_mse.reset()
         for bi, batch in enumerate(val):
             model.validation_step(_to_device(batch, model.device), bi)
+        out = model.val_mse.compute() if hasattr(model, "val_mse") else None
+        if out is not None:
+            self.callback_metrics["val_loss"] = float(out)
+        self._call("on_validation_epoch_end", model)
         model.train()
         self._call("on_validation_end", model)
-        return model.val_mse.compute() if hasattr(model, "val_mse") else None
+        return out
 
     # ------------------------------------------------------------------ checkpoints
     def save_checkpoint(self, path, model=None):
         """Writes the Lightning checkpoint keys the reference's `EDM.load_from_checkpoint` reads (edm.py:159-203):
         `state_dict`, `hyper_parameters` (deinstantiated config, utils.py:5-27) and `optimizer_states[0]["ema"]`."""
+        from . import networks
         model = model if model is not None else self._model
         ckpt = {"state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
                 "hyper_parameters": dict(model.hparams), "epoch": self.current_epoch, "global_step": self.global_step,
-                "optimizer_states": [_cpu_tree(o.state_dict()) for o in self.optimizers]}
+                "optimizer_states": [_cpu_tree(o.state_dict()) for o in self.optimizers],
+                "lr_schedulers": [self.lr_scheduler.state_dict()] if hasattr(self.lr_scheduler, "state_dict") else [],
+                # what Lightning keeps in its loop state / torch RNG state: where in the epoch the run was, and the
+                # counter-based RNG position (the Philox streams are a pure function of (seed, step))
+                "tinyedm_amd": {"rng_seed": networks.rng.seed, "rng_step": networks.rng.step,
+                                "epoch_complete": bool(getattr(self, "_epoch_complete", False)),
+                                "batch_in_epoch": int(getattr(self, "_batch_in_epoch", 0))}}
         if self.global_rank == 0:
             torch.save(ckpt, path)
         return ckpt
 
-    def load_checkpoint(self, path, model):
-        """Resume: weights, optimizer (Adam moments, EMA) and counters."""
+    def load_checkpoint(self, path, model) -> int:
+        """Resume from a checkpoint written by `save_checkpoint` (or by the reference: Lightning key layout): weights,
+        optimizer (Adam moments in this build's flat layout or torch.optim.Adam's per-parameter layout, EMA), LR
+        scheduler, counters and RNG position.  Must run after the optimizers exist (fit() calls it after
+        on_fit_start).  Returns the epoch to continue with."""
+        from . import networks
         ckpt = torch.load(path, map_location="cpu", weights_only=False)
         model.load_state_dict(ckpt["state_dict"], strict=False)
+        networks.bump_weight_epoch()
         for o, sd in zip(self.optimizers, ckpt.get("optimizer_states", [])):
             o.load_state_dict(sd)
+        for sd in ckpt.get("lr_schedulers", [])[:1]:
+            if hasattr(self.lr_scheduler, "load_state_dict"):
+                self.lr_scheduler.load_state_dict(sd)
         self.current_epoch, self.global_step = ckpt.get("epoch", 0), ckpt.get("global_step", 0)
+        priv = ckpt.get("tinyedm_amd", {})
+        if "rng_step" in priv:
+            networks.rng.seed, networks.rng.step = priv["rng_seed"], priv["rng_step"]
+        # Lightning semantics: a checkpoint written at the end of epoch e continues with epoch e+1; one written
+        # mid-epoch re-enters epoch e after the batches it had already consumed
+        if priv.get("epoch_complete", True):
+            self._resume_skip = 0
+            return self.current_epoch + 1
+        self._resume_skip = int(priv.get("batch_in_epoch", 0))
+        return self.current_epoch
 
     # ------------------------------------------------------------------ predict
     @torch.no_grad()
