@@ -33,11 +33,12 @@ def note(msg):
 
 
 def host_cores():
+    """threads for the CPU baseline: every core this process may run on (EDM_CPU_THREADS overrides)"""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    return max(1, min(n, int(os.environ.get("EDM_CPU_THREADS", "16"))))
+    return max(1, int(os.environ.get("EDM_CPU_THREADS", n)))
 
 # work per unit, CIFAR-10 config (SURVEY.md 8(d) / BASELINE.md 3)
 TRAIN_GFLOP_PER_IMG = 81.0
@@ -186,42 +187,55 @@ def sampler_bench(args, model, device):
 
 
 def cpu_baseline(args):
-    """Reference algorithm on the host cores: the CPU oracle's training step (fp32, plain torch CPU ops),
-    bounded to ~10-30 s of CPU work."""
+    """Reference algorithm on the host cores: the CPU oracle's training step (plain torch CPU ops: F.conv2d, SDPA
+    math, Adam + EMA; the same CIFAR-10 model, dropout 0.13 applied with F.dropout), fp32 and -- as the reference's
+    `precision: bf16-mixed` -- under torch.autocast("cpu", bfloat16).  Bounded: ~12 s per leg."""
     from oracle import edm_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
     note(f"cpu baseline on {cores} host threads")
     ecfg, dcfg = O.cifar10_cfg()
-    P = O.init_params(ecfg, dcfg, torch.Generator().manual_seed(1), gains_nonzero=True)
-    keys = O.trainable_keys(P)
-    for k in keys:
-        P[k].requires_grad_(True)
     B = args.cpu_batch
-    g = torch.Generator().manual_seed(42)
-    clean = 0.5 * torch.randn(B, 3, 32, 32, generator=g)
-    m = {k: torch.zeros_like(P[k]) for k in keys}
-    v = {k: torch.zeros_like(P[k]) for k in keys}
-    ema = {k: P[k].detach().clone() for k in keys}
-    times = []
-    budget_t0 = time.perf_counter()
-    for it in range(1 + args.cpu_steps):
-        t0 = time.perf_counter()
-        eps, noise = torch.randn(B, generator=g), torch.randn(B, 3, 32, 32, generator=g)
-        loss = O.training_loss(P, ecfg, dcfg, clean, eps, noise, -1.2, 1.2)
-        grads = torch.autograd.grad(loss, [P[k] for k in keys])
-        with torch.no_grad():
-            for k, gr in zip(keys, grads):
-                O.adam_step(P[k], gr, m[k], v[k], it + 1, 0.02)
-                O.ema_step(ema[k], P[k], O.ema_beta(it, 4.6036))
-        if it > 0:
-            times.append(time.perf_counter() - t0)
-        if time.perf_counter() - budget_t0 > 40 and times:
-            break
-    sec = sum(times) / len(times)
-    return {"value": B / sec, "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} fp32 training steps of the CPU oracle (oracle/edm_oracle.py), batch {B}, "
-                      f"same CIFAR-10 model, dropout off, {sec:.2f} s/step"}
+
+    def leg(autocast, budget_s):
+        P = O.init_params(ecfg, dcfg, torch.Generator().manual_seed(1), gains_nonzero=True)
+        keys = O.trainable_keys(P)
+        for k in keys:
+            P[k].requires_grad_(True)
+        g = torch.Generator().manual_seed(42)
+        clean = 0.5 * torch.randn(B, 3, 32, 32, generator=g)
+        m = {k: torch.zeros_like(P[k]) for k in keys}
+        v = {k: torch.zeros_like(P[k]) for k in keys}
+        ema = {k: P[k].detach().clone() for k in keys}
+        times = []
+        budget_t0 = time.perf_counter()
+        for it in range(1 + args.cpu_steps):
+            t0 = time.perf_counter()
+            eps, noise = torch.randn(B, generator=g), torch.randn(B, 3, 32, 32, generator=g)
+            with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+                loss = O.training_loss(P, ecfg, dcfg, clean, eps, noise, -1.2, 1.2)
+            grads = torch.autograd.grad(loss.float(), [P[k] for k in keys])
+            with torch.no_grad():
+                for k, gr in zip(keys, grads):
+                    O.adam_step(P[k], gr.float(), m[k], v[k], it + 1, 0.02)
+                    O.ema_step(ema[k], P[k], O.ema_beta(it, 4.6036))
+            if it > 0:
+                times.append(time.perf_counter() - t0)
+            if time.perf_counter() - budget_t0 > budget_s and times:
+                break
+        return sum(times) / len(times), len(times)
+
+    sec, n = leg(False, 12.0)
+    out = {"value": B / sec, "unit": "img/s", "cores": cores, "kind": "port",
+           "sample": f"{n} fp32 training steps of the CPU oracle (oracle/edm_oracle.py), batch {B}, same CIFAR-10 model, "
+                     f"dropout 0.13, {sec:.2f} s/step"}
+    try:
+        sec_bf, n_bf = leg(True, 12.0)
+        out["bf16_autocast"] = {"value": B / sec_bf, "unit": "img/s",
+                                "sample": f"{n_bf} steps under torch.autocast('cpu', bfloat16), {sec_bf:.2f} s/step"}
+    except Exception as e:          # noqa: BLE001  (a CPU without a usable bf16 path must not sink the bench line)
+        out["bf16_autocast"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
+    return out
 
 
 def main():
@@ -300,6 +314,9 @@ def main():
                 "algorithmic_gflop_per_step": round(conv["gflop"], 1),
                 "whole_step_mfma_frac": round(ips / world * TRAIN_GFLOP_PER_IMG / 1e3 / MFMA_PEAK_TFLOPS, 4),
                 "whole_step_hbm_frac": round(ips / world * 108.6e6 / 1e9 / HBM_PEAK_GBS, 4),
+                # BASELINE.json's literal "HBM-bound 3x3-conv roofline": 3x3-conv activation bytes only (59.7 MB per
+                # training image) over 8 TB/s; 70 % of it would need 7 PFLOP/s of bf16 MFMA (not reachable)
+                "northstar_hbm3x3_frac": round(ips / world * 59.7e6 / 1e9 / HBM_PEAK_GBS, 4),
                 "per_kernel": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in roof.items()},
             },
         }

@@ -143,7 +143,8 @@ int edm_dropout_mask(unsigned char* mask, long n, float pdrop, unsigned long lon
 /* 2x2 average pool / nearest-exact x2 (networks.py:80, 72); H,W = OUTPUT dims; scale folds the backward factors */
 int edm_pool2(const void* x, void* y, int B, int Hout, int Wout, int C, float scale, edm_stream_t stream);
 int edm_up2(const void* x, void* y, int B, int Hout, int Wout, int C, float scale, edm_stream_t stream);
-/* out[b,c] += scale * sum_hw x[b,hw,c] (* y[b,hw,c])  -- ScaleLong mean (networks.py:116) and its gate gradient */
+/* out[b,c] = scale * sum_hw x[b,hw,c] (* y[b,hw,c])  -- ScaleLong mean (networks.py:116) and its gate gradient;
+ * written, not accumulated, in a fixed summation order (bit-reproducible) */
 int edm_reduce_hw(const void* x, long x_stride, const void* y, long y_stride, float* out, int B, int HW, int C,
                   float scale, edm_stream_t stream);
 /* ScaleLong gate MLP (networks.py:112-118), fp32, per sample */

@@ -15,6 +15,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import edm_oracle as O
+from parity_log import record
 
 DEV = "cuda"
 
@@ -51,10 +52,10 @@ def mnist_cfg():
     return e, d
 
 
-def imagenet_cfg():
+def imagenet_cfg(channels=4):
     import tinyedm_amd.networks as N
     e = O.EmbeddingCfg(192, 768, 1000)
-    d = O.DenoiserCfg(4, 4, list(N.get_encoder_blocks_types()), list(N.get_decoder_blocks_types()),
+    d = O.DenoiserCfg(channels, channels, list(N.get_encoder_blocks_types()), list(N.get_decoder_blocks_types()),
                       list(N.get_encoder_out_channels()), list(N.get_decoder_out_channels()),
                       list(N.get_skip_connections()), dropout_rate=0.0, sigma_data=0.5, embedding_dim=768, num_heads=4)
     return e, d
@@ -77,6 +78,7 @@ def eval_parity(ecfg, dcfg, shape, seed, tol):
     c_skip, _, _ = O.precond_scalars(sigma, dcfg.sigma_data)
     base = c_skip * noisy
     r = rel(D.cpu() - base, D_or - base)
+    record(f"configs/eval_forward_vs_bf16_oracle[{tuple(shape)} emb{ecfg.embedding_dim}]", r, tol)
     assert r <= tol, f"eval forward rel {r:.3e}"
     return P, emb, den, (noisy, sigma, labels)
 
@@ -104,6 +106,7 @@ def train_smoke(emb, den, batch, P=None, ecfg=None, dcfg=None, loss_tol=None):
         _, eo = O.embedding_forward(Pb, ecfg, sigma, labels)
         Do = O.denoiser_forward(Pb, dcfg, noisy, sigma, eo, training=True, bf16=True)
         lo = O.weighted_mse((sigma ** 2 + 0.25) / (sigma * 0.5) ** 2, Do, noisy * 0.3)
+        record(f"configs/train_loss_vs_bf16_oracle[{tuple(noisy.shape)}]", abs(loss.item() - lo.item()) / abs(lo.item()), loss_tol)
         assert abs(loss.item() - lo.item()) <= loss_tol * abs(lo.item()), (loss.item(), lo.item())
 
 
@@ -126,6 +129,49 @@ def test_imagenet64_default_denoiser_forward_and_training_step():
     ecfg, dcfg = imagenet_cfg()
     P, emb, den, batch = eval_parity(ecfg, dcfg, (1, 4, 64, 64), seed=3, tol=2e-2)
     train_smoke(emb, den, batch)
+
+
+def test_imagenet64_pixel_config_training_step_loss_vs_oracle():
+    """BASELINE configs[3]: ImageNet-64 class-conditional PIXEL-space net (3 channels, 64x64, 272 M parameters):
+    eval forward and the training-mode loss against the oracle with the same bf16 rounding points; every parameter
+    receives a finite gradient."""
+    ecfg, dcfg = imagenet_cfg(channels=3)
+    P, emb, den, batch = eval_parity(ecfg, dcfg, (1, 3, 64, 64), seed=4, tol=2e-2)
+    train_smoke(emb, den, batch, P, ecfg, dcfg, loss_tol=3e-2)
+
+
+def test_latent32_hipgraph_32_step_sampler_matches_eager_loop():
+    """BASELINE configs[4], sampler leg: 32 Heun steps (63 evaluations) of the default 272 M-parameter net on
+    32x32x4 latents, captured as ONE hipGraph, against the eager loop (solvers.py:43-59)."""
+    import tinyedm_amd as T
+    ecfg, dcfg = imagenet_cfg()
+    P = O.init_params(ecfg, dcfg, torch.Generator().manual_seed(9))
+    emb, den = build(ecfg, dcfg, P)
+    emb.eval(); den.eval()
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.emb, self.den = emb, den
+
+        def forward(self, x, t, lab):
+            _, e = self.emb(t, lab)
+            return self.den(x, t, e)
+    model = Model().eval()
+    sol = T.DeterministicSolver(num_steps=32)
+    g = torch.Generator().manual_seed(2)
+    x0 = torch.randn(2, 4, 32, 32, generator=g).to(DEV)
+    lab = torch.randint(0, 1000, (2, 1), generator=g).to(DEV)
+    x_eager = sol.solve(model, x0, lab)
+    x_eager2 = sol.solve(model, x0, lab)
+    x_graph = sol.solve(model, x0, lab, graph=True)
+    x_replay = sol.solve(model, x0, lab, graph=True)
+    assert torch.isfinite(x_eager).all() and x_eager.abs().max() < 50
+    # the evaluation path is bit-reproducible (fixed summation orders, no float atomics): eager == eager == graph
+    assert torch.equal(x_eager2, x_eager), rel(x_eager2, x_eager)
+    r = rel(x_graph, x_eager)
+    record("configs/latent32_hipgraph_32step_vs_eager", r, 0.0)
+    assert torch.equal(x_graph, x_eager) and torch.equal(x_replay, x_eager), r
 
 
 def test_latent32_default_denoiser_forward():
@@ -159,4 +205,5 @@ def test_full_size_configs_match_reference_golden(golden_dir, name):
     base = c_skip * noisy
     r_hip, r_ref = rel(D - base, ref32 - base), rel(refbf - base, ref32 - base)
     print(f"{name}: HIP vs reference fp32 {r_hip:.3e}; reference's own bf16 autocast {r_ref:.3e}")
+    record(f"configs/{name}_vs_reference_fp32", r_hip, max(2.0 * r_ref, 5e-3))
     assert r_hip <= max(2.0 * r_ref, 5e-3)

@@ -1,0 +1,162 @@
+"""Oracle checks of the kernel instantiations the benchmark actually dispatches: the full-size
+layers -- B = 128, 32x32 (512x128-tile v4 kernel), 16x16 (512x64 tile) and 8x8 -- with their fused epilogues, each
+compared on images {0, 63, 127} of the batch against an fp64 evaluation of the SAME bf16 operands (reference:
+F.conv2d networks.py:37 and the elementwise chain networks.py:253-260 / 319-324 and its autograd), never against
+another HIP kernel; and the CIFAR-10 unconditional network at B = 128 against the oracle with bf16 rounding points."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import edm_oracle as O
+from parity_log import record
+
+DEV = "cuda"
+IMGS = [0, 63, 127]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tinyedm_amd import ops as _ops
+    return _ops
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+
+
+def rt(x):          # bf16 rounding, as a double tensor
+    return x.to(torch.bfloat16).double()
+
+
+def nchw64(x_nhwc):  # NHWC bf16 (any device) -> NCHW fp64 on the CPU
+    return x_nhwc.float().cpu().permute(0, 3, 1, 2).double()
+
+
+def _layer(B, HW, Cin, Cout, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, HW, HW, Cin, generator=g).to(torch.bfloat16)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)).to(torch.bfloat16)
+    wp = w.permute(2, 3, 0, 1).reshape(9, Cout, Cin).contiguous()
+    return x, w, wp
+
+
+def _conv64(x, w):   # fp64 conv of the chosen images, NCHW
+    return F.conv2d(nchw64(x[IMGS]), w.double(), padding=1)
+
+
+SHAPES = [(128, 32, 256, 256, "v4 512x128"), (128, 32, 512, 256, "v4 512x128"), (128, 16, 256, 256, "v4 512x64"),
+          (128, 8, 256, 256, "8x8")]
+
+
+@pytest.mark.parametrize("B,HW,Cin,Cout,kern", SHAPES)
+def test_full_size_conv_plain_and_residual(ops, B, HW, Cin, Cout, kern):
+    x, w, wp = _layer(B, HW, Cin, Cout, 1)
+    r = torch.randn(B, HW, HW, Cout, generator=torch.Generator().manual_seed(2)).to(torch.bfloat16)
+    ref = _conv64(x, w)
+    y = ops.conv_igemm(x.to(DEV), wp.to(DEV), 9)
+    e = rel(nchw64(y[IMGS]), ref)
+    record(f"fullsize/conv3x3[{kern} {Cin}->{Cout} {HW}x{HW}]", e, 4e-3)
+    assert e <= 4e-3, e
+    y2 = ops.conv_igemm(x.to(DEV), wp.to(DEV), 9, residual=r.to(DEV), alpha=0.7, beta=0.3)
+    e2 = rel(nchw64(y2[IMGS]), 0.7 * ref + 0.3 * nchw64(r[IMGS]))
+    record(f"fullsize/conv3x3+residual[{kern} {Cin}->{Cout} {HW}x{HW}]", e2, 4e-3)
+    assert e2 <= 4e-3, e2
+
+
+@pytest.mark.parametrize("B,HW,Cin,Cout,kern", SHAPES)
+def test_full_size_mod_epilogues_against_the_oracle_chain(ops, B, HW, Cin, Cout, kern):
+    """forward: u = conv(x) (bf16), a2 = dropout(mp_silu(u*(lin*gain+1)));  backward of the block's second conv with
+    the modulation backward in its epilogue: gr = d a2/d u applied to ga = alpha*conv(dy, wd), glin per sample.
+    Reference: the same chain in fp64 torch + autograd (the keep mask is data: the kernel's own Philox mask)."""
+    pdrop, seed, sub, step = 0.13, 1234, 7, 3
+    x, w, wp = _layer(B, HW, Cin, Cout, 3)
+    g = torch.Generator().manual_seed(4)
+    lin = torch.randn(B, Cout, generator=g)
+    gain = torch.tensor(0.6)
+    u, a2 = ops.conv3x3_mod(x.to(DEV), wp.to(DEV), lin.to(DEV), gain.to(DEV), pdrop, seed, sub, step, want_u=True)
+    mask = ops.dropout_mask(B * HW * HW * Cout, pdrop, seed, sub, step, DEV).view(B, HW, HW, Cout)
+    keep = mask[IMGS].cpu().permute(0, 3, 1, 2).double() / (1.0 - pdrop)
+    u_ref = _conv64(x, w)
+    e_u = rel(nchw64(u[IMGS]), u_ref)
+    m = (lin[IMGS].double() * gain.double() + 1.0).view(len(IMGS), Cout, 1, 1)
+    ub = rt(u_ref)                                       # the kernel modulates the bf16-rounded conv output
+    a2_ref = O.mp_silu(ub * m) * keep
+    e_a = rel(nchw64(a2[IMGS]), a2_ref)
+    record(f"fullsize/conv3x3_mod.u[{kern} {Cin}->{Cout} {HW}x{HW}]", e_u, 4e-3)
+    record(f"fullsize/conv3x3_mod.a2[{kern} {Cin}->{Cout} {HW}x{HW}]", e_a, 6e-3)
+    assert e_u <= 4e-3 and e_a <= 6e-3, (e_u, e_a)
+
+    # ---- backward: second conv of the block is Cout -> Cout; its dgrad feeds the modulation backward
+    gy = torch.randn(B, HW, HW, Cout, generator=g).to(torch.bfloat16)
+    w2 = (torch.randn(Cout, Cout, 3, 3, generator=g) / math.sqrt(Cout * 9)).to(torch.bfloat16)
+    wd = w2.flip(2, 3).permute(2, 3, 1, 0).reshape(9, Cout, Cout).contiguous()     # dgrad pack [8-tap][ci][co]
+    alpha = 0.55
+    r1 = u                                                # pre-activation saved by the forward
+    gr, glin, ggain = ops.conv3x3_modbwd(gy.to(DEV), wd.to(DEV), alpha, r1, lin.to(DEV), gain.to(DEV), pdrop, seed, sub, step)
+    ga_ref = alpha * F.conv_transpose2d(nchw64(gy[IMGS]), w2.double(), padding=1)  # dgrad of conv(.., w2)
+    ur = nchw64(u[IMGS]).requires_grad_(True)
+    linr = lin[IMGS].double().clone().requires_grad_(True)
+    a2_fn = O.mp_silu(ur * (linr * gain.double() + 1.0).view(len(IMGS), Cout, 1, 1)) * keep
+    a2_fn.backward(rt(ga_ref))                            # the kernel rounds ga to bf16 before the epilogue
+    e_gr = rel(nchw64(gr[IMGS]), ur.grad)
+    e_gl = rel(glin[IMGS].cpu(), linr.grad)
+    record(f"fullsize/conv3x3_modbwd.gr[{kern} {HW}x{HW}]", e_gr, 8e-3)
+    record(f"fullsize/conv3x3_modbwd.glin[{kern} {HW}x{HW}]", e_gl, 8e-3)
+    assert e_gr <= 8e-3 and e_gl <= 8e-3, (e_gr, e_gl)
+
+
+@pytest.mark.parametrize("B,HW,Cin,Cout,kern", SHAPES)
+def test_full_size_silubwd_epilogue(ops, B, HW, Cin, Cout, kern):
+    """dgrad of a decoder block's first conv with the mp_silu backward fused: gx = mp_silu'(xpre)*conv^T(g) + s*extra"""
+    g = torch.Generator().manual_seed(6)
+    gy = torch.randn(B, HW, HW, Cout, generator=g).to(torch.bfloat16)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)).to(torch.bfloat16)
+    wd = w.flip(2, 3).permute(2, 3, 1, 0).reshape(9, Cin, Cout).contiguous()
+    xpre = torch.randn(B, HW, HW, Cin, generator=g).to(torch.bfloat16)
+    extra = torch.randn(B, HW, HW, Cin, generator=g).to(torch.bfloat16)
+    gx = ops.conv3x3_silubwd(gy.to(DEV), wd.to(DEV), xpre.to(DEV), extra.to(DEV), 0.4)
+    gref = rt(F.conv_transpose2d(nchw64(gy[IMGS]), w.double(), padding=1))
+    xp = nchw64(xpre[IMGS]).requires_grad_(True)
+    O.mp_silu(xp).backward(gref)
+    ref = xp.grad + 0.4 * nchw64(extra[IMGS])
+    e = rel(nchw64(gx[IMGS]), ref)
+    record(f"fullsize/conv3x3_silubwd[{kern} {Cout}->{Cin} {HW}x{HW}]", e, 6e-3)
+    assert e <= 6e-3, e
+
+
+def test_cifar10_unconditional_forward_b128_vs_oracle():
+    """BASELINE configs[1] as benchmarked: CIFAR-10 unconditional U-Net (35.6 M parameters), batch 128, eval forward;
+    images {0, 63, 127} against O.edm_forward with the same bf16 rounding points (on D - c_skip*x)."""
+    import tinyedm_amd as T
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    ecfg, dcfg = O.cifar10_cfg()
+    P = O.init_params(ecfg, dcfg, torch.Generator().manual_seed(1), gains_nonzero=True)
+    emb = T.Embedding(ecfg.fourier_dim, ecfg.embedding_dim, ecfg.num_classes, ecfg.add_factor)
+    den = T.Denoiser(dcfg.in_channels, dcfg.out_channels, tuple(dcfg.encoder_block_types),
+                     tuple(dcfg.decoder_block_types), tuple(dcfg.encoder_out_channels),
+                     tuple(dcfg.decoder_out_channels), tuple(dcfg.skip_connections), dcfg.dropout_rate,
+                     dcfg.sigma_data, dcfg.encoder_add_factor, dcfg.decoder_add_factor, dcfg.embedding_dim, dcfg.num_heads)
+    emb.load_state_dict({k[len("embedding."):]: v for k, v in P.items() if k.startswith("embedding.")})
+    den.load_state_dict({k[len("denoiser."):]: v for k, v in P.items() if k.startswith("denoiser.")})
+    emb, den = emb.to(DEV).eval(), den.to(DEV).eval()
+    g = torch.Generator().manual_seed(12)
+    B = 128
+    clean = 0.5 * torch.randn(B, 3, 32, 32, generator=g)
+    sigma = (torch.randn(B, generator=g) * 1.2 - 1.2).exp()
+    noisy = clean + sigma.view(-1, 1, 1, 1) * torch.randn(B, 3, 32, 32, generator=g)
+    with torch.no_grad():
+        _, e = emb(sigma.to(DEV), None)
+        D = den(noisy.to(DEV), sigma.to(DEV), e).cpu()
+        D_or = O.edm_forward(P, ecfg, dcfg, noisy[IMGS], sigma[IMGS], None, bf16=True)
+    c_skip, _, _ = O.precond_scalars(sigma[IMGS], dcfg.sigma_data)
+    base = c_skip * noisy[IMGS]
+    err = rel(D[IMGS] - base, D_or - base)
+    record("fullsize/cifar10_uncond_B128_forward_vs_bf16_oracle", err, 1.5e-2)
+    assert err <= 1.5e-2, err

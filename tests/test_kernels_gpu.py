@@ -41,9 +41,12 @@ def rel(a, b):
 
 
 def close_bf16(y, ref, l2=4e-3, mx=1.5e-2):
+    import os
+    from parity_log import record
     ref = ref.double()
     y = y.double()
     assert torch.isfinite(y).all()
+    record("kernels/" + os.environ.get("PYTEST_CURRENT_TEST", "?").split("::")[-1].split(" ")[0], rel(y, ref), l2)
     assert rel(y, ref) <= l2, f"rel L2 {rel(y, ref):.3e}"
     assert (y - ref).abs().max().item() <= mx * ref.abs().max().item() + 1e-6, \
         f"max err {(y - ref).abs().max().item():.3e} vs scale {ref.abs().max().item():.3e}"

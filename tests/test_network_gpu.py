@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import edm_oracle as O
 from oracle.make_golden import tiny_cfgs, grad_digest
+from parity_log import record
 
 DEV = "cuda"
 
@@ -78,6 +79,8 @@ def test_eval_forward_matches_golden_and_oracle(tiny):
     # network part F*c_out (D - c_skip*x): compare on the residual so c_skip*x cannot hide errors
     c_skip, _, _ = O.precond_scalars(sigma, dcfg.sigma_data)
     base = c_skip * noisy
+    record("tiny_net/eval_D_vs_bf16_oracle", rel(D.cpu() - base, D_or - base), 1e-2)
+    record("tiny_net/eval_D_vs_reference_fp32", rel(D.cpu() - base, ref32 - base), max(2.0 * rel(refbf - base, ref32 - base), 5e-3))
     assert rel(D.cpu() - base, D_or - base) <= 1e-2, rel(D.cpu() - base, D_or - base)
     assert rel(D.cpu() - base, ref32 - base) <= max(2.0 * rel(refbf - base, ref32 - base), 5e-3)
     # unconditional and scalar-sigma call patterns (solvers.py:48)
@@ -136,6 +139,8 @@ def test_training_step_grads_match_golden_and_oracle(tiny):
         gn = float(g["grad_digest"][i][1])
         assert abs(gr.double().norm().item() - gn) <= 5e-2 * gn + 1e-6, f"{k}: |g| {gr.norm().item()} vs {gn}"
     print("worst per-tensor grad rel err vs bf16 oracle:", worst)
+    record("tiny_net/worst_param_grad_vs_bf16_oracle", worst, 6e-2)
+    record("tiny_net/train_loss_vs_reference", abs(loss.item() - float(g["train_loss"])) / abs(float(g["train_loss"])), 3e-2)
 
 
 def test_blocks_match_golden(golden_dir):
@@ -169,6 +174,35 @@ def test_blocks_match_golden(golden_dir):
         assert rel(y, T_(g[tag + "::y"])) <= 2e-2, (tag, rel(y, T_(g[tag + "::y"])))
 
 
+def test_blocks64_match_reference_golden(golden_dir):
+    """Every block flavour -- plain / down / up / attention / widening 1x1 / skip + ScaleLong gate (+attention, +up) --
+    on the HIP path against the reference's own module output (oracle/make_golden_blocks64.py): 64 channels, head dim
+    32, 8x8 maps.  Bar: no worse than 2x the reference's OWN bf16-autocast deviation from its fp32 output, floor 1e-2."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import tinyedm_amd as T
+    from oracle.make_golden_blocks64 import SPECS
+    from test_oracle_golden import _blocks64_case
+    from parity_log import record
+    g = np.load(os.path.join(golden_dir, "blocks64.npz"))
+    emb = T_(g["emb"]).to(DEV)
+    for tag, kind, cin, cout, skip, resample, attn, hw, seed in SPECS:
+        if kind == "enc":
+            m = T.networks.EncoderBlock(cin, cout, 64, resample, attn, num_heads=2)
+        else:
+            m = T.networks.DecoderBlock(cin, cout, 64, resample, attn, num_heads=2, skip_channels=skip)
+        _, P, x, sk = _blocks64_case(g, tag, m)
+        m.load_state_dict(P, strict=True)
+        m = m.to(DEV).eval()
+        with torch.no_grad():
+            y = m(x.to(DEV), emb) if kind == "enc" else m(x.to(DEV), emb, None if sk is None else sk.to(DEV))
+        ref, refbf = T_(g[tag + "::y"]), T_(g[tag + "::y_autocast_bf16"])
+        r, r_ref = rel(y, ref), rel(refbf, ref)
+        lim = max(2.0 * r_ref, 1e-2)
+        record(f"blocks64/{tag}_vs_reference_fp32", r, lim)
+        assert y.shape == ref.shape and r <= lim, f"{tag}: rel {r:.3e} (reference's own bf16 autocast: {r_ref:.3e})"
+
+
 def test_heun_trajectory_matches_reference_and_hipgraph_replay(tiny, golden_dir):
     """Fixed-seed Heun trajectory (solvers.py:43-59) of the HIP path vs the trajectory the reference's own solver
     produced with the same weights (fp32, tests/golden/solver.npz) and vs the oracle with bf16 rounding points.
@@ -191,11 +225,13 @@ def test_heun_trajectory_matches_reference_and_hipgraph_replay(tiny, golden_dir)
     x_eager = sol.solve(model, x0, lab)
     ref = T_(s["x_heun5"])
     r_ref = rel(x_eager, ref)
+    record("tiny_net/heun5_vs_reference_fp32", r_ref, 1e-2)
     assert r_ref <= 1e-2, f"trajectory vs reference fp32: {r_ref:.3e}"
     t5 = O.karras_schedule(5, 0.01, 20.0, 5.0)
     with torch.no_grad():
         x_or = O.heun_solve(lambda x, t, l: O.edm_forward(P, ecfg, dcfg, x, t, l, bf16=True), T_(s["x0"]), t5, T_(s["labels"]))
     r_or = rel(x_eager, x_or)
+    record("tiny_net/heun5_vs_bf16_oracle", r_or, 1e-2)
     assert r_or <= 1e-2, f"trajectory vs bf16 oracle: {r_or:.3e}"
     x_graph = sol.solve(model, x0, lab, graph=True)
     x_graph2 = sol.solve(model, x0, lab, graph=True)       # second call = pure replay

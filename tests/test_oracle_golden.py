@@ -120,6 +120,42 @@ def test_blocks(golden_dir):
         assert torch.allclose(y, T(g[tag + "::y"]), rtol=1e-4, atol=1e-4), tag
 
 
+def _blocks64_case(g, tag, names_module):
+    """inputs + seeded parameters of one blocks64.npz case (oracle/make_golden_blocks64.py)"""
+    from oracle.make_golden_blocks64 import SPECS, block_inputs, block_params
+    spec = {s[0]: s for s in SPECS}[tag]
+    _, kind, cin, cout, skip, resample, attn, hw, seed = spec
+    P = block_params(names_module, seed)
+    assert [str(k) for k in g[tag + "::keys"]] == sorted(P), tag
+    from oracle.make_golden import grad_digest
+    np.testing.assert_allclose(np.stack([grad_digest(P[k]) for k in sorted(P)]), g[tag + "::digest"], rtol=1e-6, atol=1e-7)
+    x, sk = block_inputs(cin, skip, hw, seed)
+    return spec, P, x, sk
+
+
+def test_blocks64_oracle_matches_reference(golden_dir):
+    """every block flavour at HIP-supported widths (64 channels, head dim 32): oracle == the reference's modules"""
+    from oracle.make_golden_blocks64 import SPECS
+    import tinyedm_amd as TA
+    g = _ld(golden_dir, "blocks64.npz")
+    emb = T(g["emb"])
+    for tag, kind, cin, cout, skip, resample, attn, hw, seed in SPECS:
+        # the tinyedm_amd module only supplies parameter names and shapes (identical to the reference's state_dict)
+        if kind == "enc":
+            names = TA.networks.EncoderBlock(cin, cout, 64, resample, attn, num_heads=2)
+        else:
+            names = TA.networks.DecoderBlock(cin, cout, 64, resample, attn, num_heads=2, skip_channels=skip)
+        _, P, x, sk = _blocks64_case(g, tag, names)
+        P = {"b." + k: v for k, v in P.items()}
+        if kind == "enc":
+            y = O.encoder_block(P, "b.", x, emb, resample, attn, 2, 0.3, 0.0, False)
+        else:
+            y = O.decoder_block(P, "b.", x, emb, sk, resample, attn, 2, 0.3, 0.0, False)
+        ref = T(g[tag + "::y"])
+        rel = ((y - ref).norm() / ref.norm()).item()
+        assert rel <= 1e-4, f"{tag}: oracle vs reference rel {rel:.3e}"
+
+
 def test_solver_tables_bitwise_and_trajectory(golden_dir):
     g, ecfg, dcfg, P = _tiny(golden_dir)
     s = _ld(golden_dir, "solver.npz")

@@ -450,47 +450,56 @@ extern "C" int edm_up2(const void* x, void* y, int B, int Hout, int Wout, int C,
 }
 
 // ------------------------------------------------------------------ ScaleLong skip gate (networks.py:106-118) + concat (:311)
-// sum over HW of  x (optionally x*y)  per (b,c)  -> out[b,c] += scale * sum      (out pre-zeroed)
-__global__ void k_reduce_hw(const bf16* __restrict__ x, long xs, const bf16* __restrict__ y, long ys,
-                            float* __restrict__ out, int HW, int C, int PIXW, float scale) {
-  extern __shared__ __attribute__((aligned(16))) float red[];
-  const int CL = C >> 3;
-  const int PS = blockDim.x / CL;
-  const int c8 = threadIdx.x % CL, ps = threadIdx.x / CL;
-  const int b = blockIdx.x;
-  const int p_begin = blockIdx.y * PIXW, p_end = min(HW, p_begin + PIXW);
+// Deterministic form (the default): one workgroup owns a 64-channel slice of ONE sample and walks all of its pixels,
+// 32 pixel rows in flight (8 lanes x 16 B = the 128 contiguous bytes of a row's slice), four loads per thread issued
+// together; the 32 per-lane partial sums meet in LDS in a fixed order.  out[b,c] = scale * sum (plain store: no
+// atomics, no zero-fill needed, bit-reproducible -- a mean that differs in its last bit from run to run flips bf16
+// roundings downstream and makes two evaluations of the same network differ by ~1e-3).
+__global__ __launch_bounds__(256) void k_reduce_hw_det(const bf16* __restrict__ x, long xs, const bf16* __restrict__ y,
+                                                         long ys, float* __restrict__ out, int HW, int C, float scale) {
+  __shared__ float red[32][65];
+  const int b = blockIdx.x, c0 = blockIdx.y * 64;
+  const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int c = c0 + cl * 8;
+  const bool cok = c < C;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int p = p_begin + ps; p < p_end; p += PS) {
-    const long pix = (long)b * HW + p;
-    float v[8], u[8];
-    load8(x + pix * xs + c8 * 8, v);
-    if (y) {
-      load8(y + pix * ys + c8 * 8, u);
+  const long base = (long)b * HW;
+  for (int p0 = pl; p0 < HW; p0 += 128) {
+    float v[4][8], u[4][8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += v[j] * u[j];
-    } else {
+    for (int k = 0; k < 4; ++k) {
+      const int p = p0 + 32 * k;
+      const bool ok = cok && p < HW;
+      if (ok) load8(x + (base + p) * xs + c, v[k]);
+      if (ok && y) load8(y + (base + p) * ys + c, u[k]);
+      if (!ok) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += v[j];
+        for (int j = 0; j < 8; ++j) v[k][j] = 0.f;
+      }
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += (y && cok && p0 + 32 * k < HW) ? v[k][j] * u[k][j] : v[k][j];
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) red[ps * C + c8 * 8 + j] = acc[j];
+  for (int j = 0; j < 8; ++j) red[pl][cl * 8 + j] = acc[j];
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  if (threadIdx.x < 64 && c0 + (int)threadIdx.x < C) {
     float s = 0.f;
-    for (int q = 0; q < PS; ++q) s += red[q * C + c];
-    atomicAdd(out + (long)b * C + c, s * scale);
+#pragma unroll
+    for (int q = 0; q < 32; ++q) s += red[q][threadIdx.x];
+    out[(long)b * C + c0 + threadIdx.x] = s * scale;
   }
 }
-// x: rows of xs elements (uses first C), y optional rows of ys elements; out[b,c] += scale*sum_hw x*(y)
+// x: rows of xs elements (uses first C), y optional rows of ys elements; out[b,c] = scale*sum_hw x*(y)
+// (written, not accumulated; deterministic summation order).
 extern "C" int edm_reduce_hw(const void* x, long x_stride, const void* y, long y_stride, float* out, int B, int HW,
                              int C, float scale, hipStream_t st) {
-  EDM_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && C > 0 && C <= 1024 && x_stride % 8 == 0 && y_stride % 8 == 0,
+  EDM_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && C > 0 && C <= 4096 && x_stride % 8 == 0 && y_stride % 8 == 0,
               "reduce_hw: bad args");
-  int CL = C / 8, block = block_for_chunks(CL), PS = block / CL;
-  int PIXW = HW >= 256 ? 128 : HW;
-  hipLaunchKernelGGL(k_reduce_hw, dim3(B, cdiv(HW, PIXW)), dim3(block), PS * C * sizeof(float), st, (const bf16*)x,
-                     x_stride, (const bf16*)y, y_stride, out, HW, C, PIXW, scale);
+  hipLaunchKernelGGL(k_reduce_hw_det, dim3(B, cdiv(C, 64)), dim3(256), 0, st, (const bf16*)x, x_stride, (const bf16*)y,
+                     y_stride, out, HW, C, scale);
   EDM_CHECK_LAUNCH("reduce_hw");
   return EDM_OK;
 }

@@ -247,7 +247,7 @@ def reduce_hw(x, C=None, c_off=0, y=None, scale=1.0):
     C = Cx - c_off if C is None else C
     if c_off % 8 or c_off + C > Cx:
         raise ValueError("reduce_hw: bad channel slice")
-    out = zeros_f32((B, C), x.device)
+    out = torch.empty(B, C, device=x.device, dtype=f32)      # written (not accumulated) in a fixed summation order
     ys = 0
     if y is not None:
         By, Hy, Wy, Cy = _nhwc(y, "y")

@@ -1,0 +1,81 @@
+"""How far is the bf16-network sampler from the reference's fp32 sampler?  
+
+The reference samples in fp32 (generate.py:39-44, solvers.py:43-59); this build evaluates the network in bf16 (fp32
+accumulation, fp32 Heun state).  This tool integrates the SAME 32-step Heun trajectory (63 evaluations) of the
+CIFAR-10 U-Net (35.6 M parameters, seeded weights with non-zero gains) from the same x0
+  (a) on the HIP path (bf16 network, hipGraph), and
+  (b) on the CPU oracle in fp32 (the reference's arithmetic: oracle pinned to the reference's golden vectors),
+and writes the relative L2 distance of the final images and of every intermediate state to
+gpurun_out/r02_sampler_parity.json (copied to profiles/).   python tools/sampler_parity.py [--images 2]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import edm_oracle as O  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=32)
+    a = ap.parse_args()
+    import tinyedm_amd as T
+    dev = torch.device("cuda", 0)
+    ecfg, dcfg = O.cifar10_cfg()
+    P = O.init_params(ecfg, dcfg, torch.Generator().manual_seed(1), gains_nonzero=True)
+    emb = T.Embedding(ecfg.fourier_dim, ecfg.embedding_dim, ecfg.num_classes, ecfg.add_factor)
+    den = T.Denoiser(dcfg.in_channels, dcfg.out_channels, tuple(dcfg.encoder_block_types), tuple(dcfg.decoder_block_types),
+                     tuple(dcfg.encoder_out_channels), tuple(dcfg.decoder_out_channels), tuple(dcfg.skip_connections),
+                     dcfg.dropout_rate, dcfg.sigma_data, dcfg.encoder_add_factor, dcfg.decoder_add_factor,
+                     dcfg.embedding_dim, dcfg.num_heads)
+    emb.load_state_dict({k[len("embedding."):]: v for k, v in P.items() if k.startswith("embedding.")})
+    den.load_state_dict({k[len("denoiser."):]: v for k, v in P.items() if k.startswith("denoiser.")})
+    emb, den = emb.to(dev).eval(), den.to(dev).eval()
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.emb, self.den = emb, den
+
+        def forward(self, x, t, lab):
+            _, e = self.emb(t, lab)
+            return self.den(x, t, e)
+    x0 = torch.randn(a.images, 3, 32, 32, generator=torch.Generator().manual_seed(7))
+    sol = T.DeterministicSolver(num_steps=a.steps)
+    x_hip = sol.solve(Model().eval(), x0.to(dev), None, graph=True).cpu()
+
+    torch.set_num_threads(len(os.sched_getaffinity(0)))
+    t0 = time.time()
+    ts = O.karras_schedule(a.steps)
+    with torch.no_grad():
+        x_f32 = O.heun_solve(lambda x, t, l: O.edm_forward(P, ecfg, dcfg, x, t, l, bf16=False), x0, ts, None)
+        x_bf = O.heun_solve(lambda x, t, l: O.edm_forward(P, ecfg, dcfg, x, t, l, bf16=True), x0, ts, None)
+    cpu_s = time.time() - t0
+
+    def rel(u, v):
+        return ((u.double() - v.double()).norm() / v.double().norm()).item()
+    out = {"config": "CIFAR-10 unconditional U-Net (35.6M params, seeded weights, gains non-zero)", "heun_steps": a.steps,
+           "nfe": 2 * a.steps - 1, "images": a.images,
+           "hip_bf16net_vs_fp32_oracle_rel_l2": rel(x_hip, x_f32),
+           "hip_bf16net_vs_bf16_oracle_rel_l2": rel(x_hip, x_bf),
+           "bf16_oracle_vs_fp32_oracle_rel_l2": rel(x_bf, x_f32),
+           "final_image_rms": x_f32.pow(2).mean().sqrt().item(),
+           "max_abs_diff_vs_fp32": (x_hip - x_f32).abs().max().item(),
+           "note": "state integrated in fp32 on both sides; only the network evaluation differs (bf16 operands, fp32 "
+                   "accumulation on the HIP path). 1/255 of the [-1,1] image range is 7.8e-3.",
+           "oracle_cpu_seconds": round(cpu_s, 1)}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "r02_sampler_parity.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
