@@ -33,12 +33,31 @@ def note(msg):
 
 
 def host_cores():
-    """threads for the CPU baseline: every core this process may run on (EDM_CPU_THREADS overrides)"""
+    """Threads for the CPU baseline = the cores this process may actually USE: the scheduler affinity, cut down to the
+    cgroup CPU quota when one is set.  A GPU box exposes every logical CPU of the host (256) to each tenant but grants
+    a share of them (16 per GPU): without a visible quota the share is taken to be 16 (EDM_CPU_THREADS overrides) --
+    running 256 oversubscribed threads there took minutes per step."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    return max(1, int(os.environ.get("EDM_CPU_THREADS", n)))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2: "<quota|max> <period>"
+            q, p = f.read().split()
+            if q != "max":
+                quota = max(1, -(-int(q) // int(p)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f1, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                q, p = int(f1.read()), int(f2.read())
+                if q > 0:
+                    quota = max(1, -(-q // p))
+        except (OSError, ValueError):
+            pass
+    if "EDM_CPU_THREADS" in os.environ:
+        return max(1, int(os.environ["EDM_CPU_THREADS"]))
+    return max(1, min(n, quota if quota is not None else 16))
 
 # work per unit, CIFAR-10 config (SURVEY.md 8(d) / BASELINE.md 3)
 TRAIN_GFLOP_PER_IMG = 81.0
@@ -193,7 +212,7 @@ def cpu_baseline(args):
     from oracle import edm_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
-    note(f"cpu baseline on {cores} host threads")
+    note(f"cpu baseline on {cores} host threads ({os.cpu_count()} logical CPUs visible)")
     ecfg, dcfg = O.cifar10_cfg()
     B = args.cpu_batch
 
@@ -221,6 +240,7 @@ def cpu_baseline(args):
                     O.ema_step(ema[k], P[k], O.ema_beta(it, 4.6036))
             if it > 0:
                 times.append(time.perf_counter() - t0)
+            note(f"  cpu step {it} ({'bf16 autocast' if autocast else 'fp32'}): {time.perf_counter() - t0:.2f} s")
             if time.perf_counter() - budget_t0 > budget_s and times:
                 break
         return sum(times) / len(times), len(times)

@@ -50,6 +50,11 @@ int edm_conv_igemm_v3(const void* X, const void* Wp, void* Y, const void* R, flo
  * masks folded into addresses, incremental DMA pointers); -3 for shapes it does not cover (taps != 9, Cin % 64 != 0) */
 int edm_conv_igemm_v4(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
                       int W, int Cin, int Cout, int taps, edm_stream_t stream);
+/* small feature maps (8x8 layers; W <= 16, Cin % 256 == 0), 3x3 only: 128x64 tile whose reduction dimension is split
+ * over the four waves of the workgroup (private LDS regions, no barrier in the main loop, fixed-order LDS reduction);
+ * -3 for shapes it does not cover */
+int edm_conv_igemm_s(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
+                     int W, int Cin, int Cout, int taps, edm_stream_t stream);
 /* first 3x3 conv of a block with the embedding modulation fused into its epilogue (networks.py:253-260 / 317-324):
  * Y = conv3x3(X) (bf16, may be NULL in eval), Y2 = dropout(mp_silu(Y * (lin[b,:]*gain + 1))) -- bit-identical to
  * edm_mod_silu_drop_fwd applied to Y (same Philox counters), so edm_mod_silu_drop_bwd serves as its backward. */
@@ -113,6 +118,18 @@ int edm_weight_prep_multi(const void* descs, const int* groups, int n_groups, in
 /* reduce split-K slabs and project through the normalisation -> gradient of the fp32 master weight [O,I,taps]. */
 int edm_wgrad_finish(const float* slabs, int S, const float* w, float* grad, const int* perm, int O, int I, int Ipad,
                      int taps, float scale, int accumulate, edm_stream_t stream);
+
+/* the same for up to 40 tensors in ONE launch (`items` is a HOST array read during the call) */
+typedef struct {
+  const float* slabs; /* fp32 [S][taps][O][Ipad] */
+  const float* w;     /* fp32 master weight [O][I][taps] */
+  float* grad;        /* fp32 gradient, same layout */
+  const int* perm;    /* or NULL */
+  int S, O, I, Ipad, taps;
+  float scale;
+  int accumulate;
+} edm_finish_item;
+int edm_wgrad_finish_multi(const edm_finish_item* items, int n, edm_stream_t stream);
 
 /* ---------------------------------------------------------------- attention (networks.py:194-202) */
 /* qkv [B*N,3C] channel order [head][q|k|v][d]; q,k,v pixel-normalised over d; softmax(qk^T/sqrt(d)) v. d = 64, N<=256 */

@@ -66,10 +66,16 @@ CONV_SHAPES = [
     (2, 14, 14, 32, 64),
     (2, 8, 8, 512, 256),
     (1, 64, 64, 64, 64),
+    # small-map kernel (conv_igemm5.hip: Cin % 256 == 0, W <= 16): ragged tiles, partial channel tiles, 2 and 4 rounds
+    (16, 8, 8, 256, 256),
+    (3, 16, 16, 256, 192),
+    (5, 7, 7, 256, 72),
+    (2, 4, 4, 512, 128),
+    (1, 3, 16, 1024, 64),
 ]
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["igemm-auto", "igemm-v1", "igemm-v2", "igemm-v3", "igemm-v4"])
+@pytest.fixture(params=[0, 1, 2, 3, 4, 5], ids=["igemm-auto", "igemm-v1", "igemm-v2", "igemm-v3", "igemm-v4", "igemm-s"])
 def igemm_version(request, ops):
     """Every generation of the implicit-GEMM kernel must pass the same parity tests (the per-shape dispatcher
     picks v2/v3 only for full-size layers, so they are forced here on the small test shapes)."""

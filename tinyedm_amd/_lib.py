@@ -44,6 +44,7 @@ SIGNATURES = {
     "edm_conv_igemm_v2": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_v3": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_v4": [P, P, P, P, F, F, I, I, I, I, I, I, P],
+    "edm_conv_igemm_s": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv3x3_mod": [P, P, P, P, P, L, P, F, U64, U, U, I, I, I, I, I, P, P],
     "edm_conv3x3_modbwd": [P, P, F, P, P, L, P, P, P, F, U64, U, U, I, I, I, I, I, P, P],
     "edm_conv3x3_silubwd": [P, P, P, P, F, P, I, I, I, I, I, P],
@@ -78,6 +79,7 @@ SIGNATURES = {
     "edm_weight_prep": [P, I, I, I, I, P, P, P, P, I, P],
     "edm_weight_prep_multi": [P, P, I, I, I, P],
     "edm_wgrad_finish": [P, I, P, P, P, I, I, I, I, F, I, P],
+    "edm_wgrad_finish_multi": [P, I, P],
     # data.hip
     "edm_u8_gather_normalize": [P, P, P, I, I, I, I, L, F, F, I, U64, U, P],
     "edm_denormalize_u8": [P, P, L, F, F, P],
@@ -97,6 +99,12 @@ _lib = None
 
 class HipKernelError(RuntimeError):
     pass
+
+
+class FinishItem(ctypes.Structure):
+    """edm_finish_item (include/tinyedm_hip.h)"""
+    _fields_ = [("slabs", P), ("w", P), ("grad", P), ("perm", P), ("S", I), ("O", I), ("I", I), ("Ipad", I), ("taps", I),
+                ("scale", F), ("accumulate", I)]
 
 
 class WGrad3Item(ctypes.Structure):

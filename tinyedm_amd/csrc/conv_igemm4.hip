@@ -310,6 +310,10 @@ extern "C" int edm_conv_igemm_v4(const void* X, const void* Wp, void* Y, const v
 
 int edm_conv_igemm_v1_ex(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
                          int W, int Cin, int Cout, int taps, const ModEpilogue& mod, hipStream_t st);
+// conv_igemm5.hip: small feature maps (reduction split over the waves of a workgroup)
+bool edm_conv_s_worthwhile(long npix, int W, int Cin, int Cout);
+int edm_conv_igemm_s_ex(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
+                        int W, int Cin, int Cout, int taps, const ModEpilogue& mod, hipStream_t st);
 
 // 3x3 conv with the fused embedding modulation epilogue (networks.py:253-260 / 317-324):
 //   u  = conv3x3(X, Wp)                               -> Y  (bf16; may be null when the caller does not need it: eval)
@@ -325,6 +329,10 @@ extern "C" int edm_conv3x3_mod(const void* X, const void* Wp, void* Y, void* Y2,
                   nullptr, nullptr, nullptr, 0.f, 0, (const StepParams*)dyn};
   if (edm_conv_v4_worthwhile((long)B * H * W, Cout)) {
     const int rc = edm_conv_igemm_v4_ex(X, Wp, Y, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
+    if (rc != EDM_ERR_UNSUPPORTED) return rc;
+  }
+  if (edm_conv_s_worthwhile((long)B * H * W, W, Cin, Cout)) {
+    const int rc = edm_conv_igemm_s_ex(X, Wp, Y, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
     if (rc != EDM_ERR_UNSUPPORTED) return rc;
   }
   return edm_conv_igemm_v1_ex(X, Wp, Y, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
@@ -350,6 +358,10 @@ extern "C" int edm_conv3x3_modbwd(const void* dY, const void* Wd, float alpha, c
     const int rc = edm_conv_igemm_v4_ex(dY, Wd, nullptr, nullptr, alpha, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
     if (rc != EDM_ERR_UNSUPPORTED) return rc;
   }
+  if (edm_conv_s_worthwhile((long)B * H * W, W, Cin, Cout)) {
+    const int rc = edm_conv_igemm_s_ex(dY, Wd, nullptr, nullptr, alpha, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
+    if (rc != EDM_ERR_UNSUPPORTED) return rc;
+  }
   return edm_conv_igemm_v1_ex(dY, Wd, nullptr, nullptr, alpha, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
 }
 
@@ -365,6 +377,10 @@ extern "C" int edm_conv3x3_silubwd(const void* dY, const void* Wd, const void* X
                   add_scale, 2, nullptr};
   if (edm_conv_v4_worthwhile((long)B * H * W, Cout)) {
     const int rc = edm_conv_igemm_v4_ex(dY, Wd, nullptr, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
+    if (rc != EDM_ERR_UNSUPPORTED) return rc;
+  }
+  if (edm_conv_s_worthwhile((long)B * H * W, W, Cin, Cout)) {
+    const int rc = edm_conv_igemm_s_ex(dY, Wd, nullptr, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
     if (rc != EDM_ERR_UNSUPPORTED) return rc;
   }
   return edm_conv_igemm_v1_ex(dY, Wd, nullptr, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);

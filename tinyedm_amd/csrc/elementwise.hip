@@ -464,10 +464,11 @@ __global__ __launch_bounds__(256) void k_reduce_hw_det(const bf16* __restrict__ 
   const bool cok = c < C;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const long base = (long)b * HW;
-  for (int p0 = pl; p0 < HW; p0 += 128) {
-    float v[4][8], u[4][8];
+  constexpr int UN = 8;   // loads in flight per thread: the pass is latency-bound (one sample slice per workgroup)
+  for (int p0 = pl; p0 < HW; p0 += 32 * UN) {
+    float v[UN][8], u[UN][8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < UN; ++k) {
       const int p = p0 + 32 * k;
       const bool ok = cok && p < HW;
       if (ok) load8(x + (base + p) * xs + c, v[k]);
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(256) void k_reduce_hw_det(const bf16* __restrict__ 
       }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < UN; ++k)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] += (y && cok && p0 + 32 * k < HW) ? v[k][j] * u[k][j] : v[k][j];
   }

@@ -367,7 +367,137 @@ __global__ __launch_bounds__(1024) void k_wgrad_finish(const float* __restrict__
   }
 }
 
+// ---- multi-tensor finish: the same reduction + projection for up to MAXF tensors in ONE launch (a training step has
+// ~70 small weight gradients -- 1x1 convs, embedding / gate linears -- whose separate finish launches cost 8 us each).
+constexpr int MAXF = 40;
+struct FinItem {
+  const float* slabs;
+  const float* w;
+  float* grad;
+  const int* perm;
+  int S, O, I, Ipad, taps, G, row0;
+  float scale;
+  int accumulate, pad;
+};
+struct FinGroup {
+  FinItem it[MAXF];
+  int n;
+};
+__global__ __launch_bounds__(512) void k_wgrad_finish_multi(const FinGroup g) {
+  extern __shared__ __attribute__((aligned(16))) float smm[];
+  __shared__ float red[16];
+  int k = 0;
+  while (k + 1 < g.n && (int)blockIdx.x >= g.it[k + 1].row0) ++k;
+  const int r = blockIdx.x - g.it[k].row0;
+  const float* __restrict__ slabs = g.it[k].slabs;
+  const int S = g.it[k].S, O = g.it[k].O, I = g.it[k].I, Ipad = g.it[k].Ipad, taps = g.it[k].taps, G = g.it[k].G;
+  const float scale = g.it[k].scale;
+  const int mo = g.it[k].perm ? g.it[k].perm[r] : r;
+  const int n = I * taps;
+  float* part = smm;                 // [G][n] packed (t major, i minor)
+  float* gm = smm + (long)G * n;     // [n] master order
+  const float* row = g.it[k].w + (long)mo * n;
+  const long slab_stride = (long)taps * O * Ipad;
+  if ((I & 3) == 0 && (Ipad & 3) == 0) {
+    const int I4 = I >> 2, E4 = taps * I4;
+    for (int idx = threadIdx.x; idx < E4 * G; idx += blockDim.x) {
+      const int sg = idx / E4, e4 = idx - sg * E4;
+      const int t = e4 / I4, i = (e4 - t * I4) * 4;
+      const float* sp = slabs + ((long)t * O + r) * Ipad + i;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      int s = sg;
+      for (; s + 3 * G < S; s += 4 * G) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(sp + (long)(s + u * G) * slab_stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a += v[u];
+      }
+      for (; s < S; s += G) a += *reinterpret_cast<const f32x4*>(sp + (long)s * slab_stride);
+      *reinterpret_cast<f32x4*>(part + (long)sg * n + e4 * 4) = a;
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < n * G; idx += blockDim.x) {
+      const int sg = idx / n, e = idx - sg * n;
+      const int t = e / I, i = e - t * I;
+      const float* sp = slabs + ((long)t * O + r) * Ipad + i;
+      float a = 0.f;
+      for (int s = sg; s < S; s += G) a += sp[(long)s * slab_stride];
+      part[(long)sg * n + e] = a;
+    }
+  }
+  __syncthreads();
+  float dot = 0.f, ss = 0.f;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    float a = 0.f;
+    for (int sg = 0; sg < G; ++sg) a += part[(long)sg * n + e];
+    a *= scale;
+    const int t = e / I, i = e - t * I;
+    const float wv = row[i * taps + t];
+    gm[i * taps + t] = a;
+    dot += a * wv;
+    ss += wv * wv;
+  }
+  dot = block_sum(dot, red);
+  ss = block_sum(ss, red);
+  const float rn = sqrtf(ss);
+  const float sqn = sqrtf((float)n);
+  const float d = NORM_EPS + rn / sqn;
+  const float c0 = 1.0f / (d * sqn);
+  const float c1 = rn > 0.f ? dot / (d * rn * sqn) : 0.f;
+  __syncthreads();
+  float* out = g.it[k].grad + (long)mo * n;
+  const int accumulate = g.it[k].accumulate;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    const float v = c0 * (gm[e] - row[e] * c1);
+    out[e] = accumulate ? out[e] + v : v;
+  }
+}
+
 }  // namespace
+
+extern "C" {
+typedef struct {
+  const float* slabs;   // fp32 [S][taps][O][Ipad] split-K partial sums (packed row order)
+  const float* w;       // fp32 master weight [O][I][taps]
+  float* grad;          // fp32 gradient, same layout
+  const int* perm;      // packed row -> master row, or NULL
+  int S, O, I, Ipad, taps;
+  float scale;
+  int accumulate;
+} edm_finish_item;
+}
+
+// Reduce + project up to 40 weight gradients in one launch (`items` is HOST memory, read during the call).
+extern "C" int edm_wgrad_finish_multi(const edm_finish_item* items, int n, hipStream_t st) {
+  EDM_REQUIRE(items && n > 0 && n <= MAXF, "wgrad_finish_multi: need 1..%d tensors, got %d", MAXF, n);
+  FinGroup g;
+  g.n = n;
+  int row = 0;
+  size_t lds = 0;
+  for (int k = 0; k < n; ++k) {
+    const edm_finish_item& a = items[k];
+    EDM_REQUIRE(a.slabs && a.w && a.grad && a.S > 0 && a.O > 0 && a.I > 0 && a.taps > 0 && a.Ipad >= a.I,
+                "wgrad_finish_multi: bad item %d", k);
+    const int nn = a.I * a.taps;
+    const int E = ((a.I & 3) == 0 && (a.Ipad & 3) == 0) ? nn / 4 : nn;
+    int G = 1;
+    while (G < 8 && 2 * G <= a.S && E * 2 * G <= 512 && (long)(2 * G + 1) * nn * 4 <= 96 * 1024) G *= 2;
+    EDM_REQUIRE((long)(G + 1) * nn * 4 <= 128 * 1024, "wgrad_finish_multi: fan_in %d too large for the LDS row buffer", nn);
+    g.it[k] = FinItem{a.slabs, a.w, a.grad, a.perm, a.S, a.O, a.I, a.Ipad, a.taps, G, row, a.scale, a.accumulate, 0};
+    row += a.O;
+    const size_t need = (size_t)(G + 1) * nn * sizeof(float);
+    if (need > lds) lds = need;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_finish_multi), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_wgrad_finish_multi, dim3(row), dim3(512), lds, st, g);
+  EDM_CHECK_LAUNCH("wgrad_finish_multi");
+  return EDM_OK;
+}
 
 // w [O, I, taps] fp32 master (taps = k*k, OIHW flattened).  Any of wp_fwd / wp_dgrad / w_hat may be null.
 //   wp_fwd   bf16 [taps, O, Ipad]   (ci >= I zero-filled)      -> edm_conv_igemm forward

@@ -105,11 +105,16 @@ class _WNBase(nn.Module):
         w = self.weight
         I = w.shape[1]
         if w.grad is not None and getattr(w, "_edm_direct", False):
-            # flat-arena mode: accumulate straight into the gradient arena (no autograd AccumulateGrad pass,
-            # no temporary) and tell the data-parallel reducer this gradient is final.
-            ops.wgrad_finish(slabs, w.data, self._taps(), I, perm=self._perm, scale=scale, out=w.grad)
-            for hook in getattr(w, "_edm_hooks", ()):
-                hook(w)
+            # flat-arena mode: the reduction + projection accumulates straight into the gradient arena (no autograd
+            # AccumulateGrad pass, no temporary).  It is DEFERRED: ~70 such tensors per step share a few
+            # multi-tensor launches (_flush_fin), after which the data-parallel reducer is told they are final.
+            key = w.device.index
+            pend = _fin_pending.setdefault(key, [])
+            pend.append((slabs, w, self._perm, self._taps(), I, scale))
+            w._edm_deferred = True
+            if len(pend) >= FIN_GROUP:
+                _flush_fin(key)
+            _queue_backward_end(w.device)
             return None
         g = ops.wgrad_finish(slabs, w.data, self._taps(), I, perm=self._perm, scale=scale)
         return g.view_as(w)
@@ -118,8 +123,10 @@ class _WNBase(nn.Module):
 WGRAD_STREAM = os.environ.get("EDM_WGRAD_STREAM", "1") != "0"
 # 3x3 weight gradients: layers per grouped stream-K launch (csrc/conv_wgrad3.hip; 0 = previous per-layer kernels)
 W3_GROUP = max(0, min(16, int(os.environ.get("EDM_W3_GROUP", "12"))))
+FIN_GROUP = 40              # small weight gradients per multi-tensor finish launch (csrc/weights.hip)
 _bwd_end_queued = set()     # devices whose end-of-backward callback is queued for the running backward pass
 _w3_pending = {}            # device index -> [(mod, x, dy, scale)] 3x3 layers waiting for their grouped launch
+_fin_pending = {}           # device index -> [(slabs, w, perm, taps, I, scale)] small weight gradients to finish
 
 
 def _run_on_side(device, fn, tensors=()):
@@ -145,10 +152,26 @@ def _flush_w3(key):
     args = [(x, dy, m.weight.data, m.weight.grad, m._perm, scale, True) for m, x, dy, scale in items]
     keep = [t for _, x, dy, _ in items for t in (x, dy)]
     _run_on_side(dev, lambda: ops.wgrad3_group(args), keep)
+    _flush_fin(key)             # the small gradients of the same stretch of the backward pass ride along
     for m, _, _, _ in items:
         m.weight._edm_deferred = False
         for hook in getattr(m.weight, "_edm_hooks", ()):
             hook(m.weight)
+
+
+def _flush_fin(key):
+    """One multi-tensor launch for the pending small weight gradients of device `key` (on the auxiliary stream,
+    ordered after both streams' producers of the slabs)."""
+    items = _fin_pending.pop(key, None)
+    if not items:
+        return
+    dev = items[0][1].device
+    args = [(slabs, w.data, w.grad, perm, taps, I, scale, True) for slabs, w, perm, taps, I, scale in items]
+    _run_on_side(dev, lambda: ops.wgrad_finish_multi(args), [a[0] for a in args])
+    for _, w, *_rest in items:
+        w._edm_deferred = False
+        for hook in getattr(w, "_edm_hooks", ()):
+            hook(w)
 
 
 def _backward_end(key):
@@ -156,6 +179,7 @@ def _backward_end(key):
     backward wait for the auxiliary stream (the optimizer reads what the weight-gradient kernels wrote)."""
     _bwd_end_queued.discard(key)
     _flush_w3(key)
+    _flush_fin(key)
     if WGRAD_STREAM:
         torch.cuda.current_stream(key).wait_stream(ops.side_stream(key))
 
@@ -174,8 +198,12 @@ def _queue_backward_end(device):
 def reset_backward_state():
     """Forget deferred work of a backward pass that did not complete (an exception inside autograd leaves its
     end-of-backward callback unrun).  Called at the start of every Denoiser forward."""
-    if _bwd_end_queued or _w3_pending:
+    if _bwd_end_queued or _w3_pending or _fin_pending:
         _bwd_end_queued.clear()
+        for items in _fin_pending.values():
+            for _, w, *_rest in items:
+                w._edm_deferred = False
+        _fin_pending.clear()
         for items in _w3_pending.values():
             for m, _, _, _ in items:
                 m.weight._edm_deferred = False
@@ -431,6 +459,7 @@ class ScaleLong(nn.Module):
 class _ConcatGateFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inp, skip, w1, w2, sl: ScaleLong, want_silu: bool = False):
+        ctx.set_materialize_grads(False)          # no zero-filled gradient tensor for the non-differentiable `sil`
         B, H, W, Cs = skip.shape
         w1h, w2h = sl.layer1.packs()[2], sl.layer2.packs()[2]
         mean = ops.reduce_hw(skip, scale=1.0 / (H * W))
@@ -486,6 +515,7 @@ class FourierEmbedding(nn.Module):
 class _EmbeddingFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sigma, labels, w_sigma, w_cls, mod: "Embedding"):
+        ctx.set_materialize_grads(False)
         B = max(sigma.numel(), labels.numel() if labels is not None else 1)
         four = ops.fourier_fwd(sigma, mod.fourier_embed.freqs, mod.fourier_embed.phases, B)
         wsh = mod.sigma_embed.packs()[2]
@@ -877,6 +907,7 @@ class _EmbedAllFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, emb, den, *weights):
+        ctx.set_materialize_grads(False)
         blocks = den._res_blocks()
         whs = [b.embed.packs()[2] for b in blocks]
         wcat = torch.cat(whs, 0)

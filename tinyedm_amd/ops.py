@@ -383,6 +383,8 @@ def _igemm_entry(npix, W, Cout, taps, Cin=0):
         return "edm_conv_igemm_v3"
     if IGEMM_VERSION == 4:
         return "edm_conv_igemm_v4" if (taps == 9 and Cin % 64 == 0 and Cin <= 2016) else "edm_conv_igemm_v3"
+    if IGEMM_VERSION == 5:
+        return "edm_conv_igemm_s" if (taps == 9 and Cin % 256 == 0 and Cin <= 2016 and W <= 16) else "edm_conv_igemm"
     # per-shape choice from the r01 microbenchmarks (tools/microbench_conv.py): the LDS-DMA tall-tile kernels only pay
     # off when they still give every CU >= 2 tiles; small feature maps keep the 128x128 register-staged kernel.
     if taps == 9:
@@ -393,6 +395,9 @@ def _igemm_entry(npix, W, Cout, taps, Cin=0):
             return "edm_conv_igemm_v4" if v4_ok else "edm_conv_igemm_v3"
         if v4_ok and tm * ((Cout + 63) // 64) >= 256:     # 512x64 tiles of the same kernel (16x16 layers at batch 128)
             return "edm_conv_igemm_v4"
+        ts = ((npix + 127) // 128) * ((Cout + 63) // 64)
+        if W <= 16 and Cin % 256 == 0 and Cin <= 2016 and 128 <= ts <= 1024:   # small maps: K split over the waves
+            return "edm_conv_igemm_s"
         return "edm_conv_igemm"
     tiles2 = ((npix + 255) // 256) * ((Cout + 127) // 128)
     return "edm_conv_igemm_v2" if tiles2 >= 1024 else "edm_conv_igemm"
@@ -400,6 +405,8 @@ def _igemm_entry(npix, W, Cout, taps, Cin=0):
 
 def _v4_suffix(entry, npix, Cout):
     """profile-key suffix naming the kernel instantiation: _v4 = 512x128 tiles, _v4s = 512x64 tiles (small maps)"""
+    if entry == "edm_conv_igemm_s":
+        return "_s"
     if entry != "edm_conv_igemm_v4":
         return entry[len("edm_conv_igemm"):]
     return "_v4" if ((npix + 511) // 512) * ((Cout + 127) // 128) >= 512 else "_v4s"
@@ -442,7 +449,7 @@ def conv3x3_mod(x, wp, lin, gain, pdrop, seed, sub, step, want_u=True, dyn=None)
     a2 = torch.empty(B, H, W, Cout, device=x.device, dtype=bf16)
     npix = B * H * W
     entry = _igemm_entry(npix, W, Cout, 9, Cin)
-    pname = "conv3x3_igemm" + (_v4_suffix(entry, npix, Cout) if entry == "edm_conv_igemm_v4" else "")
+    pname = "conv3x3_igemm" + (_v4_suffix(entry, npix, Cout) if entry in ("edm_conv_igemm_v4", "edm_conv_igemm_s") else "")
     with _prof(pname, 2.0 * npix * Cin * Cout * 9, 2.0 * (npix * (Cin + Cout * (2 if want_u else 1)) + wp.numel())):
         _lib.call("edm_conv3x3_mod", _p(x), _p(wp), _p(u), _p(a2), _p(lin), ls, _p(gain), float(pdrop), int(seed),
                   int(sub), int(step), B, H, W, Cin, Cout, _dyn(dyn), _stream())
@@ -469,7 +476,7 @@ def conv3x3_modbwd(gout, wd, alpha, r1, lin, gain, pdrop, seed, sub, step, glin_
     ggain = zeros_f32((), r1.device) if ggain_out is None else _chk(ggain_out, f32, "ggain_out", ())
     npix = B * H * W
     entry = _igemm_entry(npix, W, Cout, 9, Cin)
-    pname = "conv3x3_igemm" + (_v4_suffix(entry, npix, Cout) if entry == "edm_conv_igemm_v4" else "") + "_modbwd"
+    pname = "conv3x3_igemm" + (_v4_suffix(entry, npix, Cout) if entry in ("edm_conv_igemm_v4", "edm_conv_igemm_s") else "") + "_modbwd"
     with _prof(pname, 2.0 * npix * Cin * Cout * 9, 2.0 * (npix * (Cin + 2 * Cout) + wd.numel())):
         _lib.call("edm_conv3x3_modbwd", _p(gout), _p(wd), float(alpha), _p(r1), _p(lin), ls, _p(gain), _p(gr), _p(gm),
                   float(pdrop), int(seed), int(sub), int(step), B, H, W, Cin, Cout, _dyn(dyn), _stream())
@@ -491,7 +498,7 @@ def conv3x3_silubwd(g, wd, xpre, gextra=None, extra_scale=1.0):
     gx = torch.empty_like(xpre)
     npix = B * H * W
     entry = _igemm_entry(npix, W, Cout, 9, Cin)
-    pname = "conv3x3_igemm" + (_v4_suffix(entry, npix, Cout) if entry == "edm_conv_igemm_v4" else "") + "_silubwd"
+    pname = "conv3x3_igemm" + (_v4_suffix(entry, npix, Cout) if entry in ("edm_conv_igemm_v4", "edm_conv_igemm_s") else "") + "_silubwd"
     with _prof(pname, 2.0 * npix * Cin * Cout * 9,
                2.0 * (npix * (Cin + Cout * (3 if gextra is not None else 2)) + wd.numel())):
         _lib.call("edm_conv3x3_silubwd", _p(g), _p(wd), _p(xpre), _p(gextra), float(extra_scale), _p(gx), B, H, W, Cin,
@@ -622,6 +629,25 @@ def wgrad_finish(slabs, w, taps, I, perm=None, scale=1.0, out=None):
     _lib.call("edm_wgrad_finish", _p(slabs), S, _p(w), _p(out), _p(perm), O, I, Ipad, taps, float(scale), int(accumulate),
               _stream())
     return out
+
+
+def wgrad_finish_multi(items):
+    """items: sequence of (slabs, w, grad, perm, taps, I, scale, accumulate): wgrad_finish for all of them, 40 per launch"""
+    for c0 in range(0, len(items), 40):
+        chunk = items[c0:c0 + 40]
+        arr = (_lib.FinishItem * len(chunk))()
+        for k, (slabs, w, grad, perm, taps, I, scale, accumulate) in enumerate(chunk):
+            _chk(slabs, f32, "slabs")
+            _chk(w, f32, "w")
+            S, t_, O, Ipad = slabs.shape
+            if t_ != taps or w.shape[0] != O or w.numel() != O * I * taps:
+                raise ValueError("wgrad_finish_multi: shape mismatch")
+            _chk(grad, f32, "grad", w.shape)
+            if perm is not None:
+                _chk(perm, torch.int32, "perm", (O,))
+            arr[k] = _lib.FinishItem(slabs.data_ptr(), w.data_ptr(), grad.data_ptr(), None if perm is None else perm.data_ptr(),
+                                     S, O, I, Ipad, taps, float(scale), int(bool(accumulate)))
+        _lib.call("edm_wgrad_finish_multi", ctypes.byref(arr), len(chunk), _stream())
 
 
 # ------------------------------------------------------------------ attention

@@ -45,4 +45,11 @@ for (HW, Cin, Cout, taps) in shapes:
     if a.only in ("all", "wgrad"):
         ms = timeit(lambda: ops.conv_wgrad(x, gy, taps))
         line += f"wgrad {ms * 1e3:8.1f} us {fl / ms / 1e9:7.1f} TF/s"
+    if a.only in ("all", "wgrad3") and taps == 9:
+        w = torch.randn(Cout, Cin, 3, 3, device=dev)
+        gr = torch.zeros_like(w)
+        for n in (1, 4):                 # one layer per launch / four layers of this shape per grouped launch
+            items = [(x, gy, w, gr, None, 1.0, True)] * n
+            ms = timeit(lambda: ops.wgrad3_group(items))
+            line += f"wgrad3 x{n} {ms * 1e3 / n:8.1f} us/layer {n * fl / ms / 1e9:7.1f} TF/s   "
     print(line, flush=True)

@@ -25,6 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--images", type=int, default=2)
     ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--bf16-oracle", action="store_true", help="also integrate the oracle with bf16 rounding points")
     a = ap.parse_args()
     import tinyedm_amd as T
     dev = torch.device("cuda", 0)
@@ -51,12 +52,22 @@ def main():
     sol = T.DeterministicSolver(num_steps=a.steps)
     x_hip = sol.solve(Model().eval(), x0.to(dev), None, graph=True).cpu()
 
-    torch.set_num_threads(len(os.sched_getaffinity(0)))
+    import bench
+    torch.set_num_threads(bench.host_cores())
     t0 = time.time()
     ts = O.karras_schedule(a.steps)
+    calls = [0]
+
+    def net(bf16):
+        def f(x, t, l):
+            calls[0] += 1
+            if calls[0] % 8 == 0:
+                print(f"[sampler_parity] oracle evaluation {calls[0]} ({time.time() - t0:.0f} s)", flush=True)
+            return O.edm_forward(P, ecfg, dcfg, x, t, l, bf16=bf16)
+        return f
     with torch.no_grad():
-        x_f32 = O.heun_solve(lambda x, t, l: O.edm_forward(P, ecfg, dcfg, x, t, l, bf16=False), x0, ts, None)
-        x_bf = O.heun_solve(lambda x, t, l: O.edm_forward(P, ecfg, dcfg, x, t, l, bf16=True), x0, ts, None)
+        x_f32 = O.heun_solve(net(False), x0, ts, None)
+        x_bf = O.heun_solve(net(True), x0, ts, None) if a.bf16_oracle else x_f32
     cpu_s = time.time() - t0
 
     def rel(u, v):
@@ -64,8 +75,8 @@ def main():
     out = {"config": "CIFAR-10 unconditional U-Net (35.6M params, seeded weights, gains non-zero)", "heun_steps": a.steps,
            "nfe": 2 * a.steps - 1, "images": a.images,
            "hip_bf16net_vs_fp32_oracle_rel_l2": rel(x_hip, x_f32),
-           "hip_bf16net_vs_bf16_oracle_rel_l2": rel(x_hip, x_bf),
-           "bf16_oracle_vs_fp32_oracle_rel_l2": rel(x_bf, x_f32),
+           "hip_bf16net_vs_bf16_oracle_rel_l2": rel(x_hip, x_bf) if a.bf16_oracle else None,
+           "bf16_oracle_vs_fp32_oracle_rel_l2": rel(x_bf, x_f32) if a.bf16_oracle else None,
            "final_image_rms": x_f32.pow(2).mean().sqrt().item(),
            "max_abs_diff_vs_fp32": (x_hip - x_f32).abs().max().item(),
            "note": "state integrated in fp32 on both sides; only the network evaluation differs (bf16 operands, fp32 "
