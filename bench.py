@@ -114,26 +114,53 @@ def train_bench(args, rank, world, device):
         base.grad_scale = reducer.finish()
         opt.step()
         opt.zero_grad()
-        return loss
+        return loss.detach()
 
     # One GPU: the whole step (fwd + bwd + Adam/EMA, side stream included) is replayed from a hipGraph; the
     # per-step scalars come from a device record (tinyedm_amd/graph.py).  N > 1: the collective-bearing step stays
     # eager (RCCL all-reduces issued from autograd hooks, overlapped with the backward pass).
     eager_step = step
-    use_graph = world == 1 and not args.no_graph and not reducer.active
-    if use_graph:
+    from tinyedm_amd import _lib as _L
+    can_graph = world == 1 and not reducer.active
+    mode = args.step_launch if can_graph else "eager"
+    launch_info = {}
+    opt.zero_grad()
+    note(f"model built, warmup {args.warmup} steps")
+    for i in range(args.warmup):
+        loss = eager_step(i)
+    torch.cuda.synchronize()
+
+    def probe(fn, n=5):
+        """(wall ms per step, host enqueue ms per step, entry-point calls per step) over n steps"""
+        torch.cuda.synchronize()
+        c0, t0 = _L.N_CALLS, time.perf_counter()
+        for i in range(n):
+            fn(i)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        return (t2 - t0) / n * 1e3, (t1 - t0) / n * 1e3, (_L.N_CALLS - c0) / n
+    if rank == 0 or world > 1:
+        e_ms, e_host, e_calls = probe(eager_step)
+        launch_info = {"eager_probe_ms": round(e_ms, 3), "host_enqueue_ms_per_step": round(e_host, 3),
+                       "entry_point_calls_per_step": round(e_calls, 1)}
+    if can_graph and mode in ("auto", "graph"):
         from tinyedm_amd.graph import CapturedTrainStep
         captured = CapturedTrainStep(model, opt)
-
+        for i in range(CapturedTrainStep.WARMUP + 1):        # warm-up on the capture stream, then the capture itself
+            captured(batch)
+        g_ms, g_host, _ = probe(lambda i: captured(batch))
+        launch_info.update({"graph_probe_ms": round(g_ms, 3), "graph_host_ms_per_step": round(g_host, 3)})
+        if mode == "auto":
+            mode = "graph" if g_ms < launch_info["eager_probe_ms"] else "eager"
+        note(f"step launch probe: eager {launch_info['eager_probe_ms']:.2f} ms (host enqueue {e_host:.2f} ms), "
+             f"hipGraph replay {g_ms:.2f} ms -> timing the {mode} step")
+    if mode == "graph":
         def step(i):                            # noqa: F811
             return captured(batch)
-
-    opt.zero_grad()
-    note(f"model built, warmup {args.warmup} steps" + (" (hipGraph-captured step)" if use_graph else ""))
-    for i in range(max(args.warmup, 3 if use_graph else 0)):
-        loss = step(i)
-    torch.cuda.synchronize()
-    note(f"warmup done, timing {args.steps} steps")
+    use_graph = mode == "graph"
+    launch_info["step_launch"] = "hipGraph replay" if use_graph else "eager"
+    note(f"warmup done, timing {args.steps} steps ({launch_info['step_launch']})")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -182,7 +209,7 @@ def train_bench(args, rank, world, device):
         for name, recs in over.items():
             if name in roof:
                 roof[name]["ms_overlapped"] = sum(s.elapsed_time(e) for s, e, _, _ in recs)
-    return model, B * world * args.steps / dt, dt / args.steps * 1e3, final_loss, roof, use_graph
+    return model, B * world * args.steps / dt, dt / args.steps * 1e3, final_loss, roof, launch_info
 
 
 def sampler_bench(args, model, device):
@@ -268,11 +295,16 @@ def main():
     ap.add_argument("--sampler-batch", type=int, default=512)
     ap.add_argument("--sampler-iters", type=int, default=2)
     ap.add_argument("--no-sampler", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="time the eager Python step instead of the hipGraph replay")
+    ap.add_argument("--step-launch", choices=["auto", "graph", "eager"], default="auto",
+                    help="one GPU: time the hipGraph replay of the step, the eager Python step, or (auto) whichever a "
+                         "5-step probe finds faster; N > 1 ranks always run the eager, hook-driven step")
+    ap.add_argument("--no-graph", action="store_true", help="same as --step-launch eager")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=20, help="timed CPU-oracle steps (~0.5 s each on 16 threads)")
     args = ap.parse_args()
+    if args.no_graph:
+        args.step_launch = "eager"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -298,7 +330,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    model, ips, ms, final_loss, roof, used_graph = train_bench(args, rank, world, device)
+    model, ips, ms, final_loss, roof, launch_info = train_bench(args, rank, world, device)
     out = None
     if rank == 0:
         # dominant kernel: k_conv3x3_v4<5,0> (3x3 implicit GEMM of the 32x32 layers: forward convs, with the modulation
@@ -316,7 +348,7 @@ def main():
                                    "full training step: diffuse+embed+denoiser fwd/bwd+loss+grad all-reduce+Adam+EMA",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "conditional": bool(args.conditional), "final_loss": final_loss,
-                       "step_launch": "hipGraph replay" if used_graph else "eager",
+                       **launch_info,
                        "collective": ("rccl all-reduce (forced, 1 rank)" if forced else "rccl bucketed all-reduce")
                        if (world > 1 or forced) else "none"},
             "roofline": {

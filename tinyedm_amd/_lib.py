@@ -130,8 +130,13 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+N_CALLS = 0     # entry-point invocations so far (bench.py reports launches per step from it)
+
+
 def call(name: str, *args):
     """Invoke a status-returning entry point; raise HipKernelError on a non-zero status."""
+    global N_CALLS
+    N_CALLS += 1
     h = lib()
     rc = getattr(h, name)(*args)
     if name in _NO_STATUS:

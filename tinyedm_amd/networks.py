@@ -965,7 +965,17 @@ class _ConvOutFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gD):
         x, wh, gain_out, Fraw, sigma = ctx.saved_tensors
-        gx, gwh, gg = ops.conv_out_bwd(x, wh, gain_out, Fraw, gD.contiguous().float(), sigma, ctx.den.sigma_data)
+        # flat-arena mode: d loss / d gain_out is accumulated straight into the gradient arena (like the block gains):
+        # no AccumulateGrad node ever runs for a parameter, which is also what keeps a stream capture of the step
+        # independent of the stream earlier (eager) steps ran on
+        gp = ctx.den.gain_out
+        gdirect = gp.grad is not None and getattr(gp, "_edm_direct", False) and gp.grad.is_contiguous()
+        gx, gwh, gg = ops.conv_out_bwd(x, wh, gain_out, Fraw, gD.contiguous().float(), sigma, ctx.den.sigma_data,
+                                       gg_out=gp.grad if gdirect else None)
+        if gdirect:
+            gg = None
+            for hook in getattr(gp, "_edm_hooks", ()):
+                hook(gp)
         gw = ctx.den.conv_out.finish_grad(gwh.view(1, 1, *gwh.shape))
         return gx, gw, gg, None, None, None
 

@@ -338,7 +338,8 @@ def conv_out_fwd(x, w_hat, gain_out, noisy, sigma, sigma_data, want_fraw=True):
     return D, Fraw
 
 
-def conv_out_bwd(x, w_hat, gain_out, Fraw, dD, sigma, sigma_data):
+def conv_out_bwd(x, w_hat, gain_out, Fraw, dD, sigma, sigma_data, gg_out=None):
+    """gg_out: optional 0-dim fp32 tensor that d loss / d gain_out is ACCUMULATED into (else a fresh zero scalar)"""
     B, H, W, C = _nhwc(x, "x")
     Co = w_hat.shape[0]
     _chk(dD, f32, "dD", (B, Co, H, W))
@@ -346,7 +347,7 @@ def conv_out_bwd(x, w_hat, gain_out, Fraw, dD, sigma, sigma_data):
     ss = _sigma_arg(sigma, B)
     gx = torch.empty_like(x)
     gw = zeros_f32(w_hat.shape, w_hat.device)
-    gg = zeros_f32((), x.device)
+    gg = zeros_f32((), x.device) if gg_out is None else _chk(gg_out, f32, "gg_out", ())
     _lib.call("edm_conv_out_bwd", _p(x), _p(w_hat), _p(gain_out), _p(Fraw), _p(dD), _p(sigma), ss, float(sigma_data),
               _p(gx), _p(gw), _p(gg), B, H * W, C, Co, _stream())
     return gx, gw, gg
