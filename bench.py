@@ -165,12 +165,17 @@ def train_bench(args, rank, world, device):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    marks = []
     for i in range(args.steps):
         loss = step(args.warmup + i)
+        marks.append(time.perf_counter())
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    host = [(b - a) * 1e3 for a, b in zip([t0] + marks[:-1], marks)]
+    launch_info["host_step_ms_max"] = round(max(host), 2)
+    launch_info["host_step_ms_median"] = round(sorted(host)[len(host) // 2], 2)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

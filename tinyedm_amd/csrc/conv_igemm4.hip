@@ -15,6 +15,7 @@
 //  * 6-deep weight ring (5 tiles in flight), counted vmcnt immediates, raw s_barrier.
 // Geometry as generation 3: 512 pixels x 128 channels per workgroup, 8 waves x (128 co x 64 px), Cin % 64 == 0.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -26,6 +27,7 @@ constexpr int ROWB = KC * 2;      // 64-byte LDS rows
 // NI = 32-channel blocks per wave: 4 -> 512x128 workgroup tile (BN above); 2 -> 512x64, for layers too small to give
 // every CU a 512x128 tile (the 16x16 layers at batch 128: 64 pixel tiles x 2 channel tiles = 128 workgroups).
 constexpr int WRING = 6, D = WRING - 1;
+
 constexpr int ZERO_PAGE = 4096;
 
 __device__ __forceinline__ void dma16(const void* src, char* lds_dst) {
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
                                                          bf16* __restrict__ Y, const bf16* __restrict__ R,
                                                          const char* __restrict__ zeros, float alpha, float beta,
                                                          int Npix, int H, int W, int Cin, int Cout, int tiles_m,
-                                                         int tiles_n, ModEpilogue mod) {
+                                                         int tiles_n, int stagger, ModEpilogue mod) {
   apply_dyn(mod);
   constexpr int XROWS = NX * 8 * 16;  // LDS rows per slab buffer; rows >= xrows are zero rows
   constexpr int XBYTES = XROWS * ROWB;
@@ -89,6 +91,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = pixel octant of this wave
+  const bool late = stagger && wave >= 4;                       // second-dispatched half of the workgroup (see below)
   const int l31 = lane & 31, lhi = lane >> 5;
   const int drow = lane >> 2, dp = lane & 3;  // DMA lane -> (row in 16-row slot, physical 16-B chunk)
 
@@ -225,7 +228,17 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
         for (int i = 0; i < NX; ++i)
           dma16(xsrc[i] + (long)(chunk + 1) * (KC * 2), Xb + (cpar ^ 1) * XBYTES + (wave + 8 * i) * 1024);
       }
-      // ---- 2 x 8 MFMAs; all addresses = register + immediate
+      // ---- 2 x 8 MFMAs; all addresses = register + immediate.
+      // Stagger (MI355X_MICROARCH.md, "Two waves per SIMD", item 9): the two waves of a SIMD run this same program in
+      // lockstep -- both read, then both multiply.  Waves 4-7 therefore DEFER the second half-step's 8 MFMAs (their
+      // operands are already in registers) to just behind the next barrier, where waves 0-3 are issuing DMA and
+      // fragment reads: after every barrier one partner feeds the matrix pipe while the other feeds the LDS pipe.
+      // The deferred MFMAs touch registers only, so the ring-slot reuse rules are unchanged (every read of tile t is
+      // still retired before the barrier of step t+1).
+      if (late && !(u == 0 && chunk2 == 0)) {
+        mfma_half(1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (u == 0 && chunk2 == 0) READ_HALF(0, 0, 0, 0, 0);  // pipeline fill (first step of the kernel only)
       READ_HALF(1, 1, tap, cpar, u % WRING);
       lgkm_wait<2 + NI>();
@@ -237,10 +250,13 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
       } else {
         lgkm_wait<0>();
       }
-      mfma_half(1);
-      __builtin_amdgcn_sched_barrier(0);
+      if (!late) {
+        mfma_half(1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     });
   }
+  if (late) mfma_half(1);   // the last step's deferred half
 #undef READ_HALF
 
   // ---- epilogue: transposed through wave-private LDS so that residual reads and stores are whole rows
@@ -257,13 +273,14 @@ void launch4(const void* X, const void* Wp, void* Y, const void* R, float alpha,
   const size_t lds = (size_t)2 * NX * 8 * 16 * ROWB + WRING * (32 * NI * ROWB);
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
   auto kern = k_conv3x3_v4<NX, EPI, NI>;
+  static const int stagger = [] { const char* e = getenv("EDM_V4_STAGGER"); return e ? atoi(e) : 1; }();
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const bf16*)X, (const bf16*)Wp, (bf16*)Y, (const bf16*)R,
-                     (const char*)edm_zero_page(), alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n, mod);
+                     (const char*)edm_zero_page(), alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n, stagger, mod);
 }
 
 }  // namespace

@@ -15,6 +15,7 @@
 //  * `k_wgrad3_finish` (one launch per group, one workgroup per weight row) sums a row's partials, applies the
 //    weight-normalisation projection and accumulates into the gradient arena.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -61,16 +62,33 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-#define TR_RD(dst, base, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "i"(imm))
+#define TR_RD_(dst, base, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "i"(imm))
+// timing-only builds with ABL bit 4 keep the registers "written" without reading LDS
+#define TR_RD(dst, base, imm)                                     \
+  do {                                                            \
+    if constexpr (ABL & 16) asm volatile("" : "=v"(dst) : "v"(base)); \
+    else TR_RD_(dst, base, imm);                                  \
+  } while (0)
 #define LGKM_WAIT(n)                                       \
   asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory");  \
   __builtin_amdgcn_sched_barrier(0)
+template <int N>
+struct IC { static constexpr int value = N; };
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(IC<B>{});
+    static_for<B + 1, E>(f);
+  }
+}
 __device__ __forceinline__ bf16x8 frag_of(const u32x2_t& lo, const u32x2_t& hi) {
   u32x4 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int LEADS>
+// ABL: timing-only ablation builds for tools/ (outputs wrong by construction): bit0 no MFMA, bit1 no DMA issue,
+// bit2 no barrier, bit3 no fragment reads + MFMA.  ABL = 0 is the product.
+template <int LEADS, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void k_wgrad3(const W3Group g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int XR = Ring<LEADS>::XR, MIRR = Ring<LEADS>::MIRR, XSLOTS = Ring<LEADS>::XSLOTS;
@@ -190,77 +208,101 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3(const W3Group g) {
       // retire dY(t) and X(t+2*LEADS); dY(t+1) (4 DMAs per wave, issued last) may stay in flight
       if (t + 1 < nst) wait_vmcnt<4>();
       else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      if (t + 2 <= nst) {
+      if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
+      // ---- sources of this stage's DMAs: X(t+2*LEADS+1), then dY(t+2) (dY(t+2) has the rows of X(t+2+LEADS): the
+      // stage decoded here when LEADS == 1, the one decoded a stage earlier when LEADS == 2).  They are ISSUED further
+      // down, spread between the MFMAs (an LDS-DMA instruction costs the issuing wave 60-180 cycles: issued in a block
+      // in front of the MFMAs they took 20 % of the kernel).
+      const bool do_x = t + 2 <= nst && !(ABL & 2), do_dy = t + 2 < nst && !(ABL & 2);
+      const bf16* xsrc0 = g.zeros;
+      const bf16* xsrc1 = g.zeros;
+      const bf16* dsrc[4] = {g.zeros, g.zeros, g.zeros, g.zeros};
+      const int xslot = (t + 2 * LEADS + 1) & (XR - 1);
+      if (do_x) {
         const long kpp = kp;
         const int wp = sw, hp = sh, np_ = sn;
         advance();
-        issue_x(t + 2 * LEADS + 1);
-        if (t + 2 < nst) {
+        bool valid;
+        long pix = pixel(valid);
+        if (valid && ci0 < Cin) xsrc0 = X + pix * Cin + ci0 + dp * 8;
+        if (valid && ci0 + 32 < Cin) xsrc1 = X + pix * Cin + ci0 + 32 + dp * 8;
+        if (do_dy) {
+          long kq = kp;
           if (LEADS == 2) {
+            // decode state of the previous stage
             const long kpn = kp;
             const int wn = sw, hn = sh, nn = sn;
             kp = kpp; sw = wp; sh = hp; sn = np_;
-            issue_dy(t + 2);
+            pix = pixel(valid);
+            kq = kp;
             kp = kpn; sw = wn; sh = hn; sn = nn;
-          } else {
-            issue_dy(t + 2);
           }
+          valid = valid && kq < ks1;
+#pragma unroll
+          for (int sub = 0; sub < 4; ++sub)
+            if (valid && co0 + sub * 32 < Cout) dsrc[sub] = dY + pix * Cout + co0 + sub * 32 + dp * 8;
         }
       }
-      {
+      char* const xdst = Xb + xslot * SUBB + wave * 1024;
+      char* const ddst = dYb + ((t + 2) % DYRING) * (4 * SUBB) + wave * 1024;
+      if constexpr (!(ABL & 8)) {
         const int slot = (t + LEADS) & (XR - 1);                        // X stage t+LEADS is the centre of the window
         const int base_row = (slot < LEADS ? slot + XR : slot) * KP;    // mirrored position when the window would wrap
-        const unsigned a_u = (unsigned)(uintptr_t)(lds_char*)dYb + (t % DYRING) * (4 * SUBB) + (cb * 2) * SUBB + krow_l * 64 + chan_b;
+        unsigned a_u = (unsigned)(uintptr_t)(lds_char*)dYb + (t % DYRING) * (4 * SUBB) + (cb * 2) * SUBB + krow_l * 64 + chan_b;
         const unsigned b_u = (unsigned)(uintptr_t)(lds_char*)Xb + ib * (XSLOTS * SUBB) + (base_row + krow_l) * 64 + chan_b;
         unsigned tb[9];
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) tb[tp] = b_u + ((tp / 3 - 1) * PW + (tp % 3 - 1)) * 64;
-        u32x2_t A[2][2][2], Bf[2][3][2];
-        // item (k-step ks, tap group gg): 6 MFMAs; its X fragments are read one item ahead, the dY fragments of
-        // k-step ks+1 during item (ks, 2).  At most 12 LDS reads are outstanding (lgkmcnt is a 4-bit counter).
-#define RD_A(ks)                                                                                     \
-  TR_RD(A[(ks) & 1][0][0], a_u, (ks) * 1024);        TR_RD(A[(ks) & 1][0][1], a_u, (ks) * 1024 + 256);        \
-  TR_RD(A[(ks) & 1][1][0], a_u, SUBB + (ks) * 1024); TR_RD(A[(ks) & 1][1][1], a_u, SUBB + (ks) * 1024 + 256)
-#define RD_B(set, ks, gg)                                                                                   \
-  TR_RD(Bf[set][0][0], tb[3 * (gg) + 0], (ks) * 1024); TR_RD(Bf[set][0][1], tb[3 * (gg) + 0], (ks) * 1024 + 256); \
-  TR_RD(Bf[set][1][0], tb[3 * (gg) + 1], (ks) * 1024); TR_RD(Bf[set][1][1], tb[3 * (gg) + 1], (ks) * 1024 + 256); \
-  TR_RD(Bf[set][2][0], tb[3 * (gg) + 2], (ks) * 1024); TR_RD(Bf[set][2][1], tb[3 * (gg) + 2], (ks) * 1024 + 256)
-#define MM1(i, set, ks, gg, j)                                                                         \
-  acc[i][3 * (gg) + (j)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                    \
-      frag_of(A[(ks) & 1][i][0], A[(ks) & 1][i][1]), frag_of(Bf[set][j][0], Bf[set][j][1]), acc[i][3 * (gg) + (j)], 0, 0, 0)
-// tap 8 accumulates in ARCHITECTURAL VGPRs: hipcc allocates builtin-MFMA accumulators to the 256 AGPRs only (16
-// blocks), the 17th and 18th block would spill; an asm MFMA with "+v" operands keeps them in v[] (the register file
-// is unified, 288 accumulator registers + ~120 others fit).  Same-register C/D chains need no wait states.
-#define MMV(i, set, ks)                                                                                  \
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"                                                 \
-               : "+v"(accv[i])                                                                           \
-               : "v"(frag_of(A[(ks) & 1][i][0], A[(ks) & 1][i][1])), "v"(frag_of(Bf[set][2][0], Bf[set][2][1])))
-#define MM6(set, ks, gg)                                                                   \
-  MM1(0, set, ks, gg, 0); MM1(1, set, ks, gg, 0); MM1(0, set, ks, gg, 1); MM1(1, set, ks, gg, 1); \
-  MM1(0, set, ks, gg, 2); MM1(1, set, ks, gg, 2)
-#define MM6V(set, ks)                                                                      \
-  MM1(0, set, ks, 2, 0); MM1(1, set, ks, 2, 0); MM1(0, set, ks, 2, 1); MM1(1, set, ks, 2, 1); \
-  MMV(0, set, ks); MMV(1, set, ks)
-        RD_A(0); RD_B(0, 0, 0); LGKM_WAIT(6);
-        RD_B(1, 0, 1); LGKM_WAIT(6); MM6(0, 0, 0);
-        RD_B(0, 0, 2); LGKM_WAIT(6); MM6(1, 0, 1);
-        RD_A(1); LGKM_WAIT(4); RD_B(1, 1, 0); MM6V(0, 0);
-        RD_B(0, 1, 1); LGKM_WAIT(6); MM6(1, 1, 0);
-        RD_B(1, 1, 2); LGKM_WAIT(6); MM6(0, 1, 1);
-        RD_A(2); LGKM_WAIT(4); RD_B(0, 2, 0); MM6V(1, 1);
-        RD_B(1, 2, 1); LGKM_WAIT(6); MM6(0, 2, 0);
-        RD_B(0, 2, 2); LGKM_WAIT(6); MM6(1, 2, 1);
-        RD_A(3); LGKM_WAIT(4); RD_B(1, 3, 0); MM6V(0, 2);
-        RD_B(0, 3, 1); LGKM_WAIT(6); MM6(1, 3, 0);
-        RD_B(1, 3, 2); LGKM_WAIT(6); MM6(0, 3, 1);
-        LGKM_WAIT(0); MM6V(1, 3);
-#undef RD_A
-#undef RD_B
-#undef MM1
-#undef MM6
-#undef MM6V
-#undef MMV
+        // ---- 72 MFMAs of this stage: k-step ks (16 rows) x tap p; fragment n = 9 ks + p.  Everything is inline asm in
+        // program order: one MFMA, then ONE fragment read for three fragments ahead (the wave issues in order: reads
+        // placed in a block in front of a block of MFMAs do not overlap with them -- measured: reads+waits alone 281 us,
+        // MFMAs alone 264 us, together 638 us), waits counted per position.  The dY fragments of k-step ks+1 are read
+        // behind taps 4 and 5.  At most 10 LDS reads are outstanding (lgkmcnt is a 4-bit counter).
+        u32x2_t A[2][2][2], Bf[6][2];
+        TR_RD(A[0][0][0], a_u, 0); TR_RD(A[0][0][1], a_u, 256);
+        TR_RD(A[0][1][0], a_u, SUBB); TR_RD(A[0][1][1], a_u, SUBB + 256);
+        TR_RD(Bf[0][0], tb[0], 0); TR_RD(Bf[0][1], tb[0], 256);
+        TR_RD(Bf[1][0], tb[1], 0); TR_RD(Bf[1][1], tb[1], 256);
+        TR_RD(Bf[2][0], tb[2], 0); TR_RD(Bf[2][1], tb[2], 256);
+        static_for<0, 36>([&](auto nc) {
+          constexpr int n = decltype(nc)::value;
+          constexpr int ks = n / 9, p = n % 9;
+          const unsigned au_ = a_u;      // (named outside the `if constexpr` below so that the generic lambda captures it)
+          // reads younger than fragment n at this point: fragments n+1, n+2 (if any) + the next k-step's dY reads
+          constexpr int cnt = ks < 3 ? (p == 5 || p == 8 ? 6 : (p == 6 || p == 7 ? 8 : 4))
+                                     : (p <= 6 ? 4 : (p == 7 ? 2 : 0));
+          if constexpr (!(ABL & 32)) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(cnt) : "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          // DMA issue points (X first, then dY: the order the stage-level vmcnt counts on)
+          if constexpr (n == 1) { if (do_x) { dma16(xsrc0, xdst); if (xslot < MIRR) dma16(xsrc0, xdst + XR * SUBB); } __builtin_amdgcn_sched_barrier(0); }
+          if constexpr (n == 5) { if (do_x) { dma16(xsrc1, xdst + XSLOTS * SUBB); if (xslot < MIRR) dma16(xsrc1, xdst + (XSLOTS + XR) * SUBB); } __builtin_amdgcn_sched_barrier(0); }
+          if constexpr (n == 10) { if (do_dy) dma16(dsrc[0], ddst); __builtin_amdgcn_sched_barrier(0); }
+          if constexpr (n == 14) { if (do_dy) dma16(dsrc[1], ddst + SUBB); __builtin_amdgcn_sched_barrier(0); }
+          if constexpr (n == 19) { if (do_dy) dma16(dsrc[2], ddst + 2 * SUBB); __builtin_amdgcn_sched_barrier(0); }
+          if constexpr (n == 23) { if (do_dy) dma16(dsrc[3], ddst + 3 * SUBB); __builtin_amdgcn_sched_barrier(0); }
+          const bf16x8 bfr = frag_of(Bf[n % 6][0], Bf[n % 6][1]);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const bf16x8 afr = frag_of(A[ks & 1][i][0], A[ks & 1][i][1]);
+            if constexpr (!(ABL & 1)) {
+              // taps 0..7 accumulate in AGPRs; tap 8 in architectural VGPRs (256 AGPRs hold 16 of the 18 blocks)
+              if constexpr (p < 8) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][p < 8 ? p : 0]) : "v"(afr), "v"(bfr));
+              else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accv[i]) : "v"(afr), "v"(bfr));
+            }
+            if constexpr (n + 3 < 36) {      // one read of fragment n+3 behind each MFMA
+              constexpr int m = n + 3;
+              TR_RD(Bf[m % 6][i], tb[m % 9], (m / 9) * 1024 + i * 256);
+            }
+          }
+          if constexpr (ks < 3 && (p == 4 || p == 5)) {   // dY fragments of k-step ks+1: co block p-4
+            constexpr int ia = p - 4;
+            TR_RD(A[(ks + 1) & 1][ia][0], au_, ia * SUBB + (ks + 1) * 1024);
+            TR_RD(A[(ks + 1) & 1][ia][1], au_, ia * SUBB + (ks + 1) * 1024 + 256);
+          }
+        });
+      } else {
+        if (do_x) { dma16(xsrc0, xdst); if (xslot < MIRR) dma16(xsrc0, xdst + XR * SUBB); dma16(xsrc1, xdst + XSLOTS * SUBB); if (xslot < MIRR) dma16(xsrc1, xdst + (XSLOTS + XR) * SUBB); }
+        if (do_dy) { dma16(dsrc[0], ddst); dma16(dsrc[1], ddst + SUBB); dma16(dsrc[2], ddst + 2 * SUBB); dma16(dsrc[3], ddst + 3 * SUBB); }
       }
     }
     // ---- flush the partial tile: [tap][128 co][64 ci] fp32, always whole (inactive blocks hold zeros).
@@ -469,7 +511,27 @@ extern "C" int edm_wgrad3_group(const edm_wgrad3_item* items, int n, void* works
   P.wg.zeros = zeros;
   P.fg.work = (const float*)workspace;
   static bool set1 = false, set2 = false, setf = false;
-  if (P.leads == 1) {
+  static const int abl = [] { const char* e = getenv("EDM_W3_ABLATE"); return e ? atoi(e) : 0; }();   // tools only
+  if (P.leads == 1 && abl) {
+    auto go = [&](auto kern) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL(kern, dim3(P.wg.nwg), dim3(256), Ring<1>::LDS, st, P.wg);
+    };
+    switch (abl) {
+      case 1: go(k_wgrad3<1, 1>); break;
+      case 2: go(k_wgrad3<1, 2>); break;
+      case 4: go(k_wgrad3<1, 4>); break;
+      case 6: go(k_wgrad3<1, 6>); break;
+      case 8: go(k_wgrad3<1, 8>); break;
+      case 10: go(k_wgrad3<1, 10>); break;
+      case 16: go(k_wgrad3<1, 16>); break;
+      case 34: go(k_wgrad3<1, 34>); break;
+      case 38: go(k_wgrad3<1, 38>); break;
+      case 18: go(k_wgrad3<1, 18>); break;
+      case 22: go(k_wgrad3<1, 22>); break;
+      default: go(k_wgrad3<1, 14>); break;
+    }
+  } else if (P.leads == 1) {
     if (!set1) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       set1 = true;
