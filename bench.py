@@ -25,6 +25,7 @@ import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import tinyedm_amd  # noqa: E402,F401  (before the first GPU call: sets the HIP runtime flag hipGraph replay needs)
 
 
 def note(msg):
@@ -69,12 +70,14 @@ HBM_PEAK_GBS = 8000.0
 def pmc_traffic(kernel):
     """HBM GB per launch of `kernel` from the committed PMC summary (tools/pmc_hbm.py; counters cannot be read from
     inside the process, so this is the offline measurement of the same command), or None."""
+    import glob
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as f:
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))[-1]     # newest round's pass
+        with open(path) as f:
             ks = json.load(f)["kernels"]
-        rec = ks.get(kernel + "<5, 0, 4>") or ks.get(kernel + "<5, 0>") or ks.get(kernel)
+        rec = next((v for k, v in ks.items() if k.startswith(kernel + "<5, 0, 4")), None) or ks.get(kernel)
         return None if rec is None else round(rec["hbm_gb_per_launch"], 4)
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError, KeyError, IndexError):
         return None
 
 
@@ -141,7 +144,7 @@ def train_bench(args, rank, world, device):
         t2 = time.perf_counter()
         return (t2 - t0) / n * 1e3, (t1 - t0) / n * 1e3, (_L.N_CALLS - c0) / n
     if rank == 0 or world > 1:
-        e_ms, e_host, e_calls = probe(eager_step)
+        e_ms, e_host, e_calls = probe(eager_step, 10)
         launch_info = {"eager_probe_ms": round(e_ms, 3), "host_enqueue_ms_per_step": round(e_host, 3),
                        "entry_point_calls_per_step": round(e_calls, 1)}
     if can_graph and mode in ("auto", "graph"):
@@ -149,7 +152,9 @@ def train_bench(args, rank, world, device):
         captured = CapturedTrainStep(model, opt)
         for i in range(CapturedTrainStep.WARMUP + 1):        # warm-up on the capture stream, then the capture itself
             captured(batch)
-        g_ms, g_host, _ = probe(lambda i: captured(batch))
+        for i in range(3):                                   # the first replays upload the executable graph
+            captured(batch)
+        g_ms, g_host, _ = probe(lambda i: captured(batch), 10)
         launch_info.update({"graph_probe_ms": round(g_ms, 3), "graph_host_ms_per_step": round(g_host, 3)})
         if mode == "auto":
             mode = "graph" if g_ms < launch_info["eager_probe_ms"] else "eager"
@@ -181,37 +186,37 @@ def train_bench(args, rank, world, device):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     final_loss = float(loss.detach())
+    wnorm = float(base.arena.theta.norm())
+    if not (final_loss == final_loss and abs(final_loss) < 1e4 and wnorm == wnorm and wnorm < 1e6):
+        # a diverged / corrupted run draws less power, clocks higher and "wins": never report it
+        raise RuntimeError(f"bench: loss {final_loss}, |weights| {wnorm} after the timed region -- the step is broken")
     note(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
 
-    # ---- roofline of the dominant kernel (3x3 implicit-GEMM conv): one extra, instrumented step AFTER the
+    # ---- roofline of the dominant kernel (3x3 implicit-GEMM conv): one extra, instrumented EAGER step AFTER the
     # timed region: HIP events around every launch on the launch stream; algorithmic FLOPs from the shapes.
-    # Every rank runs the extra steps (they contain the gradient all-reduce); only rank 0 instruments them.
-    # Two instrumented steps: (a) as timed (weight-gradient kernels overlapped on the side stream: per-kernel
-    # durations include contention), (b) with the side stream off (kernels back to back on one stream: the isolated
-    # per-launch durations the roofline is quoted on; EDM_WGRAD_STREAM=0 reproduces it under rocprofv3).
+    # Every rank runs the extra step (it contains the gradient all-reduce); only rank 0 instruments it.  Kernels run
+    # back to back on one stream (the weight-gradient side stream is off by default since round 2); when it is enabled
+    # (EDM_WGRAD_STREAM=1) a second instrumented step records the per-kernel durations under that overlap too.
     from tinyedm_amd import networks as _nets
     roof = None
-    roofs = []
-    for overlapped in (True, False):
+    roofs = {}
+    for overlapped in ((False, True) if _nets.WGRAD_STREAM else (False,)):
         saved = _nets.WGRAD_STREAM
         _nets.WGRAD_STREAM = saved and overlapped
         if rank == 0:
             ops.PROFILE = {}
-        eager_step(args.warmup + args.steps + (0 if overlapped else 1))
+        eager_step(args.warmup + args.steps + int(overlapped))
         torch.cuda.synchronize()
         _nets.WGRAD_STREAM = saved
         if rank == 0:
-            prof, ops.PROFILE = ops.PROFILE, None
-            roofs.append(prof)
+            roofs[overlapped], ops.PROFILE = ops.PROFILE, None
     if rank == 0:
-        prof = roofs[1]
-        over = roofs[0]
         roof = {}
-        for name, recs in prof.items():
+        for name, recs in roofs[False].items():
             ms = sum(s.elapsed_time(e) for s, e, _, _ in recs)
             roof[name] = {"launches": len(recs), "ms": ms, "gflop": sum(f for _, _, f, _ in recs) / 1e9,
                           "gbytes": sum(b for _, _, _, b in recs) / 1e9}
-        for name, recs in over.items():
+        for name, recs in roofs.get(True, {}).items():
             if name in roof:
                 roof[name]["ms_overlapped"] = sum(s.elapsed_time(e) for s, e, _, _ in recs)
     return model, B * world * args.steps / dt, dt / args.steps * 1e3, final_loss, roof, launch_info
@@ -362,7 +367,7 @@ def main():
                 "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "traffic_unit": "GB of HBM traffic per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc "
-                                "passes, profiles/r01_pmc_hbm.json)",
+                                "passes, newest profiles/r*_pmc_hbm.json)",
                 "algorithmic_gbytes_per_launch": round(conv["gbytes"] / max(1, conv["launches"]), 4),
                 "library_gemm_tflops_same_shape": 1031.0,
                 "achieved_overlapped": round(conv["gflop"] / conv["ms_overlapped"], 2) if conv.get("ms_overlapped") else None,

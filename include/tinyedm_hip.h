@@ -24,6 +24,11 @@ const char* edm_last_error(void);
 /* per-device constants (a 4 KiB page of zeros the LDS-DMA kernels point padding rows at): allocate once per device,
  * outside any stream capture; idempotent and thread-safe.  Every kernel that needs the page fails with -1 until then. */
 int edm_init(int device);
+/* hipGraph capture of these entry points: on ROCm 7.2 the runtime's default AQL-packet-capture path runs the first
+ * replay that follows a hipStreamSynchronize / hipDeviceSynchronize with clobbered kernel arguments.  The library's
+ * load-time constructor therefore sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 when the variable is unset (the runtime reads
+ * it at its first HIP call: load this library before that).  Returns 1 when the environment holds the safe value. */
+int edm_graph_replay_safe(void);
 /* Per-step scalars of a hipGraph-captured training step.  By-value arguments are frozen into a graph at capture time;
  * entry points with a `dyn` parameter read these fields from DEVICE memory instead when dyn != NULL, so the host can
  * rewrite the 48-byte record (one small async copy) before every replay: step/seed feed the Philox streams of dropout

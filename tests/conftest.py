@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import tinyedm_amd  # noqa: E402,F401  (before any GPU call: sets the HIP runtime flag the hipGraph paths need)
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 TESTS = os.path.join(ROOT, "tests")
 if TESTS not in sys.path:

@@ -106,3 +106,33 @@ def test_replays_draw_fresh_noise():
     step = CapturedTrainStep(model, opt)
     losses = [float(step(b)) for _ in range(5)]
     assert len(set(round(l, 5) for l in losses)) == 5, losses
+
+
+def test_replay_after_stream_sync_is_not_corrupted():
+    """ROCm 7.2 runtime bug (tinyedm_amd/_runtime_env.py): the first hipGraph replay after a stream / device
+    synchronisation ran with clobbered kernel arguments.  tests/graph_sync_probe.py is the sequence that failed every
+    time; it runs in its own process so that the flag is set by the package import alone."""
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "graph_sync_probe.py")], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    last = out.stdout.strip().splitlines()[-1]
+    record("graph/replay_after_sync_clean", 0.0 if last.startswith("CLEAN") else 1.0, 0.0)
+    assert last.startswith("CLEAN"), last
+    # informational: the same sequence with the runtime's default path (documents whether the bug is still there)
+    env["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(here, "graph_sync_probe.py")], env=env, capture_output=True,
+                         text=True, timeout=300)
+    lines = out.stdout.strip().splitlines()
+    print("default runtime path:", lines[-1][:200] if lines else out.stderr[-300:])
+
+
+def test_graph_paths_refuse_when_the_runtime_flag_is_unsafe(monkeypatch):
+    from tinyedm_amd import _runtime_env
+    monkeypatch.setattr(_runtime_env, "GRAPH_REPLAY_SAFE", False)
+    with pytest.raises(RuntimeError, match="hipGraph replay is unsafe"):
+        _runtime_env.require_graph_replay_safe("test")

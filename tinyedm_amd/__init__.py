@@ -3,6 +3,7 @@
 alias package re-exports these names so reference configs (``_target_: tinyedm.EDM``) resolve."""
 __version__ = "0.1.0"
 
+from . import _runtime_env  # noqa: F401  (first: sets HIP runtime flags before anything can initialise the GPU)
 from .edm import EDM, Diffuser
 from .ema import EMA, EMAOptimizer, FusedAdam, sigma_rel_to_gamma
 from .metric import WeightedMeanSquaredError

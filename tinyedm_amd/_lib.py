@@ -18,6 +18,7 @@ SIGNATURES = {
     "edm_last_error": [],
     # runtime.hip
     "edm_init": [I],
+    "edm_graph_replay_safe": [],
     # elementwise.hip
     "edm_pixelnorm_silu_fwd": [P, P, P, P, L, I, P],
     "edm_pixelnorm_silu_bwd": [P, P, P, F, P, P, L, I, P],
@@ -92,7 +93,7 @@ DIAG_SIGNATURES = {
     "edm_conv_igemm_v2_ablate": [P, P, P, I, I, I, I, I, I, P],
 }
 _RET = {"edm_last_error": ctypes.c_char_p, "edm_wgrad3_workspace": ctypes.c_long}
-_NO_STATUS = {"edm_version", "edm_last_error", "edm_conv_wgrad_nsplit", "edm_conv_wgrad_1x1_nsplit", "edm_wgrad3_workspace"}
+_NO_STATUS = {"edm_version", "edm_graph_replay_safe", "edm_last_error", "edm_conv_wgrad_nsplit", "edm_conv_wgrad_1x1_nsplit", "edm_wgrad3_workspace"}
 
 _lib = None
 

@@ -56,7 +56,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 // Fragment reads are issued from inline asm and retired by hand-counted lgkmcnt: left to itself hipcc answers a
 // "6 older + 6 younger reads in flight" state with s_waitcnt lgkmcnt(0), which serialises the two halves again.
-#define LDS_RD128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
+#define LDS_RD128_(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
+#define LDS_RD128(dst, addr, imm)                                   \
+  do {                                                              \
+    if constexpr (ABL & 16) asm volatile("" : "=v"(dst) : "v"(addr)); \
+    else LDS_RD128_(dst, addr, imm);                                \
+  } while (0)
 #define LGKM_WAIT(n)                                       \
   asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory");  \
   __builtin_amdgcn_sched_barrier(0)
@@ -66,14 +71,21 @@ __device__ __forceinline__ void lgkm_wait() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int NX, int EPI = 0, int NI = 4>
-__global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ X, const bf16* __restrict__ Wp,
+// ABL: timing-only ablation builds for tools/ (outputs wrong by construction): bit0 no MFMA, bit1 no DMA issue in the
+// loop, bit2 no barrier, bit4 no fragment reads.  ABL = 0 is the product.
+// NJ = 32-pixel blocks per wave: 2 -> 512-pixel tile, 254 registers, one workgroup per CU (the product).  NJ = 1 (256x64
+// tile, <= 128 registers, TWO workgroups per CU so that one's prologue / epilogue / reads run under the other's MFMAs)
+// was built and measured in round 2: correct, but 20 % SLOWER on the 32x32 layers (177 vs 147 us) and equal on the
+// 16x16 ones -- the smaller tile doubles the weight staging and the barriers per MFMA; it is not dispatched.
+template <int NX, int EPI = 0, int NI = 4, int ABL = 0, int NJ = 2>
+__global__ __launch_bounds__(512, NJ == 1 ? 4 : 2) void k_conv3x3_v4(const bf16* __restrict__ X, const bf16* __restrict__ Wp,
                                                          bf16* __restrict__ Y, const bf16* __restrict__ R,
                                                          const char* __restrict__ zeros, float alpha, float beta,
                                                          int Npix, int H, int W, int Cin, int Cout, int tiles_m,
                                                          int tiles_n, int stagger, ModEpilogue mod) {
   apply_dyn(mod);
   constexpr int XROWS = NX * 8 * 16;  // LDS rows per slab buffer; rows >= xrows are zero rows
+  constexpr int BMW = 8 * 32 * NJ;    // pixels per workgroup
   constexpr int XBYTES = XROWS * ROWB;
   constexpr int BNW = 32 * NI;        // output channels per workgroup
   constexpr int WTILE = BNW * ROWB;   // 8 KiB (NI = 4) or 4 KiB weight tile
@@ -85,9 +97,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
   const int xcd = id & 7, k = id >> 3;
   const int tn = k % tiles_n, tm = (k / tiles_n) * 8 + xcd;
   if (tm >= tiles_m) return;
-  const int m0 = tm * BM, n0 = tn * BNW;
+  const int m0 = tm * BMW, n0 = tn * BNW;
   const int HALO = W + 1;
-  const int xrows = BM + 2 * HALO;  // < XROWS (host-checked): row XROWS-1 is always a zero row
+  const int xrows = BMW + 2 * HALO;  // < XROWS (host-checked): row XROWS-1 is always a zero row
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = pixel octant of this wave
@@ -126,10 +138,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
 
   // ---- the 36 pixel-fragment LDS addresses (tap, pixel block, k-step), border masks folded in
   const unsigned xb_off = (unsigned)(uintptr_t)(lds_char*)Xb;
-  unsigned bp[TAPS][2];  // LDS byte offsets for k-step 0; k-step 1 = same offset with bit 5 flipped (chunk ^ 2)
+  unsigned bp[TAPS][NJ];  // LDS byte offsets for k-step 0; k-step 1 = same offset with bit 5 flipped (chunk ^ 2)
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int ml = wave * 64 + j * 32 + l31;
+  for (int j = 0; j < NJ; ++j) {
+    const int ml = wave * (32 * NJ) + j * 32 + l31;
     const int m = m0 + ml;
     const int w = m % W, h = (m / W) % H;
 #pragma unroll
@@ -146,11 +158,11 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
   const unsigned wb_off = (unsigned)(uintptr_t)(lds_char*)Wb;
   const unsigned ap[2] = {wb_off + l31 * ROWB + (((0 + lhi) ^ a_sw) << 4), wb_off + l31 * ROWB + (((2 + lhi) ^ a_sw) << 4)};
 
-  f32x16 acc[NI][2];
+  f32x16 acc[NI][NJ];
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -167,25 +179,26 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
   // of the NEXT half are in flight while the current half computes, so the LDS pipe and the matrix pipe overlap
   // inside one wave instead of alternating (all 8 waves of the group are barrier-aligned, so they would otherwise
   // all read, then all compute).  The barrier at the top of step u therefore retires tile u+1 as well as tile u.
-  u32x4 fa[2][NI], fb[2][2];
+  u32x4 fa[2][NI], fb[2][NJ];
   auto mfma_half = [&](int set) {
+    if constexpr (ABL & 1) return;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][i]),
-                                                         __builtin_bit_cast(bf16x8, fb[set][0]), acc[i][0], 0, 0, 0);
-      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][i]),
-                                                         __builtin_bit_cast(bf16x8, fb[set][1]), acc[i][1], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][i]),
+                                                           __builtin_bit_cast(bf16x8, fb[set][j]), acc[i][j], 0, 0, 0);
     }
   };
 #define READ_HALF(set, ks, tap, cpar, slot)                                               \
   {                                                                                       \
-    unsigned o0 = bp[tap][0], o1 = bp[tap][1];                                            \
+    unsigned o0 = bp[tap][0], o1 = bp[tap][NJ - 1];                                       \
     if (ks) { /* opaque xor: keep 18, not 36, address registers */                        \
       asm volatile("v_xor_b32 %0, 32, %1" : "=v"(o0) : "v"(bp[tap][0]));                  \
-      asm volatile("v_xor_b32 %0, 32, %1" : "=v"(o1) : "v"(bp[tap][1]));                  \
+      if constexpr (NJ == 2) asm volatile("v_xor_b32 %0, 32, %1" : "=v"(o1) : "v"(bp[tap][NJ - 1])); \
     }                                                                                     \
     LDS_RD128(fb[set][0], o0, (cpar) * XBYTES);                                           \
-    LDS_RD128(fb[set][1], o1, (cpar) * XBYTES);                                           \
+    if constexpr (NJ == 2) LDS_RD128(fb[set][NJ - 1], o1, (cpar) * XBYTES);               \
     LDS_RD128(fa[set][0], ap[ks], (slot) * WTILE + 0 * 32 * ROWB);                        \
     LDS_RD128(fa[set][1], ap[ks], (slot) * WTILE + 1 * 32 * ROWB);                        \
     if constexpr (NI == 4) {                                                              \
@@ -213,9 +226,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
           default: wait_vmcnt<0>(); break;
         }
       }
-      __builtin_amdgcn_s_barrier();
+      if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
       // ---- issue weight tile t+D into the ring slot read at iteration t-1, then (tap 0) the next slab
-      {
+      if constexpr (!(ABL & 2)) {
         constexpr int tq = tap + D;                       // tap index of tile t+D, maybe in the next chunk
         constexpr int cq = cpar + (tq >= TAPS ? 1 : 0);   // chunk offset from chunk2 (0, 1 or 2)
         constexpr int tapq = tq >= TAPS ? tq - TAPS : tq;
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
           dma16(wsrc + (long)(chunk2 + cq) * (KC * 2) + tapq * tap_stride,
                 Wb + ((u + D) % WRING) * WTILE + wave * (WROWS * ROWB));
       }
-      if (tap == 0 && more_chunks) {
+      if (tap == 0 && more_chunks && !(ABL & 2)) {
 #pragma unroll
         for (int i = 0; i < NX; ++i)
           dma16(xsrc[i] + (long)(chunk + 1) * (KC * 2), Xb + (cpar ^ 1) * XBYTES + (wave + 8 * i) * 1024);
@@ -241,12 +254,12 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
       }
       if (u == 0 && chunk2 == 0) READ_HALF(0, 0, 0, 0, 0);  // pipeline fill (first step of the kernel only)
       READ_HALF(1, 1, tap, cpar, u % WRING);
-      lgkm_wait<2 + NI>();
+      lgkm_wait<NJ + NI>();
       mfma_half(0);
       __builtin_amdgcn_sched_barrier(0);
       if (more_chunks || tap + 1 < TAPS) {
         READ_HALF(0, 0, (tap + 1) % TAPS, (u + 1) / TAPS % 2, (u + 1) % WRING);
-        lgkm_wait<2 + NI>();
+        lgkm_wait<NJ + NI>();
       } else {
         lgkm_wait<0>();
       }
@@ -262,18 +275,20 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v4(const bf16* __restrict__ 
   // ---- epilogue: transposed through wave-private LDS so that residual reads and stores are whole rows
   // (common.h: store_tile_transposed; direct stores from the MFMA layout cost 1.7x the HBM write bytes)
   __builtin_amdgcn_s_barrier();  // every wave is done with the slab / weight ring
-  store_tile_transposed<NI, 2, EPI>(acc, smem + wave * (32 * (NI * 64 + 16)), Y, R, alpha, beta, (long)m0 + wave * 64, Npix,
+  store_tile_transposed<NI, NJ, EPI>(acc, smem + wave * (32 * (NI * 64 + 16)), Y, R, alpha, beta, (long)m0 + wave * (32 * NJ), Npix,
                                     n0, Cout, mod);
 }
 
-template <int NX, int EPI = 0, int NI = 4>
+template <int NX, int EPI = 0, int NI = 4, int ABL = 0, int NJ = 2>
 void launch4(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int Npix, int H, int W,
              int Cin, int Cout, const ModEpilogue& mod, hipStream_t st) {
-  const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + 32 * NI - 1) / (32 * NI);
+  constexpr int BMW = 8 * 32 * NJ;
+  const int tiles_m = (Npix + BMW - 1) / BMW, tiles_n = (Cout + 32 * NI - 1) / (32 * NI);
   const size_t lds = (size_t)2 * NX * 8 * 16 * ROWB + WRING * (32 * NI * ROWB);
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
-  auto kern = k_conv3x3_v4<NX, EPI, NI>;
-  static const int stagger = [] { const char* e = getenv("EDM_V4_STAGGER"); return e ? atoi(e) : 1; }();
+  auto kern = k_conv3x3_v4<NX, EPI, NI, ABL, NJ>;
+  // wave stagger (see the kernel): measured null on this kernel (+-1 % in A/B runs on one device), off by default
+  static const int stagger = [] { const char* e = getenv("EDM_V4_STAGGER"); return e ? atoi(e) : 0; }();
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -311,6 +326,20 @@ int edm_conv_igemm_v4_ex(const void* X, const void* Wp, void* Y, const void* R, 
         : launch4<NXV, EPIV, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st))
   // backward epilogues: their own instantiations (keep the common kernels free of their registers)
   const bool nx5 = xrows < 5 * 128;
+  static const int abl = [] { const char* e = getenv("EDM_V4_ABLATE"); return e ? atoi(e) : 0; }();   // tools only
+  if (abl && wide && nx5 && mod.mode == 0) {
+    switch (abl) {
+      case 1: launch4<5, 0, 4, 1>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st); break;
+      case 2: launch4<5, 0, 4, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st); break;
+      case 4: launch4<5, 0, 4, 4>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st); break;
+      case 6: launch4<5, 0, 4, 6>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st); break;
+      case 16: launch4<5, 0, 4, 16>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st); break;
+      case 18: launch4<5, 0, 4, 18>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st); break;
+      default: launch4<5, 0, 4, 22>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st); break;
+    }
+    EDM_CHECK_LAUNCH("conv_igemm_v4");
+    return EDM_OK;
+  }
   if (mod.mode == 1) { if (nx5) L4(5, 1); else L4(6, 1); }
   else if (mod.mode == 2) { if (nx5) L4(5, 2); else L4(6, 2); }
   else { if (nx5) L4(5, 0); else L4(6, 0); }

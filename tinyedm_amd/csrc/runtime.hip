@@ -5,6 +5,8 @@
 // function, so every compute entry point stays allocation-free, sync-free and graph-capturable from its first
 // call (a cold call under stream capture used to hipMalloc) -- and is looked up per device, under a mutex.
 #include "common.h"
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 
 namespace {
@@ -13,6 +15,22 @@ constexpr size_t ZERO_BYTES = 4096;   // >= the longest zero row any kernel read
 void* g_zero[MAX_DEV] = {};
 std::mutex g_mu;
 }  // namespace
+
+// hipGraph replay on ROCm 7.2: with the runtime's default AQL-packet-capture path the first replay after a
+// hipStreamSynchronize / hipDeviceSynchronize runs graph nodes with clobbered kernel arguments (measured round 2,
+// tools/nan_hunt.py; see tinyedm_amd/_runtime_env.py).  The runtime reads DEBUG_CLR_GRAPH_PACKET_CAPTURE at its
+// initialisation, so the library's load-time constructor sets it to 0 when the host has not chosen a value: a host
+// that loads libtinyedm_hip.so before its first HIP call (and captures these entry points into graphs) is covered.
+namespace {
+__attribute__((constructor)) void edm_runtime_ctor() { (void)setenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0", /*overwrite=*/0); }
+}  // namespace
+
+// 1 when the environment holds the graph-safe runtime setting (it takes effect only if it was in place before the
+// first HIP call of the process), 0 otherwise.
+extern "C" int edm_graph_replay_safe(void) {
+  const char* e = getenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE");
+  return e && strcmp(e, "0") == 0;
+}
 
 // Allocate the device-side constants of `device` (idempotent, thread-safe).  Must be called once per device before
 // the first kernel entry point, outside any stream capture; tinyedm_amd._lib does so when it binds the library.

@@ -21,7 +21,7 @@ import math
 import numpy as np
 import torch
 
-from . import networks, ops
+from . import _runtime_env, networks, ops
 from .ema import EMAOptimizer, FusedAdam
 
 
@@ -72,6 +72,7 @@ class CapturedTrainStep:
         self.base = optimizer.optimizer if isinstance(optimizer, EMAOptimizer) else optimizer
         if not isinstance(self.base, FusedAdam):
             raise TypeError("CapturedTrainStep needs the flat-arena FusedAdam")
+        _runtime_env.require_graph_replay_safe("CapturedTrainStep")
         self.ema = optimizer if isinstance(optimizer, EMAOptimizer) else None
         self.grad_scale = grad_scale
         self.params = StepParams(self.base.arena.theta.device)

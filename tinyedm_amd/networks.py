@@ -120,7 +120,11 @@ class _WNBase(nn.Module):
         return g.view_as(w)
 
 
-WGRAD_STREAM = os.environ.get("EDM_WGRAD_STREAM", "1") != "0"
+# Weight-gradient kernels on an auxiliary stream (EDM_WGRAD_STREAM=1).  Off by default since round 2: the grouped
+# stream-K weight-gradient launches fill all 256 CUs, so running them beside the dgrad chain only makes both contend
+# (hipGraph replay of the step: 15.6 ms with the side branch, 14.2 ms as one chain; eager: no difference).  In round 1,
+# with per-layer launches that left CUs idle, the overlap was worth 7 %.
+WGRAD_STREAM = os.environ.get("EDM_WGRAD_STREAM", "0") != "0"
 # 3x3 weight gradients: layers per grouped stream-K launch (csrc/conv_wgrad3.hip; 0 = previous per-layer kernels)
 W3_GROUP = max(0, min(16, int(os.environ.get("EDM_W3_GROUP", "12"))))
 FIN_GROUP = 40              # small weight gradients per multi-tensor finish launch (csrc/weights.hip)

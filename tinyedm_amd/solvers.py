@@ -1,7 +1,7 @@
 """2nd-order Heun sampler (reference solvers.py:4-59) with the loop optionally captured in a hipGraph."""
 import torch
 
-from . import ops
+from . import _runtime_env, ops
 
 
 class DeterministicSolver:
@@ -57,6 +57,7 @@ class DeterministicSolver:
         key = (id(model), tuple(x0.shape), None if class_labels is None else tuple(class_labels.shape), x0.device.index)
         ent = self._graphs.get(key)
         if ent is None:
+            _runtime_env.require_graph_replay_safe("DeterministicSolver.solve(graph=True)")
             t_dev = self.t_steps.to(x0.device)
             sx = x0.clone()
             sl = None if class_labels is None else class_labels.clone()

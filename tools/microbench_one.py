@@ -33,4 +33,4 @@ torch.cuda.synchronize()
 n = 1 if kind == "igemm" else 4
 fl = 2.0 * B * HW * HW * Cin * Cout * 9 * n
 ms = s.elapsed_time(e) / iters
-print(f"{kind} {HW}x{HW} {Cin}->{Cout}: {ms * 1e3:.1f} us  {fl / ms / 1e9:.0f} TF/s  (ablate={os.environ.get('EDM_W3_ABLATE', '0')})", flush=True)
+print(f"{kind} {HW}x{HW} {Cin}->{Cout}: {ms * 1e3:.1f} us  {fl / ms / 1e9:.0f} TF/s  (ablate={os.environ.get('EDM_W3_ABLATE', os.environ.get('EDM_V4_ABLATE', '0'))})", flush=True)
