@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtinyedm_hip.so")
+LIB_PATH = os.environ.get("EDM_LIB_PATH") or os.path.join(_HERE, "libtinyedm_hip.so")   # override: A/B runs in tools/
 
 P, I, L, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 U, U64 = ctypes.c_uint, ctypes.c_ulonglong

@@ -49,7 +49,10 @@ def build(verbose: bool = True, force: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(cc, jobs))
     objs = [os.path.join(OBJ, s[:-4] + ".o") for s in srcs]
-    if jobs or not os.path.exists(LIB):
+    stale = [o for o in os.listdir(OBJ) if o.endswith(".o") and os.path.join(OBJ, o) not in objs]
+    for o in stale:                     # object of a source that no longer exists: drop it and relink
+        os.remove(os.path.join(OBJ, o))
+    if jobs or stale or not os.path.exists(LIB):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

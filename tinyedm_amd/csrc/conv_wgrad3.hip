@@ -7,11 +7,16 @@
 //  * workgroup tile 128(co) x 64(ci) x 9 taps, ONE wave per SIMD with the whole 512-register file: a wave owns
 //    64(co) x 32(ci) x 9 taps = 18 accumulator blocks, so a k-step is 2 dY + 9 X fragments for 18 MFMAs
 //    (1.2 transposing reads per MFMA instead of 2.2: the LDS pipe was busier than the matrix pipe);
-//  * the reduction dimension of ALL layers of the group is laid end to end ("stream-K"): workgroup w takes the
-//    stages [w*q, (w+1)*q) of that sequence, keeps its accumulators across consecutive stages of one tile and
-//    flushes a partial tile only when it crosses a tile boundary or its range ends.  Partial-tile traffic is
-//    (workgroups + tiles) x 288 KiB per LAUNCH instead of per layer, small layers no longer get a launch (and a
-//    quarter-filled chip) each, and a partial's position is static: slot(w, tile) = w + tile;
+//  * the reduction dimension of ALL layers of the group is laid end to end ("stream-K"), and the unit that walks
+//    it is a TEAM of 8 workgroups resident on ONE XCD (blockIdx % 8 is the XCD): a layer's tiles are cut into
+//    groups of 8 (gco co-tiles x gci ci-tiles, member i of a team owns tile i of the group), the sequence is
+//    (layer, tile group, stage), and team t takes the stages [t*q, (t+1)*q) of it.  The 8 members therefore read
+//    the SAME pixel rows at the same time -- the X slice of a ci-tile is shared by the gco members above it, the dY
+//    slice of a co-tile by the gci members beside it -- so the second..eighth read of a row hits that XCD's L2
+//    instead of HBM (round 2, first form: every workgroup walked its own range and the kernel fetched 3.1x its
+//    algorithmic bytes).  A member keeps its accumulators across consecutive stages of its tile and flushes a
+//    partial tile only when the team crosses a group boundary or its range ends; a partial's position is static:
+//    slot(member, team, group) = member * (teams + groups) + team + group;
 //  * `k_wgrad3_finish` (one launch per group, one workgroup per weight row) sums a row's partials, applies the
 //    weight-normalisation projection and accumulates into the gradient arena.
 #include "common.h"
@@ -44,12 +49,14 @@ struct W3Layer {
   const bf16* dY;
   int B, H, W, Cin, Cout;
   int PW, PH, lead_rows, kmult;
-  int tiles_ci, ntiles, nst, tile0;
+  int tiles_ci, tiles_co, nst;
+  int gci, gco, nblk_ci, ngroups, group0;   // tile groups of 8 = gco x gci (see the header)
   long stage0, kbeg0, kend;
 };
 struct W3Group {
   W3Layer L[MAXL];
   int nlayers, nwg;
+  int tpx, slots_per_member;   // teams per XCD; partial-tile slots of one member = teams + groups
   long total, q;
   float* work;
   const bf16* zeros;
@@ -103,7 +110,10 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3(const W3Group g) {
   const int chan_b = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
   const int l31 = lane & 31, lhi = lane >> 5;
 
-  long pos = (long)blockIdx.x * g.q;
+  // blockIdx -> (XCD, local index on it) -> (team, member): the 8 members of a team share an XCD (and its L2)
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int member = local & 7, team = xcd * g.tpx + (local >> 3);
+  long pos = (long)team * g.q;
   const long pend = (pos + g.q < g.total) ? pos + g.q : g.total;
   int li = 0;
   while (li + 1 < g.nlayers && pos >= g.L[li + 1].stage0) ++li;
@@ -115,15 +125,21 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3(const W3Group g) {
     const int B = g.L[li].B, H = g.L[li].H, W = g.L[li].W, Cin = g.L[li].Cin, Cout = g.L[li].Cout;
     const int PW = g.L[li].PW, PH = g.L[li].PH;
     const long rel = pos - g.L[li].stage0;
-    const int tl = (int)(rel / g.L[li].nst);
-    const int st0 = (int)(rel - (long)tl * g.L[li].nst);
+    const int grp = (int)(rel / g.L[li].nst);
+    const int st0 = (int)(rel - (long)grp * g.L[li].nst);
     int nst = g.L[li].nst - st0;
     if ((long)nst > pend - pos) nst = (int)(pend - pos);
-    const int tco = tl / g.L[li].tiles_ci, tci = tl - tco * g.L[li].tiles_ci;
+    const int bco = grp / g.L[li].nblk_ci, bci = grp - bco * g.L[li].nblk_ci;
+    const int tco = bco * g.L[li].gco + member / g.L[li].gci, tci = bci * g.L[li].gci + member % g.L[li].gci;
+    if (tco >= g.L[li].tiles_co || tci >= g.L[li].tiles_ci) {   // this member has no tile in the group (workgroup-uniform)
+      pos += nst;
+      if (pos >= g.L[li].stage0 + (long)g.L[li].ngroups * g.L[li].nst) ++li;
+      continue;
+    }
     const int co0 = tco * TCO, ci0 = tci * TCI;
     const long ks0 = g.L[li].kbeg0 + (long)st0 * KP;
     const long ks1 = (ks0 + (long)nst * KP < g.L[li].kend) ? ks0 + (long)nst * KP : g.L[li].kend;
-    float* __restrict__ out = g.work + (long)(blockIdx.x + g.L[li].tile0 + tl) * TILE_FLOATS;
+    float* __restrict__ out = g.work + ((long)member * g.slots_per_member + team + g.L[li].group0 + grp) * TILE_FLOATS;
 
     // per-lane decode state of the padded row this lane stages: row = base + 16*wave + (lane>>2)
     long kp = ks0 - LEADS * KP + wave * 16 + drow;
@@ -318,7 +334,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3(const W3Group g) {
           base[((r & 3) + 8 * (r >> 2) + 4 * lhi) * TCI] = (tp < 8) ? acc[i][tp < 8 ? tp : 0][r] : accv[i][r];
       }
     pos += nst;
-    if (pos >= g.L[li].stage0 + (long)g.L[li].ntiles * g.L[li].nst) ++li;
+    if (pos >= g.L[li].stage0 + (long)g.L[li].ngroups * g.L[li].nst) ++li;
     // every wave must be past its LDS reads before the next segment's prologue overwrites the rings
     __builtin_amdgcn_s_barrier();
   }
@@ -330,14 +346,15 @@ struct F3Layer {
   const float* w;
   float* grad;
   const int* perm;
-  int O, I, Cin, tiles_ci, nst, tile0, row0;
+  int O, I, Cin, tiles_ci, nst, row0;
+  int gci, gco, nblk_ci, group0;
   float scale;
   int accumulate;
   long stage0;
 };
 struct F3Group {
   F3Layer L[MAXL];
-  int nlayers;
+  int nlayers, slots_per_member;
   long q;
   const float* work;
 };
@@ -370,10 +387,13 @@ __global__ __launch_bounds__(256) void k_wgrad3_finish(const F3Group g) {
   for (int idx = threadIdx.x; idx < items; idx += blockDim.x) {
     const int c4 = idx & 15, tt = idx >> 4;
     const int tp = tt % 9, tci = tt / 9;
-    const int tl = tco * tiles_ci + tci;
-    const long s0 = g.L[li].stage0 + (long)tl * nst;
+    // the tile's group and owner, then the teams whose stage ranges touch the group: one partial each
+    const int gco = g.L[li].gco, gci = g.L[li].gci;
+    const int grp = (tco / gco) * g.L[li].nblk_ci + tci / gci, member = (tco % gco) * gci + tci % gci;
+    const long s0 = g.L[li].stage0 + (long)grp * nst;
     const int w_lo = (int)(s0 / g.q), w_hi = (int)((s0 + nst - 1) / g.q);
-    const float* p = g.work + (long)(w_lo + g.L[li].tile0 + tl) * TILE_FLOATS + ((long)tp * TCO + rl) * TCI + c4 * 4;
+    const float* p = g.work + ((long)member * g.slots_per_member + w_lo + g.L[li].group0 + grp) * TILE_FLOATS +
+                     ((long)tp * TCO + rl) * TCI + c4 * 4;
     f32x4 a = *reinterpret_cast<const f32x4*>(p);
     for (int w = w_lo + 1; w <= w_hi; ++w) {
       p += TILE_FLOATS;
@@ -409,7 +429,7 @@ __global__ __launch_bounds__(256) void k_wgrad3_finish(const F3Group g) {
 struct Plan {
   W3Group wg;
   F3Group fg;
-  int leads, rows_total, ntiles_total, max_n;
+  int leads, rows_total, ngroups_total, max_n;
   long work_floats;
 };
 
@@ -436,7 +456,7 @@ int make_plan(const edm_wgrad3_item* it, int n, Plan& P) {
   EDM_REQUIRE(it && n > 0 && n <= MAXL, "wgrad3: need 1..%d layers per group, got %d", MAXL, n);
   P.leads = 0;
   long stage = 0;
-  int tile = 0, row = 0;
+  int group = 0, row = 0;
   P.max_n = 0;
   for (int k = 0; k < n; ++k) {
     const edm_wgrad3_item& a = it[k];
@@ -460,30 +480,39 @@ int make_plan(const edm_wgrad3_item* it, int n, Plan& P) {
     L.kbeg0 = (long)(L.lead_rows - 1) * L.PW + 1;
     L.kend = ((long)L.lead_rows + (long)a.B * L.PH) * L.PW;
     L.tiles_ci = (a.Cin + TCI - 1) / TCI;
-    L.ntiles = ((a.Cout + TCO - 1) / TCO) * L.tiles_ci;
+    L.tiles_co = (a.Cout + TCO - 1) / TCO;
+    L.gco = L.tiles_co >= 8 ? 8 : L.tiles_co >= 4 ? 4 : L.tiles_co >= 2 ? 2 : 1;   // members along co: each X slice is shared by gco
+    L.gci = 8 / L.gco;                                                             // ... and each dY slice by gci members
+    L.nblk_ci = (L.tiles_ci + L.gci - 1) / L.gci;
+    L.ngroups = ((L.tiles_co + L.gco - 1) / L.gco) * L.nblk_ci;
+    L.group0 = group;
     L.nst = (int)((L.kend - L.kbeg0 + KP - 1) / KP);
-    L.tile0 = tile;
     L.stage0 = stage;
     F3Layer& F = P.fg.L[k];
     F.w = a.w; F.grad = a.grad; F.perm = a.perm;
-    F.O = a.Cout; F.I = a.I; F.Cin = a.Cin; F.tiles_ci = L.tiles_ci; F.nst = L.nst; F.tile0 = tile; F.row0 = row;
+    F.O = a.Cout; F.I = a.I; F.Cin = a.Cin; F.tiles_ci = L.tiles_ci; F.nst = L.nst; F.row0 = row;
+    F.gci = L.gci; F.gco = L.gco; F.nblk_ci = L.nblk_ci; F.group0 = group;
     F.scale = a.scale; F.accumulate = a.accumulate; F.stage0 = stage;
-    stage += (long)L.ntiles * L.nst;
-    tile += L.ntiles;
+    stage += (long)L.ngroups * L.nst;
+    group += L.ngroups;
     row += a.Cout;
     if (a.I * 9 > P.max_n) P.max_n = a.I * 9;
   }
-  constexpr int NCU = 256, QMIN = 8;     // MI355X: one workgroup per CU; at least QMIN stages per workgroup
-  long q = (stage + NCU - 1) / NCU;
-  if (q < QMIN) q = QMIN;
-  const int nwg = (int)((stage + q - 1) / q);
+  // MI355X: 8 XCDs x 32 CUs, one workgroup per CU -> up to 4 teams of 8 per XCD; at least QMIN stages per team
+  constexpr int NXCD = 8, TPX_MAX = 4, QMIN = 8;
+  int tpx = TPX_MAX;
+  while (tpx > 1 && stage < (long)QMIN * NXCD * tpx) --tpx;
+  const int teams = NXCD * tpx;
+  const long q = (stage + teams - 1) / teams;
   P.wg.nlayers = P.fg.nlayers = n;
-  P.wg.nwg = nwg;
+  P.wg.nwg = teams * 8;
+  P.wg.tpx = tpx;
+  P.wg.slots_per_member = P.fg.slots_per_member = teams + group;
   P.wg.total = stage;
   P.wg.q = P.fg.q = q;
   P.rows_total = row;
-  P.ntiles_total = tile;
-  P.work_floats = (long)(nwg + tile) * TILE_FLOATS;
+  P.ngroups_total = group;
+  P.work_floats = (long)8 * (teams + group) * TILE_FLOATS;
   return EDM_OK;
 }
 
