@@ -75,7 +75,8 @@ def pmc_traffic(kernel):
         path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))[-1]     # newest round's pass
         with open(path) as f:
             ks = json.load(f)["kernels"]
-        rec = next((v for k, v in ks.items() if k.startswith(kernel + "<5, 0, 4")), None) or ks.get(kernel)
+        rec = (next((v for k, v in ks.items() if k.startswith(kernel + "<5, 0, 4")), None) or ks.get(kernel) or
+               next((v for k, v in ks.items() if k.startswith(kernel + "<")), None))
         return None if rec is None else round(rec["hbm_gb_per_launch"], 4)
     except (OSError, ValueError, KeyError, IndexError):
         return None
@@ -379,6 +380,14 @@ def main():
                 # BASELINE.json's literal "HBM-bound 3x3-conv roofline": 3x3-conv activation bytes only (59.7 MB per
                 # training image) over 8 TB/s; 70 % of it would need 7 PFLOP/s of bf16 MFMA (not reachable)
                 "northstar_hbm3x3_frac": round(ips / world * 59.7e6 / 1e9 / HBM_PEAK_GBS, 4),
+                # the other chip-filling MFMA kernel of the step: the grouped stream-K weight gradient (conv_wgrad3.hip)
+                "wgrad3": (lambda w: {"kernel": "k_wgrad3<1> (3x3 weight gradients, 4 grouped launches per step)",
+                                      "achieved": round(w["gflop"] / w["ms"], 2) if w["ms"] else 0.0,
+                                      "frac": round(w["gflop"] / w["ms"] / MFMA_PEAK_TFLOPS, 4) if w["ms"] else 0.0,
+                                      "avg_launch_ms": round(w["ms"] / max(1, w["launches"]), 4),
+                                      "algorithmic_gbytes_per_launch": round(w["gbytes"] / max(1, w["launches"]), 4),
+                                      "traffic": pmc_traffic("k_wgrad3")})(
+                    roof.get("conv3x3_wgrad", {"launches": 0, "ms": 0.0, "gflop": 0.0, "gbytes": 0.0})),
                 "per_kernel": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in roof.items()},
             },
         }
