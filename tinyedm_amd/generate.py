@@ -37,7 +37,8 @@ def generate(ckpt_path, load_ema, output_dir, num_samples, image_size, num_class
         model = EDM.load_from_checkpoint(ckpt_path, load_ema=load_ema)
     model = model.to(dev)
     model.solver = DeterministicSolver(num_steps=num_steps)
-    if graph:
+    from . import _runtime_env
+    if graph and _runtime_env.GRAPH_REPLAY_SAFE:      # otherwise the eager Heun loop: same values
         solve = model.solver.solve
         model.solver.solve = lambda m, x0, labels=None: solve(m, x0, labels, graph=True)
     C = int(in_channels) if in_channels is not None else int(model.denoiser.in_channels)

@@ -154,8 +154,14 @@ class Trainer:
         captured = None
         if (self.use_graph and self.world_size == 1 and self.accumulate_grad_batches == 1 and isinstance(base, FusedAdam)
                 and torch.cuda.is_available()):
-            from .graph import CapturedTrainStep
-            captured = CapturedTrainStep(model, opt)
+            from . import _runtime_env
+            if _runtime_env.GRAPH_REPLAY_SAFE:
+                from .graph import CapturedTrainStep
+                captured = CapturedTrainStep(model, opt)
+            else:       # same arithmetic through the eager loop (see _runtime_env: the GPU was initialised too early)
+                import warnings
+                warnings.warn(f"tinyedm_amd: {_runtime_env.VAR}=0 was not in place before the GPU was initialised; "
+                              "training runs the eager step instead of the hipGraph replay")
         done = 0 < self.max_steps <= self.global_step
         t0, imgs = time.time(), 0
         for epoch in range(start_epoch, self.max_epochs):
