@@ -120,13 +120,18 @@ class _WNBase(nn.Module):
         return g.view_as(w)
 
 
-# Weight-gradient kernels on an auxiliary stream (EDM_WGRAD_STREAM=1).  Off by default since round 2: the grouped
-# stream-K weight-gradient launches fill all 256 CUs, so running them beside the dgrad chain only makes both contend
-# (hipGraph replay of the step: 15.6 ms with the side branch, 14.2 ms as one chain; eager: no difference).  In round 1,
-# with per-layer launches that left CUs idle, the overlap was worth 7 %.
-WGRAD_STREAM = os.environ.get("EDM_WGRAD_STREAM", "0") != "0"
-# 3x3 weight gradients: layers per grouped stream-K launch (csrc/conv_wgrad3.hip; 0 = previous per-layer kernels)
+# Weight-gradient kernels on an auxiliary stream, off the dgrad -> elementwise -> dgrad chain of the backward pass
+# (EDM_WGRAD_STREAM=0 disables).  Measured round 2, eager step (tools/bench_config.py, one gpurun call): CIFAR-10 15.2 ms
+# either way (the grouped launches fill the chip), MNIST 18.2 vs 18.4, ImageNet-64 latent config 145.9 vs 153.4 ms (its
+# long elementwise kernels overlap with MFMA-bound weight gradients).  Inside a captured hipGraph the side branch is
+# scheduled less favourably (CIFAR-10 15.5 vs 15.1 ms): graph.CapturedTrainStep switches it off while it captures.
+WGRAD_STREAM = os.environ.get("EDM_WGRAD_STREAM", "1") != "0"
+# 3x3 weight gradients: layers per grouped stream-K launch (csrc/conv_wgrad3.hip; 0 = per-layer kernels only) and the
+# largest layer (pixels) that joins a group.  A layer with more pixels fills the chip alone and its per-layer launch
+# overlaps the backward pass at a finer grain (ImageNet-64 config, 64x64 layers at batch 176: 144 vs 147 ms).  Only with
+# the side stream: on one chain (captured step) everything is grouped (154.6 vs 161 ms).
 W3_GROUP = max(0, min(16, int(os.environ.get("EDM_W3_GROUP", "12"))))
+W3_MAXPIX = int(os.environ.get("EDM_W3_MAXPIX", str(1 << 18)))
 FIN_GROUP = 40              # small weight gradients per multi-tensor finish launch (csrc/weights.hip)
 _bwd_end_queued = set()     # devices whose end-of-backward callback is queued for the running backward pass
 _w3_pending = {}            # device index -> [(mod, x, dy, scale)] 3x3 layers waiting for their grouped launch
@@ -223,7 +228,8 @@ def _wgrad(mod, x, dy, taps, scale=1.0):
     chain of the backward pass, and 3x3 layers are collected into groups of W3_GROUP per launch."""
     w = mod.weight
     direct = w.grad is not None and getattr(w, "_edm_direct", False)
-    if taps == 9 and W3_GROUP and w.dim() == 4 and ops.wgrad3_supported(x, dy, w.shape[1]):
+    if (taps == 9 and W3_GROUP and w.dim() == 4 and ops.wgrad3_supported(x, dy, w.shape[1])
+            and (not WGRAD_STREAM or x.shape[0] * x.shape[1] * x.shape[2] <= W3_MAXPIX)):
         if direct:
             key = w.device.index
             pend = _w3_pending.setdefault(key, [])

@@ -79,8 +79,11 @@ class Trainer:
         self.datamodule = None
         self.callback_metrics: dict = {}
         self._resume_skip = 0          # batches of the first epoch already consumed before the checkpoint was written
-        # one GPU, no gradient accumulation: the step is replayed from a hipGraph (EDM_GRAPH=0 keeps the eager loop)
-        self.use_graph = os.environ.get("EDM_GRAPH", "1") != "0"
+        # EDM_GRAPH=1 (one GPU, no gradient accumulation): the step is replayed from a hipGraph.  Off by default: the
+        # step is GPU-bound on every configuration measured (round 2: eager with the weight-gradient side stream
+        # 15.2 / 18.2 / 146 ms vs replay 15.1 / 18.2 / 154 ms on CIFAR-10 / MNIST / ImageNet-64), so the replay only
+        # pays on a slower host
+        self.use_graph = os.environ.get("EDM_GRAPH", "0") != "0"
 
     # ------------------------------------------------------------------ setup
     def _setup_distributed(self, model):

@@ -1,4 +1,5 @@
-"""Training-step throughput of any conf/*.yaml model on synthetic data: python tools/bench_config.py imagenet 8 [steps]"""
+"""Training-step throughput of any conf/*.yaml model on synthetic data:
+    python tools/bench_config.py imagenet 8 [steps] [--graph]      (--graph: replay the hipGraph-captured step)"""
 import os
 import sys
 import time
@@ -10,8 +11,10 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    name, B = sys.argv[1], int(sys.argv[2])
-    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    use_graph = "--graph" in sys.argv
+    argv = [a for a in sys.argv if a != "--graph"]
+    name, B = argv[1], int(argv[2])
+    steps = int(argv[3]) if len(argv) > 3 else 5
     import tinyedm
     from tinyedm.config import compose, instantiate
     from tinyedm_amd.ddp import GradReducer
@@ -39,6 +42,14 @@ def main():
         return loss
 
     opt.zero_grad()
+    if use_graph:
+        from tinyedm_amd.graph import CapturedTrainStep
+        cap = CapturedTrainStep(model, opt)
+        for i in range(CapturedTrainStep.WARMUP + 2):
+            cap((x, y))
+
+        def step(i):                        # noqa: F811
+            return cap((x, y))
     for i in range(2):
         step(i)
     torch.cuda.synchronize()
@@ -47,7 +58,8 @@ def main():
         loss = step(2 + i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    print(f"{name}: batch {B} {shape}: {dt * 1e3:.1f} ms/step, {B / dt:.1f} img/s, loss {float(loss.detach()):.4f}", flush=True)
+    print(f"{name}: batch {B} {shape}: {dt * 1e3:.1f} ms/step, {B / dt:.1f} img/s, loss {float(loss.detach()):.4f}"
+          f"{' (hipGraph replay)' if use_graph else ''}", flush=True)
 
 
 if __name__ == "__main__":
