@@ -145,8 +145,11 @@ int edm_attention_bwd(const void* qkv, const void* y, const void* gy, void* gqkv
 /* ---------------------------------------------------------------- per-pixel / elementwise */
 /* pixel_norm over C + mp_silu (networks.py:9-14, 83-84, 249-252); dsave[p] = eps + |x_p|/sqrt(C) */
 int edm_pixelnorm_silu_fwd(const void* x, void* xn, void* a, float* dsave, long P, int C, edm_stream_t stream);
+/* gadd (optional, bf16 like gx): added to the result -- the gradient reaching the same tensor along the U-Net skip, which
+ * autograd would otherwise sum with a separate add (networks.py:592-600: the encoder output feeds the next block AND a
+ * decoder block) */
 int edm_pixelnorm_silu_bwd(const void* xn, const float* dsave, const void* gxn, float gxn_scale, const void* ga,
-                           void* gx, long P, int C, edm_stream_t stream);
+                           const void* gadd, void* gx, long P, int C, edm_stream_t stream);
 /* mp_silu (networks.py:316) and its backward: gx = mp_silu'(x)*ga + extra_scale*gextra */
 int edm_silu_fwd(const void* x, void* a, long n, edm_stream_t stream);
 int edm_silu_bwd(const void* x, const void* ga, const void* gextra, float extra_scale, void* gx, long n,
@@ -164,7 +167,8 @@ int edm_dropout_mask(unsigned char* mask, long n, float pdrop, unsigned long lon
                      edm_stream_t stream);
 /* 2x2 average pool / nearest-exact x2 (networks.py:80, 72); H,W = OUTPUT dims; scale folds the backward factors */
 int edm_pool2(const void* x, void* y, int B, int Hout, int Wout, int C, float scale, edm_stream_t stream);
-int edm_up2(const void* x, void* y, int B, int Hout, int Wout, int C, float scale, edm_stream_t stream);
+/* up2: y = scale * up(x) + add (add optional, same shape as y: see edm_pixelnorm_silu_bwd's gadd) */
+int edm_up2(const void* x, const void* add, void* y, int B, int Hout, int Wout, int C, float scale, edm_stream_t stream);
 /* out[b,c] = scale * sum_hw x[b,hw,c] (* y[b,hw,c])  -- ScaleLong mean (networks.py:116) and its gate gradient;
  * written, not accumulated, in a fixed summation order (bit-reproducible) */
 int edm_reduce_hw(const void* x, long x_stride, const void* y, long y_stride, float* out, int B, int HW, int C,

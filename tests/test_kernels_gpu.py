@@ -299,6 +299,9 @@ def test_pixelnorm_silu(ops):
         (0.8 * (xn_ref * gxn).sum() + (a_ref * ga).sum()).backward()
         gx = ops.pixelnorm_silu_bwd(xn, d, nhwc(gxn), 0.8, nhwc(ga))
         close_bf16(nchw(gx), xr.grad, l2=8e-3, mx=3e-2)
+        extra = q(torch.randn(x.shape, generator=g))          # gradient of the same tensor along the U-Net skip
+        gx2 = ops.pixelnorm_silu_bwd(xn, d, nhwc(gxn), 0.8, nhwc(ga), gadd=nhwc(extra))
+        close_bf16(nchw(gx2), xr.grad + extra, l2=8e-3, mx=3e-2)
 
 
 def test_silu_axpby_resample(ops):
@@ -316,6 +319,9 @@ def test_silu_axpby_resample(ops):
     close_bf16(nchw(ops.axpby(nhwc(x), (1 - t) / c, nhwc(y), t / c)), O.mp_add(x, y, t))
     close_bf16(nchw(ops.pool2(nhwc(x))), F.avg_pool2d(x, 2, 2))
     close_bf16(nchw(ops.up2(nhwc(x))), F.interpolate(x, scale_factor=2, mode="nearest-exact"))
+    big = q(torch.randn(2, 64, 16, 16, generator=g))
+    close_bf16(nchw(ops.up2(nhwc(x), 0.25, add=nhwc(big))),
+               0.25 * F.interpolate(x, scale_factor=2, mode="nearest-exact") + big)
 
 
 @pytest.mark.parametrize("pdrop", [0.0, 0.13])

@@ -21,7 +21,7 @@ SIGNATURES = {
     "edm_graph_replay_safe": [],
     # elementwise.hip
     "edm_pixelnorm_silu_fwd": [P, P, P, P, L, I, P],
-    "edm_pixelnorm_silu_bwd": [P, P, P, F, P, P, L, I, P],
+    "edm_pixelnorm_silu_bwd": [P, P, P, F, P, P, P, L, I, P],
     "edm_silu_fwd": [P, P, L, P],
     "edm_silu_bwd": [P, P, P, F, P, L, P],
     "edm_axpby": [P, F, P, F, P, L, P],
@@ -29,7 +29,7 @@ SIGNATURES = {
     "edm_mod_silu_drop_bwd": [P, P, L, P, P, P, P, P, L, P, I, I, I, F, U64, U, U, P, P],
     "edm_dropout_mask": [P, L, F, U64, U, U, P],
     "edm_pool2": [P, P, I, I, I, I, F, P],
-    "edm_up2": [P, P, I, I, I, I, F, P],
+    "edm_up2": [P, P, P, I, I, I, I, F, P],
     "edm_reduce_hw": [P, L, P, L, P, I, I, I, F, P],
     "edm_scalelong_fwd": [P, P, P, P, P, I, I, I, P],
     "edm_scalelong_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, P],

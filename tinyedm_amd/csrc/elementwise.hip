@@ -73,12 +73,13 @@ __global__ __launch_bounds__(256) void k_pnorm_silu_fwd(const bf16* __restrict__
   }
 }
 
-// backward of the pair above.  g = gs*gxn + mp_silu'(xn)*ga ;  dx = (g - xn*<g,xn>*d/(C*(d-eps)))/d
+// backward of the pair above.  g = gs*gxn + mp_silu'(xn)*ga ;  dx = (g - xn*<g,xn>*d/(C*(d-eps)))/d  (+ gadd: the
+// gradient that reaches the same tensor along another path -- the U-Net skip -- summed here instead of by autograd)
 template <int LPP>
 __global__ __launch_bounds__(256) void k_pnorm_silu_bwd(const bf16* __restrict__ xn, const float* __restrict__ dsave,
                                                           const bf16* __restrict__ gxn, float gs,
-                                                          const bf16* __restrict__ ga, bf16* __restrict__ gx, int P,
-                                                          int C) {
+                                                          const bf16* __restrict__ ga, const bf16* __restrict__ gadd,
+                                                          bf16* __restrict__ gx, int P, int C) {
   constexpr int GPW = 64 / LPP;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lig = lane % LPP, grp = lane / LPP;
@@ -124,6 +125,12 @@ __global__ __launch_bounds__(256) void k_pnorm_silu_bwd(const bf16* __restrict__
         float o[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = (g[it][i] - y[it][i] * coef) * inv;
+        if (gadd) {
+          float t[8];
+          load8(gadd + p * C + c8 * 8, t);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] += t[i];
+        }
         store8(gx + p * C + c8 * 8, o);
       }
     }
@@ -149,12 +156,12 @@ extern "C" int edm_pixelnorm_silu_fwd(const void* x, void* xn, void* a, float* d
 }
 
 extern "C" int edm_pixelnorm_silu_bwd(const void* xn, const float* dsave, const void* gxn, float gxn_scale,
-                                      const void* ga, void* gx, long P, int C, hipStream_t st) {
+                                      const void* ga, const void* gadd, void* gx, long P, int C, hipStream_t st) {
   EDM_REQUIRE(P > 0 && C > 0 && C % 8 == 0 && C <= 1024, "pixelnorm_silu_bwd: bad P=%ld C=%d", P, C);
   int lpp = pick_lpp(C);
   int gpw = 64 / lpp;
   int grid = grid_for(P, 4 * gpw);
-#define L(N) hipLaunchKernelGGL(k_pnorm_silu_bwd<N>, dim3(grid), dim3(256), 0, st, (const bf16*)xn, dsave, (const bf16*)gxn, gxn_scale, (const bf16*)ga, (bf16*)gx, (int)P, C)
+#define L(N) hipLaunchKernelGGL(k_pnorm_silu_bwd<N>, dim3(grid), dim3(256), 0, st, (const bf16*)xn, dsave, (const bf16*)gxn, gxn_scale, (const bf16*)ga, (const bf16*)gadd, (bf16*)gx, (int)P, C)
   if (lpp == 16) L(16); else if (lpp == 32) L(32); else L(64);
 #undef L
   EDM_CHECK_LAUNCH("pixelnorm_silu_bwd");
@@ -413,8 +420,9 @@ __global__ void k_pool2(const bf16* __restrict__ x, bf16* __restrict__ y, int H,
     store8(y + i * 8, a0);
   }
 }
-// nearest-exact x2:  y[b,h,w,c] = s * x[b,h/2,w/2,c]   (H,W = OUTPUT dims)
-__global__ void k_up2(const bf16* __restrict__ x, bf16* __restrict__ y, int H, int W, int CL, long n8, float s) {
+// nearest-exact x2:  y[b,h,w,c] = s * x[b,h/2,w/2,c] (+ add[b,h,w,c])   (H,W = OUTPUT dims; add: see k_pnorm_silu_bwd)
+__global__ void k_up2(const bf16* __restrict__ x, const bf16* __restrict__ add, bf16* __restrict__ y, int H, int W, int CL,
+                      long n8, float s) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
     int c8 = (int)(i % CL);
     long pix = i / CL;
@@ -429,6 +437,12 @@ __global__ void k_up2(const bf16* __restrict__ x, bf16* __restrict__ y, int H, i
 #pragma unroll
       for (int j = 0; j < 8; ++j) a0[j] *= s;
     }
+    if (add) {
+      float t[8];
+      load8(add + i * 8, t);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a0[j] += t[j];
+    }
     store8(y + i * 8, a0);
   }
 }
@@ -440,11 +454,12 @@ extern "C" int edm_pool2(const void* x, void* y, int B, int Hout, int Wout, int 
   EDM_CHECK_LAUNCH("pool2");
   return EDM_OK;
 }
-extern "C" int edm_up2(const void* x, void* y, int B, int Hout, int Wout, int C, float scale, hipStream_t st) {
+extern "C" int edm_up2(const void* x, const void* add, void* y, int B, int Hout, int Wout, int C, float scale,
+                       hipStream_t st) {
   EDM_REQUIRE(B > 0 && Hout > 0 && Wout > 0 && Hout % 2 == 0 && Wout % 2 == 0 && C % 8 == 0, "up2: bad args");
   long n8 = (long)B * Hout * Wout * C / 8;
-  hipLaunchKernelGGL(k_up2, dim3(grid_for(n8, 256)), dim3(256), 0, st, (const bf16*)x, (bf16*)y, Hout, Wout, C / 8,
-                     n8, scale);
+  hipLaunchKernelGGL(k_up2, dim3(grid_for(n8, 256)), dim3(256), 0, st, (const bf16*)x, (const bf16*)add, (bf16*)y, Hout,
+                     Wout, C / 8, n8, scale);
   EDM_CHECK_LAUNCH("up2");
   return EDM_OK;
 }

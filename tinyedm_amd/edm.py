@@ -125,6 +125,8 @@ class EDM(LightningModule):
         noisy_image, sigma = self.diffuser(clean_image)
         fourier_embedding, embedding = self.embedding(sigma, class_label)
         denoised_image = self.denoiser(noisy_image, sigma, embedding)
+        if not (training and self.u is not None) and hasattr(metric, "forward_sigma"):
+            return metric.forward_sigma(sigma, self.sigma_data, denoised_image, clean_image)   # lambda(sigma) in-kernel
         weight = (sigma ** 2 + self.sigma_data ** 2) / (sigma * self.sigma_data) ** 2
         if training and self.u is not None:
             uncertainty = self.u(fourier_embedding).flatten()

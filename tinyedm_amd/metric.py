@@ -20,6 +20,24 @@ class _WeightedMSEFn(torch.autograd.Function):
         return None, dD * g, None
 
 
+class _SigmaMSEFn(torch.autograd.Function):
+    """The same loss with the weight lambda(sigma) = (sigma^2 + sd^2) / (sigma sd)^2 (edm.py:212) evaluated inside the
+    kernel and the metric's epoch state (sum, count: metric.py:38-49) accumulated in the same pass: one launch instead
+    of the kernel plus ~10 scalar ATen launches (pow / add / mul / div on a B-vector, state += , count +=)."""
+
+    @staticmethod
+    def forward(ctx, sigma, sigma_data, preds, target, acc_sum, acc_total, want_grad):
+        loss, dD = ops.weighted_mse(preds, target, sigma, sigma_data, want_grad=want_grad, acc_sum=acc_sum,
+                                    acc_total=acc_total)
+        ctx.save_for_backward(dD)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dD,) = ctx.saved_tensors
+        return None, None, dD * g, None, None, None, None
+
+
 def weighted_mse_loss(weight: Tensor, preds: Tensor, target: Tensor) -> Tensor:
     preds32, target32 = preds.float().contiguous(), target.float().contiguous()
     w = weight.float().flatten().contiguous()
@@ -60,6 +78,17 @@ class WeightedMeanSquaredError(torch.nn.Module):
         self.weighted_sum_squared_error += s.detach().to(self.weighted_sum_squared_error.device)
         self.total += n
         return s / n
+
+    def forward_sigma(self, sigma: Tensor, sigma_data: float, preds: Tensor, target: Tensor) -> Tensor:
+        """`forward(lambda(sigma), preds, target)` (the call of edm.py:212,221 / 243) in one kernel launch: same value,
+        same state update."""
+        st, tot = self.weighted_sum_squared_error, self.total
+        if not (preds.is_cuda and st.is_cuda and tot.is_cuda and tot.dtype == torch.int64 and tot.dim() == 0):
+            w = (sigma ** 2 + sigma_data ** 2) / (sigma * sigma_data) ** 2
+            return self.forward(w, preds, target)
+        return _SigmaMSEFn.apply(sigma.detach().float().flatten().contiguous(), float(sigma_data),
+                                 preds.float().contiguous(), target.float().contiguous(), st, tot,
+                                 torch.is_grad_enabled() and preds.requires_grad)
 
     def compute(self) -> Tensor:
         s, t = self.weighted_sum_squared_error.clone(), self.total.clone().to(self.weighted_sum_squared_error.dtype)

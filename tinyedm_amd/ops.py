@@ -137,15 +137,19 @@ def pixelnorm_silu_fwd(x):
     return xn, a, d
 
 
-def pixelnorm_silu_bwd(xn, d, gxn, gxn_scale, ga):
+def pixelnorm_silu_bwd(xn, d, gxn, gxn_scale, ga, gadd=None):
+    """gadd (optional): a gradient of the same tensor from another consumer (the U-Net skip), added in the same pass"""
     B, H, W, C = _nhwc(xn, "xn")
     _chk(d, f32, "d", (B * H * W,))
     if gxn is not None:
         _chk(gxn, bf16, "gxn", xn.shape)
     if ga is not None:
         _chk(ga, bf16, "ga", xn.shape)
+    if gadd is not None:
+        _chk(gadd, bf16, "gadd", xn.shape)
     gx = torch.empty_like(xn)
-    _lib.call("edm_pixelnorm_silu_bwd", _p(xn), _p(d), _p(gxn), float(gxn_scale), _p(ga), _p(gx), B * H * W, C, _stream())
+    _lib.call("edm_pixelnorm_silu_bwd", _p(xn), _p(d), _p(gxn), float(gxn_scale), _p(ga), _p(gadd), _p(gx), B * H * W, C,
+              _stream())
     return gx
 
 
@@ -234,10 +238,13 @@ def pool2(x, scale=0.25):
     return y
 
 
-def up2(x, scale=1.0):
+def up2(x, scale=1.0, add=None):
+    """y = scale * nearest-exact x2 upsample of x (+ add, a bf16 tensor of the output shape)"""
     B, H, W, C = _nhwc(x, "x")
+    if add is not None:
+        _chk(add, bf16, "add", (B, 2 * H, 2 * W, C))
     y = torch.empty(B, 2 * H, 2 * W, C, device=x.device, dtype=bf16)
-    _lib.call("edm_up2", _p(x), _p(y), B, 2 * H, 2 * W, C, float(scale), _stream())
+    _lib.call("edm_up2", _p(x), _p(add), _p(y), B, 2 * H, 2 * W, C, float(scale), _stream())
     return y
 
 
