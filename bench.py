@@ -349,7 +349,9 @@ def main():
         # <5,1>/<5,2> are reported beside it in per_kernel as ..._v4_modbwd / ..._v4_silubwd)
         conv = roof.get("conv3x3_igemm_v4", {"launches": 0, "ms": 0.0, "gflop": 0.0, "gbytes": 0.0})
         achieved = conv["gflop"] / conv["ms"] if conv["ms"] > 0 else 0.0          # GFLOP/ms == TFLOP/s
-        traffic = pmc_traffic("k_conv3x3_v4")
+        mfma16 = os.environ.get("EDM_V4_MFMA16", "1") != "0"      # which form of the kernel ran (conv_igemm4.hip dispatch)
+        kname = "k_conv3x3_v6" if mfma16 else "k_conv3x3_v4"
+        traffic = pmc_traffic(kname)
         out = {
             "metric": "train imgs/sec CIFAR-10 32x32 bf16",
             "value": round(ips, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -363,8 +365,9 @@ def main():
                        "collective": ("rccl all-reduce (forced, 1 rank)" if forced else "rccl bucketed all-reduce")
                        if (world > 1 or forced) else "none"},
             "roofline": {
-                "bound": "mfma", "kernel": "k_conv3x3_v4<5,0,4> (3x3 implicit-GEMM conv of the 32x32 layers: forward, incl. fused modulation "
-                                           "epilogue, and plain dgrad)",
+                "bound": "mfma", "kernel": kname + "<5,0,4> (3x3 implicit-GEMM conv of the 32x32 layers: forward, incl. fused "
+                                                   "modulation epilogue, and plain dgrad; "
+                                                   + ("v_mfma_f32_16x16x32_bf16" if mfma16 else "v_mfma_f32_32x32x16_bf16") + ")",
                 "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "traffic_unit": "GB of HBM traffic per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc "

@@ -75,7 +75,8 @@ CONV_SHAPES = [
 ]
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4, 5], ids=["igemm-auto", "igemm-v1", "igemm-v2", "igemm-v3", "igemm-v4", "igemm-s"])
+@pytest.fixture(params=[0, 1, 2, 3, 4, 5, 6],
+                ids=["igemm-auto", "igemm-v1", "igemm-v2", "igemm-v3", "igemm-v4", "igemm-s", "igemm-v6"])
 def igemm_version(request, ops):
     """Every generation of the implicit-GEMM kernel must pass the same parity tests (the per-shape dispatcher
     picks v2/v3 only for full-size layers, so they are forced here on the small test shapes)."""

@@ -45,6 +45,7 @@ SIGNATURES = {
     "edm_conv_igemm_v2": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_v3": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_v4": [P, P, P, P, F, F, I, I, I, I, I, I, P],
+    "edm_conv_igemm_v6": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_s": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv3x3_mod": [P, P, P, P, P, L, P, F, U64, U, U, I, I, I, I, I, P, P],
     "edm_conv3x3_modbwd": [P, P, F, P, P, L, P, P, P, F, U64, U, U, I, I, I, I, I, P, P],

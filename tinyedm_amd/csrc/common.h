@@ -198,12 +198,13 @@ __device__ __forceinline__ u32x4 mod_silu_drop8(const u32x4& uraw, long i8, cons
 // padded rows): the residual is read and the result written 16 B per lane, whole rows per instruction.
 // y = alpha * acc + beta * R is formed in fp32 and rounded to bf16 once.  The caller must have passed a workgroup
 // barrier after its last read of the LDS bytes that `stage` overlays.
-template <int NI, int NJ, int EPI = 0>
-__device__ __forceinline__ void store_tile_transposed(const f32x16 (&acc)[NI][NJ], char* stage, bf16* __restrict__ Y,
-                                                      const bf16* __restrict__ R, float alpha, float beta, long mb0,
-                                                      long Npix, int cw0, int Cout, const ModEpilogue& mod = ModEpilogue{}) {
+// `put(j, stage)` writes alpha * acc (+ beta * the residual already staged) of the 32-pixel block j into `stage` as
+// bf16 [32 px][NI*32 co] rows of EROW bytes: the part that depends on the MFMA shape (see the two wrappers below).
+template <int NI, int NJ, int EPI, class Put>
+__device__ __forceinline__ void store_tile_core(Put&& put, char* stage, bf16* __restrict__ Y, const bf16* __restrict__ R,
+                                                long mb0, long Npix, int cw0, int Cout, const ModEpilogue& mod) {
   constexpr int EROW = NI * 64 + 16, CPR = NI * 4, RPI = 64 / CPR;  // 16-byte chunks per row, rows per instruction
-  const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int lane = threadIdx.x & 63;
   const int c16 = lane % CPR, prow = lane / CPR;
   const int co_c = cw0 + c16 * 8;
 #pragma unroll
@@ -218,25 +219,7 @@ __device__ __forceinline__ void store_tile_transposed(const f32x16 (&acc)[NI][NJ
         *reinterpret_cast<u32x4*>(stage + px * EROW + c16 * 16) = rv;
       }
     }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        char* sp = stage + l31 * EROW + (i * 32 + 8 * g + 4 * lhi) * 2;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = alpha * acc[i][j][4 * g + r];
-        if (R) {
-          bf16x4 rv = *reinterpret_cast<const bf16x4*>(sp);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += beta * (float)rv[r];
-        }
-        bf16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
-        *reinterpret_cast<bf16x4*>(sp) = o;
-      }
-    }
+    put(j, stage);
     float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // backward form: per-lane sums over this block's pixels
 #pragma unroll(EPI ? 1 : 32 / RPI)
     for (int it = 0; it < 32 / RPI; ++it) {
@@ -273,4 +256,58 @@ __device__ __forceinline__ void store_tile_transposed(const f32x16 (&acc)[NI][NJ
       }
     }
   }
+}
+
+// 4 accumulator values (consecutive channels of ONE pixel) -> alpha * v (+ beta * staged residual) -> bf16x4 at sp
+__device__ __forceinline__ void stage4(char* sp, float v0, float v1, float v2, float v3, float alpha, float beta, bool hasR) {
+  float v[4] = {alpha * v0, alpha * v1, alpha * v2, alpha * v3};
+  if (hasR) {
+    bf16x4 rv = *reinterpret_cast<const bf16x4*>(sp);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] += beta * (float)rv[r];
+  }
+  bf16x4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+  *reinterpret_cast<bf16x4*>(sp) = o;
+}
+
+// v_mfma_f32_32x32x16 accumulators: acc[i][j] rows = channels 32 i + 8 g + 4 lhi + r, columns = pixels 32 j + l31
+template <int NI, int NJ, int EPI = 0>
+__device__ __forceinline__ void store_tile_transposed(const f32x16 (&acc)[NI][NJ], char* stage, bf16* __restrict__ Y,
+                                                      const bf16* __restrict__ R, float alpha, float beta, long mb0,
+                                                      long Npix, int cw0, int Cout, const ModEpilogue& mod = ModEpilogue{}) {
+  constexpr int EROW = NI * 64 + 16;
+  const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
+  store_tile_core<NI, NJ, EPI>(
+      [&](int j, char* st) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            stage4(st + l31 * EROW + (i * 32 + 8 * g + 4 * lhi) * 2, acc[i][j][4 * g], acc[i][j][4 * g + 1],
+                   acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], alpha, beta, R != nullptr);
+      },
+      stage, Y, R, mb0, Npix, cw0, Cout, mod);
+}
+
+// v_mfma_f32_16x16x32 accumulators: acc[i][j] (i over 2 NI channel blocks of 16, j over 2 NJ pixel blocks of 16): rows =
+// channels 16 i + 4 (lane >> 4) + r, columns = pixels 16 j + (lane & 15).  Same staging, same coalesced second phase.
+template <int NI, int NJ, int EPI = 0>
+__device__ __forceinline__ void store_tile_transposed16(const f32x4 (&acc)[2 * NI][2 * NJ], char* stage,
+                                                        bf16* __restrict__ Y, const bf16* __restrict__ R, float alpha,
+                                                        float beta, long mb0, long Npix, int cw0, int Cout,
+                                                        const ModEpilogue& mod = ModEpilogue{}) {
+  constexpr int EROW = NI * 64 + 16;
+  const int lane = threadIdx.x & 63, l15 = lane & 15, lq = lane >> 4;
+  store_tile_core<NI, NJ, EPI>(
+      [&](int j, char* st) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int i = 0; i < 2 * NI; ++i)
+            stage4(st + (h * 16 + l15) * EROW + (i * 16 + 4 * lq) * 2, acc[i][2 * j + h][0], acc[i][2 * j + h][1],
+                   acc[i][2 * j + h][2], acc[i][2 * j + h][3], alpha, beta, R != nullptr);
+      },
+      stage, Y, R, mb0, Npix, cw0, Cout, mod);
 }

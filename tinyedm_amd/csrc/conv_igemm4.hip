@@ -306,6 +306,10 @@ bool edm_conv_v4_worthwhile(long npix, int Cout) {
   return tm * ((Cout + 127) / 128) >= 512 || tm * ((Cout + 63) / 64) >= 256;
 }
 
+// conv_igemm6.hip: the same kernel on v_mfma_f32_16x16x32_bf16 (W % 16 == 0)
+int edm_conv_igemm_v6_ex(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
+                         int W, int Cin, int Cout, int taps, const ModEpilogue& mod, hipStream_t st);
+
 // 3x3 only.  Same contract as edm_conv_igemm; returns EDM_ERR_UNSUPPORTED (-3) for shapes it does not cover
 // (taps != 9, Cin % 64 != 0, Cin > 2048, W > 64, fewer than 9*Cin/32 >= 18 tiles ...).
 int edm_conv_igemm_v4_ex(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
@@ -316,6 +320,13 @@ int edm_conv_igemm_v4_ex(const void* X, const void* Wp, void* Y, const void* R, 
   if (taps != 9 || Cin <= 0 || Cin % 64 != 0 || Cin * 2 + 64 > ZERO_PAGE || W > 64) return EDM_ERR_UNSUPPORTED;
   EDM_ZERO_PAGE(zero_page_, "conv_igemm_v4");
   (void)zero_page_;
+  // MFMA shape: the shapes it covers go to the 16x16x32 form of this kernel (conv_igemm6.hip: the device holds a higher
+  // clock on that shape; 32x32 layers +11-19 %, 16x16 layers +2-3 %); EDM_V4_MFMA16=0 keeps the 32x32x16 form
+  static const int mfma16 = [] { const char* e = getenv("EDM_V4_MFMA16"); return e ? atoi(e) : 1; }();
+  if (mfma16) {
+    const int rc = edm_conv_igemm_v6_ex(X, Wp, Y, R, alpha, beta, B, H, W, Cin, Cout, taps, mod, st);
+    if (rc != EDM_ERR_UNSUPPORTED) return rc;
+  }
   const int Npix = B * H * W;
   const int xrows = BM + 2 * (W + 1);
   // 512x128 workgroup tiles when that still gives every CU two of them, else 512x64 (small feature maps)

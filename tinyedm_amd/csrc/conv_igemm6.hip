@@ -1,0 +1,382 @@
+// 3x3 implicit-GEMM convolution, the static-schedule kernel of conv_igemm4.hip on v_mfma_f32_16x16x32_bf16.
+//
+//   Y[p, co] = alpha * sum_{tap, ci} X[p + off(tap), ci] * Wp[tap, co, ci]  (+ beta * R[p, co])     (networks.py:37)
+//
+// Why a second MFMA shape.  The device is power-limited in MFMA-dense code: a bare loop that re-reads every operand
+// from LDS sustains 1.52 PFLOP/s at 1.61 GHz on v_mfma_f32_32x32x16_bf16 and 1.66 PFLOP/s at 1.80 GHz on
+// v_mfma_f32_16x16x32_bf16 -- equal cycles per FLOP, a higher held clock (tools/mfma_shape, MI355X_MICROARCH.md "DVFS
+// give-back" item 7).  Geometry, LDS images, DMA plan, ring depths and counted vmcnt waits are those of
+// k_conv3x3_v4 (512 pixels x 128 or 64 channels per workgroup, 8 waves x (all channels x 64 pixels), 64-byte LDS rows
+// with the 16-byte pieces XOR-swizzled by (row >> 2) & 3); what changes is everything fragment-shaped:
+//  * a fragment is 16 rows x 32 k: lane -> row (lane & 15), piece (lane >> 4).  A step (tap, 32-channel chunk) is ONE
+//    k-step: 2 NI weight fragments + 4 pixel fragments (the same 12 ds_read_b128 as two 32x32x16 k-steps) feeding
+//    8 NI MFMAs of 16 cycles; accumulators are 8 NI blocks of 4 registers.
+//  * pixel-fragment addresses: the swizzle term of row q + 16 j + shift(tap) does not depend on j, so the four pixel
+//    blocks of a wave are ONE per-lane address per tap plus an immediate -- 9 address registers instead of the 36 the
+//    folded-mask scheme of v4 would need here.  Image borders: a 16-pixel block lies in one image row (W % 16 == 0), so
+//    the 32 (non-centre tap, block) validity bits of a lane's pixels live in ONE register; a fragment read expands its
+//    bit to a word mask (v_bfe_i32) and selects the tap address or a zero row with it (v_bfi_b32) -- two vector
+//    instructions per fragment (four zero rows 16 apart, so the block immediate still applies).  (Scalar lane masks in
+//    SGPR pairs + v_cndmask were tried first: hoisted they need 64 SGPRs, re-derived at each use 4-6 scalar
+//    instructions per fragment, 10 % of the 64-channel kernel.)
+//  * fragment registers as v4 (48): weight fragments double-buffered by channel half, pixel fragments single-buffered
+//    with rolling reuse -- an MFMA has read its operands 8 cycles after issue, so block j of the NEXT step is loaded
+//    right behind block j's last MFMA of this step.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((address_space(3))) char lds_char;
+
+constexpr int BM = 512, KC = 32, TAPS = 9;
+constexpr int ROWB = KC * 2;      // 64-byte LDS rows
+constexpr int WRING = 6, D = WRING - 1;
+constexpr int ZERO_PAGE = 4096;
+
+__device__ __forceinline__ void dma16(const void* src, char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_dst, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int N>
+struct IC { static constexpr int value = N; };
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(IC<B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+#define LDS_RD128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NX, int EPI = 0, int NI = 4, bool WPTR64 = true, int WB = 0>
+__global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ X, const bf16* __restrict__ Wp,
+                                                         bf16* __restrict__ Y, const bf16* __restrict__ R,
+                                                         const char* __restrict__ zeros, float alpha, float beta,
+                                                         int Npix, int H, int W, int Cin, int Cout, int tiles_m,
+                                                         int tiles_n, ModEpilogue mod) {
+  apply_dyn(mod);
+  constexpr int NJ = 2;               // 32-pixel blocks per wave (epilogue units)
+  constexpr int NA = 2 * NI, NAH = NI;  // 16-channel weight fragments per step / per half
+  constexpr int NB = 4;               // 16-pixel fragments per wave
+  constexpr int XROWS = NX * 8 * 16;  // LDS rows per slab buffer; rows >= xrows are zero rows
+  constexpr int BMW = 512;
+  constexpr int XBYTES = XROWS * ROWB;
+  constexpr int BNW = 32 * NI;
+  constexpr int WTILE = BNW * ROWB;
+  constexpr int ZROW = XROWS - 1 - 48;  // zero rows ZROW + 16 j (host-checked: ZROW >= xrows)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Xb = smem;
+  char* const Wb = smem + 2 * XBYTES;
+
+  const int id = blockIdx.x;
+  const int xcd = id & 7, k = id >> 3;
+  const int tn = k % tiles_n, tm = (k / tiles_n) * 8 + xcd;
+  if (tm >= tiles_m) return;
+  const int m0 = tm * BMW, n0 = tn * BNW;
+  const int HALO = W + 1;
+  const int xrows = BMW + 2 * HALO;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = pixel octant of this wave
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int drow = lane >> 2, dp = lane & 3;  // DMA lane -> (row in 16-row slot, physical 16-B piece)
+
+  // ---- DMA sources (as k_conv3x3_v4: per lane, computed once, advancing by constants)
+  constexpr int WROWS = NI == 4 ? 16 : 8;
+  const bool w_lane = NI == 4 || lane < 32;
+  // weight tile (chunk, tap): ONE 32-bit per-lane byte offset; chunk and tap enter through the uniform base, so the DMA
+  // takes the SGPR-base + VGPR-offset form and no per-tap 64-bit pointer is kept in vector registers (host-checked:
+  // the packed weights are < 4 GiB)
+  unsigned woff;
+  {
+    const int row = wave * WROWS + (drow & (WROWS - 1));
+    const int co = min(n0 + row, Cout - 1);
+    const int c = dp ^ ((row >> 2) & 3);
+    woff = (unsigned)(((long)co * Cin + c * 8) * 2);
+  }
+  const char* const wbase = reinterpret_cast<const char*>(Wp);
+  const char* const wsrc = wbase + woff;      // NI == 2 (registers to spare): plain per-lane pointer, as k_conv3x3_v4
+  const long tap_stride = (long)Cout * Cin * 2;
+  const char* xsrc[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int row = (wave + 8 * i) * 16 + drow;
+    const int c = dp ^ ((row >> 2) & 3);
+    bool real = row < xrows;
+    if constexpr (WB != 0) {
+      // images start and end on tile boundaries (H*W % 512 == 0): the rows above the first / below the last image row
+      // are fed as zeros, which is all the vertical border handling this form needs
+      const int hw = H * W;
+      if (m0 % hw == 0 && row < HALO) real = false;
+      if ((m0 + BMW) % hw == 0 && row >= HALO + BMW) real = false;
+    }
+    if (real) {
+      long pix = (long)m0 - HALO + row;
+      pix = pix < 0 ? 0 : (pix >= Npix ? Npix - 1 : pix);  // out-of-range rows only feed masked taps
+      xsrc[i] = reinterpret_cast<const char*>(X + pix * Cin + c * 8);
+    } else {
+      xsrc[i] = zeros + c * 16;
+    }
+  }
+
+  // ---- pixel-fragment addresses: ONE per tap (block 0 of this wave; block j = + j * 16 rows = + 1024 bytes, the
+  // swizzle term of the row is unchanged by 16 j), the zero row, and the border masks
+  const unsigned xb_off = (unsigned)(uintptr_t)(lds_char*)Xb;
+  unsigned bp[TAPS];
+  {
+    const int q0 = wave * 64 + l15 + HALO;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int r = q0 + (t / 3 - 1) * W + (t % 3 - 1);
+      bp[t] = xb_off + r * ROWB + ((lq ^ ((r >> 2) & 3)) << 4);
+    }
+  }
+  const unsigned bz = xb_off + ZROW * ROWB + (lq << 4);
+  // WB != 0 (W = 16 WB, images aligned to tiles): block j starts an image row when j % WB == 0 and ends one when
+  // j % WB == WB - 1 -- compile-time facts -- so the left / right border is two more address sets in which the
+  // border lane already points at the zero row: no instruction per fragment at all
+  unsigned bpS[3], bpE[3];
+  if constexpr (WB != 0) {
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      bpS[dy] = l15 == 0 ? bz : bp[3 * dy];
+      bpE[dy] = l15 == 15 ? bz : bp[3 * dy + 2];
+    }
+  }
+  // border validity of this lane's pixel in each of the four blocks, one bit per (non-centre tap, block): bit 4 t8 + j
+  // with t8 = tap (tap < 4) or tap - 1.  A fragment read turns its bit into an all-ones / all-zeros word (v_bfe_i32) and
+  // picks the tap address or the zero row with it (v_bfi_b32): two vector instructions, no scalar work, no VCC.
+  unsigned vbits = 0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int m = m0 + wave * 64 + 16 * j + l15;
+    const int w = m % W, h = (m / W) % H;
+#pragma unroll
+    for (int t8 = 0; t8 < 8; ++t8) {
+      const int t = t8 < 4 ? t8 : t8 + 1;
+      const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+      if (hh >= 0 && hh < H && ww >= 0 && ww < W) vbits |= 1u << (4 * t8 + j);
+    }
+  }
+  // weight-fragment rows 16 i + l15: the swizzle term depends on l15 only
+  const unsigned wb_off = (unsigned)(uintptr_t)(lds_char*)Wb;
+  const unsigned ap = wb_off + l15 * ROWB + ((lq ^ ((l15 >> 2) & 3)) << 4);
+
+  f32x4 acc[NA][NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+  const int nchunks = Cin / KC;  // even (host-checked)
+
+  // ---- prologue: slab 0, then weight tiles 0..D-1 (issue order fixes the counted waits)
+#pragma unroll
+  for (int i = 0; i < NX; ++i) dma16(xsrc[i], Xb + (wave + 8 * i) * 1024);
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (w_lane) dma16(wbase + d * tap_stride + woff, Wb + d * WTILE + wave * (WROWS * ROWB));
+
+  u32x4 fa[2][NAH], fb[NB];
+  // (macros, not nested lambdas: clang rejects implicit captures of the kernel's locals from a generic lambda nested in
+  // the generic step lambda below)
+  // weight fragments of channel half `half` (blocks NAH*half ..) of ring slot `slot`
+#define RD_A(half, slot, kk) \
+  if constexpr (NAH > kk) LDS_RD128(fa[half][kk], ap, (slot) * WTILE + ((half) * NAH + kk) * 16 * ROWB);
+#define READ_A(half, slot) { RD_A(half, slot, 0) RD_A(half, slot, 1) RD_A(half, slot, 2) RD_A(half, slot, 3) }
+  // pixel fragment of block j at tap `tap` (constant expressions) in slab buffer `cpar`
+#define READ_B(j, tap, cpar)                                                                  \
+  {                                                                                           \
+    unsigned addr_ = bp[tap];                                                                 \
+    if constexpr (WB != 0) {                                                                  \
+      if constexpr ((tap) % 3 == 0 && (j) % WB == 0) addr_ = bpS[(tap) / 3];                  \
+      if constexpr ((tap) % 3 == 2 && (j) % WB == WB - 1) addr_ = bpE[(tap) / 3];             \
+    } else if constexpr ((tap) != 4) {                                                        \
+      constexpr int bit_ = 4 * ((tap) < 4 ? (tap) : (tap) - 1) + (j);                          \
+      unsigned msk_;                                                                          \
+      asm volatile("v_bfe_i32 %0, %1, %2, 1" : "=v"(msk_) : "v"(vbits), "n"(bit_));           \
+      asm volatile("v_bfi_b32 %0, %1, %2, %3" : "=v"(addr_) : "v"(msk_), "v"(bp[tap]), "v"(bz)); \
+    }                                                                                         \
+    LDS_RD128(fb[j], addr_, (cpar) * XBYTES + (j) * 16 * ROWB);                               \
+  }
+  // the NAH MFMAs of channel half h on pixel block j.  Inline asm with the accumulator tied ("+v"): with the builtin the
+  // register allocator lets the 32 accumulator blocks wander (vdst != srcC) and ends up 40-75 registers over budget.
+  // The asm is invisible to hipcc's hazard recogniser: an accumulator block is touched once per 32 MFMAs (no
+  // back-to-back dependency), and the epilogue pads the MFMA-write -> VALU-read distance by hand.
+#define MFMA1(h, j, kk)                                                                                          \
+  if constexpr (NAH > kk) {                                                                                      \
+    if constexpr (NI == 4)                                                                                       \
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[(h) * NAH + kk][j])                      \
+                   : "v"(fa[h][kk]), "v"(fb[j]));                                                                \
+    else /* 64-channel tile: the builtin fits (202 registers) and measures 10 % faster than the tied asm form */ \
+      acc[(h) * NAH + kk][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                          \
+          __builtin_bit_cast(bf16x8, fa[h][kk]), __builtin_bit_cast(bf16x8, fb[j]), acc[(h) * NAH + kk][j], 0, 0, 0); \
+  }
+#define MFMA_BLOCK(h, j)                                              \
+  {                                                                   \
+    MFMA1(h, j, 0) MFMA1(h, j, 1) MFMA1(h, j, 2) MFMA1(h, j, 3)       \
+    __builtin_amdgcn_sched_barrier(0);                                \
+  }
+
+  for (int chunk2 = 0; chunk2 < nchunks; chunk2 += 2) {
+    static_for<0, 2 * TAPS>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      constexpr int tap = u % TAPS, cpar = u / TAPS;
+      const int chunk = chunk2 + cpar;
+      const bool more_chunks = chunk + 1 < nchunks;
+      // ---- retire weight tiles t and t+1 (and slab chunk+1 before its first read, issued at tap 8): as v4
+      if (more_chunks) {
+        if (tap >= 1 && tap <= D - 1) wait_vmcnt<D - 2 + NX>();
+        else wait_vmcnt<D - 2>();
+      } else {
+        switch ((TAPS - 2 - tap) < (D - 2) ? (TAPS - 2 - tap) : (D - 2)) {  // last chunk: the ring drains
+          case 3: wait_vmcnt<3>(); break;
+          case 2: wait_vmcnt<2>(); break;
+          case 1: wait_vmcnt<1>(); break;
+          default: wait_vmcnt<0>(); break;
+        }
+      }
+      __builtin_amdgcn_s_barrier();
+      {
+        constexpr int tq = tap + D;
+        constexpr int cq = cpar + (tq >= TAPS ? 1 : 0);
+        constexpr int tapq = tq >= TAPS ? tq - TAPS : tq;
+        if constexpr (NI == 2 && WPTR64) {
+          if (chunk2 + cq < nchunks && w_lane)
+            dma16(wsrc + (long)(chunk2 + cq) * (KC * 2) + tapq * tap_stride,
+                  Wb + ((u + D) % WRING) * WTILE + wave * (WROWS * ROWB));
+        } else if (chunk2 + cq < nchunks && w_lane) {
+          const char* ub = wbase + ((long)(chunk2 + cq) * (KC * 2) + tapq * tap_stride);
+          asm volatile("" : "+s"(ub));   // keep (chunk, tap) in the scalar base: SGPR-base + VGPR-offset DMA, no per-tap
+                                         // 64-bit vector pointers hoisted out of the loop
+          dma16(ub + woff, Wb + ((u + D) % WRING) * WTILE + wave * (WROWS * ROWB));
+        }
+      }
+      if (tap == 0 && more_chunks) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+          dma16(xsrc[i] + (long)(chunk + 1) * (KC * 2), Xb + (cpar ^ 1) * XBYTES + (wave + 8 * i) * 1024);
+      }
+      // ---- 8 NI MFMAs.  LDS reads in issue order: A1(u) | A0(u+1) | B(u+1, 0..3); at the first step A0(0), B(0, *) first.
+      if (u == 0 && chunk2 == 0) {
+        READ_A(0, 0);
+        READ_B(0, 0, 0); READ_B(1, 0, 0); READ_B(2, 0, 0); READ_B(3, 0, 0);
+      }
+      READ_A(1, u % WRING);
+      __builtin_amdgcn_sched_barrier(0);
+      // channel half 0 on blocks 0..3: block j needs A0(u) and B(u, j); younger: B(u, j+1..3) and A1(u)
+      lgkm_wait<3 + NAH>(); MFMA_BLOCK(0, 0);
+      lgkm_wait<2 + NAH>(); MFMA_BLOCK(0, 1);
+      lgkm_wait<1 + NAH>(); MFMA_BLOCK(0, 2);
+      lgkm_wait<0 + NAH>(); MFMA_BLOCK(0, 3);
+      constexpr int tapn = (tap + 1) % TAPS, cparn = (u + 1) / TAPS % 2, slotn = (u + 1) % WRING;
+      if constexpr (NI == 2 && WPTR64) {
+        // 64-channel tile (registers to spare): the last step skips its prefetch
+        const bool has_next = more_chunks || tap + 1 < TAPS;
+        if (has_next) {
+          READ_A(0, slotn);
+          lgkm_wait<NAH>();
+        } else {
+          lgkm_wait<0>();
+        }
+        MFMA_BLOCK(1, 0); if (has_next) READ_B(0, tapn, cparn); __builtin_amdgcn_sched_barrier(0);
+        MFMA_BLOCK(1, 1); if (has_next) READ_B(1, tapn, cparn); __builtin_amdgcn_sched_barrier(0);
+        MFMA_BLOCK(1, 2); if (has_next) READ_B(2, tapn, cparn); __builtin_amdgcn_sched_barrier(0);
+        MFMA_BLOCK(1, 3); if (has_next) READ_B(3, tapn, cparn); __builtin_amdgcn_sched_barrier(0);
+      } else {
+        // The next step's fragments are prefetched unconditionally: behind the very last step they come from ring slot /
+        // slab positions that hold stale but in-bounds data and are never multiplied (no branch in the step body: each
+        // one costs registers here).
+        READ_A(0, slotn);
+        lgkm_wait<NAH>();
+        // channel half 1; behind block j's MFMAs its register takes the NEXT step's block j
+        MFMA_BLOCK(1, 0); READ_B(0, tapn, cparn); __builtin_amdgcn_sched_barrier(0);
+        MFMA_BLOCK(1, 1); READ_B(1, tapn, cparn); __builtin_amdgcn_sched_barrier(0);
+        MFMA_BLOCK(1, 2); READ_B(2, tapn, cparn); __builtin_amdgcn_sched_barrier(0);
+        MFMA_BLOCK(1, 3); READ_B(3, tapn, cparn); __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+  }
+#undef READ_A
+#undef RD_A
+#undef READ_B
+#undef MFMA_BLOCK
+#undef MFMA1
+
+  // ---- epilogue: transposed through wave-private LDS (common.h: store_tile_transposed16)
+  lgkm_wait<0>();                // the last step's (unused) prefetch
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // asm MFMA results -> first read by ordinary code
+  __builtin_amdgcn_s_barrier();  // every wave is done with the slab / weight ring
+  store_tile_transposed16<NI, NJ, EPI>(acc, smem + wave * (32 * (NI * 64 + 16)), Y, R, alpha, beta,
+                                       (long)m0 + wave * (32 * NJ), Npix, n0, Cout, mod);
+}
+
+template <int NX, int EPI, int NI, int WB = 0>
+void launch6(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int Npix, int H, int W,
+             int Cin, int Cout, const ModEpilogue& mod, hipStream_t st) {
+  const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + 32 * NI - 1) / (32 * NI);
+  const size_t lds = (size_t)2 * NX * 8 * 16 * ROWB + WRING * (32 * NI * ROWB);
+  const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
+  auto kern = k_conv3x3_v6<NX, EPI, NI, true, WB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const bf16*)X, (const bf16*)Wp, (bf16*)Y, (const bf16*)R,
+                     (const char*)edm_zero_page(), alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n, mod);
+}
+
+}  // namespace
+
+// Shapes this kernel covers: those of edm_conv_igemm_v4_ex with, in addition, W % 16 == 0 (a 16-pixel block in one image
+// row), H*W % 16 == 0 and 49 spare zero rows in the slab buffer.  Returns EDM_ERR_UNSUPPORTED (-3) otherwise.
+int edm_conv_igemm_v6_ex(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
+                         int W, int Cin, int Cout, int taps, const ModEpilogue& mod, hipStream_t st) {
+  EDM_REQUIRE(X && Wp && (Y || mod.Y2), "conv_igemm_v6: null pointer");
+  EDM_REQUIRE(B > 0 && H > 0 && W > 0 && (long)B * H * W < (1L << 31), "conv_igemm_v6: bad B/H/W");
+  EDM_REQUIRE(Cout > 0 && Cout % 8 == 0, "conv_igemm_v6: Cout %% 8 required");
+  if (taps != 9 || Cin <= 0 || Cin % 64 != 0 || Cin * 2 + 64 > ZERO_PAGE || W > 64 || W % 16 != 0) return EDM_ERR_UNSUPPORTED;
+  EDM_ZERO_PAGE(zero_page_, "conv_igemm_v6");
+  (void)zero_page_;
+  const int Npix = B * H * W;
+  const int xrows = BM + 2 * (W + 1);
+  const bool nx5 = xrows <= 5 * 128 - 49;
+  if (!nx5 && xrows > 6 * 128 - 49) return EDM_ERR_UNSUPPORTED;
+  const long tiles4 = (long)((Npix + BM - 1) / BM) * ((Cout + 127) / 128);
+  const bool wide = tiles4 >= 512;
+  // images aligned to the 512-pixel tiles and W = 32 / 64: border handling without per-fragment instructions
+  const int wb = ((H * W) % BM == 0 && (W == 32 || W == 64)) ? W / 16 : 0;
+#define L6(NXV, EPIV)                                                                                          \
+  (wide ? (wb == 2   ? launch6<NXV, EPIV, 4, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)      \
+           : wb == 4 ? launch6<NXV, EPIV, 4, 4>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)      \
+                     : launch6<NXV, EPIV, 4, 0>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st))     \
+        : (wb == 2   ? launch6<NXV, EPIV, 2, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)      \
+           : wb == 4 ? launch6<NXV, EPIV, 2, 4>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)      \
+                     : launch6<NXV, EPIV, 2, 0>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)))
+  if (mod.mode == 1) { if (nx5) L6(5, 1); else L6(6, 1); }
+  else if (mod.mode == 2) { if (nx5) L6(5, 2); else L6(6, 2); }
+  else { if (nx5) L6(5, 0); else L6(6, 0); }
+#undef L6
+  EDM_CHECK_LAUNCH("conv_igemm_v6");
+  return EDM_OK;
+}
+
+extern "C" int edm_conv_igemm_v6(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B,
+                                 int H, int W, int Cin, int Cout, int taps, hipStream_t st) {
+  EDM_REQUIRE(Y, "conv_igemm_v6: null pointer");
+  return edm_conv_igemm_v6_ex(X, Wp, Y, R, alpha, beta, B, H, W, Cin, Cout, taps, ModEpilogue{}, st);
+}
