@@ -114,7 +114,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
     const int row = (wave + 8 * i) * 16 + drow;
     const int c = dp ^ ((row >> 2) & 3);
     bool real = row < xrows;
-    if constexpr (WB != 0) {
+    if constexpr (WB >= 2) {
       // images start and end on tile boundaries (H*W % 512 == 0): the rows above the first / below the last image row
       // are fed as zeros, which is all the vertical border handling this form needs
       const int hw = H * W;
@@ -153,6 +153,15 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
       bpS[dy] = l15 == 0 ? bz : bp[3 * dy];
       bpE[dy] = l15 == 15 ? bz : bp[3 * dy + 2];
     }
+  }
+  // WB == 1 (16x16 images, two per tile, a wave = four whole image rows): block 0 of waves 0 and 4 is an image's first
+  // row, block 3 of waves 3 and 7 its last -- wave-uniform, so the taps that would leave the image get their own
+  // address registers (all lanes at the zero row in exactly those waves)
+  unsigned bpT[3], bpB[3];
+  if constexpr (WB == 1) {
+    const bool top = (wave & 3) == 0, bot = (wave & 3) == 3;
+    bpT[0] = top ? bz : bpS[0]; bpT[1] = top ? bz : bp[1]; bpT[2] = top ? bz : bpE[0];
+    bpB[0] = bot ? bz : bpS[2]; bpB[1] = bot ? bz : bp[7]; bpB[2] = bot ? bz : bpE[2];
   }
   // border validity of this lane's pixel in each of the four blocks, one bit per (non-centre tap, block): bit 4 t8 + j
   // with t8 = tap (tap < 4) or tap - 1.  A fragment read turns its bit into an all-ones / all-zeros word (v_bfe_i32) and
@@ -204,6 +213,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
     if constexpr (WB != 0) {                                                                  \
       if constexpr ((tap) % 3 == 0 && (j) % WB == 0) addr_ = bpS[(tap) / 3];                  \
       if constexpr ((tap) % 3 == 2 && (j) % WB == WB - 1) addr_ = bpE[(tap) / 3];             \
+      if constexpr (WB == 1 && (tap) / 3 == 0 && (j) == 0) addr_ = bpT[(tap) % 3];            \
+      if constexpr (WB == 1 && (tap) / 3 == 2 && (j) == 3) addr_ = bpB[(tap) % 3];            \
     } else if constexpr ((tap) != 4) {                                                        \
       constexpr int bit_ = 4 * ((tap) < 4 ? (tap) : (tap) - 1) + (j);                          \
       unsigned msk_;                                                                          \
@@ -358,19 +369,20 @@ int edm_conv_igemm_v6_ex(const void* X, const void* Wp, void* Y, const void* R, 
   if (!nx5 && xrows > 6 * 128 - 49) return EDM_ERR_UNSUPPORTED;
   const long tiles4 = (long)((Npix + BM - 1) / BM) * ((Cout + 127) / 128);
   const bool wide = tiles4 >= 512;
-  // images aligned to the 512-pixel tiles and W = 32 / 64: border handling without per-fragment instructions
-  const int wb = ((H * W) % BM == 0 && (W == 32 || W == 64)) ? W / 16 : 0;
-#define L6(NXV, EPIV)                                                                                          \
-  (wide ? (wb == 2   ? launch6<NXV, EPIV, 4, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)      \
-           : wb == 4 ? launch6<NXV, EPIV, 4, 4>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)      \
-                     : launch6<NXV, EPIV, 4, 0>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st))     \
-        : (wb == 2   ? launch6<NXV, EPIV, 2, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)      \
-           : wb == 4 ? launch6<NXV, EPIV, 2, 4>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)      \
-                     : launch6<NXV, EPIV, 2, 0>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)))
+  // images aligned to the 512-pixel tiles (W = 32 / 64), or 16x16 images (two per tile): border handling without
+  // per-fragment instructions
+  const int wb = ((H * W) % BM == 0 && (W == 32 || W == 64)) ? W / 16 : (H == 16 && W == 16) ? 1 : 0;
+#define L6W(NXV, EPIV, NIV)                                                                                  \
+  (wb == 1   ? launch6<NXV, EPIV, NIV, 1>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)          \
+   : wb == 2 ? launch6<NXV, EPIV, NIV, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)          \
+   : wb == 4 ? launch6<NXV, EPIV, NIV, 4>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)          \
+             : launch6<NXV, EPIV, NIV, 0>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st))
+#define L6(NXV, EPIV) (wide ? L6W(NXV, EPIV, 4) : L6W(NXV, EPIV, 2))
   if (mod.mode == 1) { if (nx5) L6(5, 1); else L6(6, 1); }
   else if (mod.mode == 2) { if (nx5) L6(5, 2); else L6(6, 2); }
   else { if (nx5) L6(5, 0); else L6(6, 0); }
 #undef L6
+#undef L6W
   EDM_CHECK_LAUNCH("conv_igemm_v6");
   return EDM_OK;
 }
