@@ -95,7 +95,11 @@ __device__ __forceinline__ bf16x8 frag_of(const u32x2_t& lo, const u32x2_t& hi) 
 
 // ABL: timing-only ablation builds for tools/ (outputs wrong by construction): bit0 no MFMA, bit1 no DMA issue,
 // bit2 no barrier, bit3 no fragment reads + MFMA.  ABL = 0 is the product.
-template <int LEADS, int ABL = 0>
+// MF16: the MFMAs are v_mfma_f32_16x16x32_bf16 (the device holds a higher clock on that shape: tools/mfma_shape,
+// conv_igemm6.hip): same LDS images and bytes, same DMA plan; a fragment is 16 channels x 32 pixel rows -- two
+// ds_read_b64_tr_b16 of rows 8g..8g+3 and 8g+4..8g+7 per 16-lane group g -- and the wave's 64(co) x 32(ci) x 9 taps are
+// 72 accumulator blocks of 4 registers (64 in AGPRs, tap 8 in VGPRs, as before).
+template <int LEADS, int ABL = 0, bool MF16 = false>
 __global__ __launch_bounds__(256, 1) void k_wgrad3(const W3Group g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int XR = Ring<LEADS>::XR, MIRR = Ring<LEADS>::MIRR, XSLOTS = Ring<LEADS>::XSLOTS;
@@ -109,6 +113,10 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3(const W3Group g) {
   const int krow_l = 8 * (lane >> 5) + ((lane & 15) >> 2);
   const int chan_b = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
   const int l31 = lane & 31, lhi = lane >> 5;
+  // 16x16x32 operands: lane 4q+p of group g = lane >> 4 supplies row 8g + q, columns 4p..4p+3 of a 16-column block
+  const int krow16 = 8 * (lane >> 4) + ((lane & 15) >> 2);
+  const int chan16 = (4 * (lane & 3)) * 2;
+  const int l15 = lane & 15, lq = lane >> 4;
 
   // blockIdx -> (XCD, local index on it) -> (team, member): the 8 members of a team share an XCD (and its L2)
   const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
@@ -188,15 +196,30 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3(const W3Group g) {
       }
     };
 
-    f32x16 acc[2][8], accv[2];   // taps 0..7 (AGPRs) and tap 8 (VGPRs, see MMV)
+    f32x16 acc[MF16 ? 1 : 2][MF16 ? 1 : 8], accv[MF16 ? 1 : 2];   // taps 0..7 (AGPRs) and tap 8 (VGPRs, see MMV)
+    f32x4 acc16[MF16 ? 4 : 1][2][MF16 ? 8 : 1], accv16[MF16 ? 4 : 1][2];   // [co block of 16][ci block of 16][tap]
+    if constexpr (MF16) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+      for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int t = 0; t < 8; ++t)
+        for (int b = 0; b < 2; ++b) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+          for (int t = 0; t < 8; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) accv[i][r] = 0.f;
+            for (int r = 0; r < 4; ++r) acc16[c][b][t][r] = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) accv16[c][b][r] = 0.f;
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accv[i][r] = 0.f;
+      }
     }
 
     {
@@ -261,7 +284,61 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3(const W3Group g) {
       }
       char* const xdst = Xb + xslot * SUBB + wave * 1024;
       char* const ddst = dYb + ((t + 2) % DYRING) * (4 * SUBB) + wave * 1024;
-      if constexpr (!(ABL & 8)) {
+      if constexpr (MF16) {
+        const int slot = (t + LEADS) & (XR - 1);
+        const int base_row = (slot < LEADS ? slot + XR : slot) * KP;
+        const unsigned a_u = (unsigned)(uintptr_t)(lds_char*)dYb + (t % DYRING) * (4 * SUBB) + (cb * 2) * SUBB + krow16 * 64 + chan16;
+        const unsigned b_u = (unsigned)(uintptr_t)(lds_char*)Xb + ib * (XSLOTS * SUBB) + (base_row + krow16) * 64 + chan16;
+        unsigned tb[9];
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) tb[tp] = b_u + ((tp / 3 - 1) * PW + (tp % 3 - 1)) * 64;
+        // ---- 144 MFMAs of this stage: k-step ks2 (32 rows) x tap tp x ci block b; X fragment n = 18 ks2 + 2 tp + b feeds
+        // four MFMAs (the wave's four co blocks).  One MFMA, then ONE fragment read for three X fragments ahead (behind the
+        // first two MFMAs of a fragment); the four dY fragments of k-step 1 are read behind fragments 8, 10, 12, 14.
+        // dY fragment c (co block c of 16): sub-image c >> 1, columns 16 (c & 1) ..; k-step: + 32 rows.
+        u32x2_t A[2][4][2], Bf[6][2];
+#define A_RD(set, c, ks2_)                                                                    \
+  TR_RD(A[set][c][0], a_u, ((c) >> 1) * SUBB + ((c) & 1) * 32 + (ks2_) * 2048);               \
+  TR_RD(A[set][c][1], a_u, ((c) >> 1) * SUBB + ((c) & 1) * 32 + (ks2_) * 2048 + 256);
+        A_RD(0, 0, 0) A_RD(0, 1, 0) A_RD(0, 2, 0) A_RD(0, 3, 0)
+        TR_RD(Bf[0][0], tb[0], 0); TR_RD(Bf[0][1], tb[0], 256);
+        TR_RD(Bf[1][0], tb[0], 32); TR_RD(Bf[1][1], tb[0], 32 + 256);
+        TR_RD(Bf[2][0], tb[1], 0); TR_RD(Bf[2][1], tb[1], 256);
+        static_for<0, 36>([&](auto nc) {
+          constexpr int n = decltype(nc)::value;
+          constexpr int ks2 = n / 18, f = n % 18, tp = f / 2, b = f % 2;
+          const unsigned au_ = a_u;
+          // reads younger than fragment n: fragments n+1, n+2 and the dY reads issued in slots n-3 .. n-1 (slots 8, 10, 12, 14)
+          constexpr int na = ((n - 3 <= 8 && 8 <= n - 1) ? 1 : 0) + ((n - 3 <= 10 && 10 <= n - 1) ? 1 : 0) +
+                             ((n - 3 <= 12 && 12 <= n - 1) ? 1 : 0) + ((n - 3 <= 14 && 14 <= n - 1) ? 1 : 0);
+          constexpr int cnt = n >= 33 ? (35 - n) * 2 : 4 + 2 * na;
+          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(cnt) : "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (n == 1) { if (do_x) { dma16(xsrc0, xdst); if (xslot < MIRR) dma16(xsrc0, xdst + XR * SUBB); } __builtin_amdgcn_sched_barrier(0); }
+          if constexpr (n == 5) { if (do_x) { dma16(xsrc1, xdst + XSLOTS * SUBB); if (xslot < MIRR) dma16(xsrc1, xdst + (XSLOTS + XR) * SUBB); } __builtin_amdgcn_sched_barrier(0); }
+          if constexpr (n == 10) { if (do_dy) dma16(dsrc[0], ddst); __builtin_amdgcn_sched_barrier(0); }
+          if constexpr (n == 14) { if (do_dy) dma16(dsrc[1], ddst + SUBB); __builtin_amdgcn_sched_barrier(0); }
+          if constexpr (n == 19) { if (do_dy) dma16(dsrc[2], ddst + 2 * SUBB); __builtin_amdgcn_sched_barrier(0); }
+          if constexpr (n == 23) { if (do_dy) dma16(dsrc[3], ddst + 3 * SUBB); __builtin_amdgcn_sched_barrier(0); }
+          const bf16x8 bfr = frag_of(Bf[n % 6][0], Bf[n % 6][1]);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const bf16x8 afr = frag_of(A[ks2 & 1][c][0], A[ks2 & 1][c][1]);
+            if constexpr (tp < 8) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc16[c][b][tp < 8 ? tp : 0]) : "v"(afr), "v"(bfr));
+            else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accv16[c][b]) : "v"(afr), "v"(bfr));
+            if constexpr (n + 3 < 36) {
+              constexpr int m = n + 3, ksm = m / 18, fm = m % 18;
+              if (c < 2) TR_RD(Bf[m % 6][c < 2 ? c : 0], tb[fm / 2], ksm * 2048 + (fm % 2) * 32 + (c < 2 ? c : 0) * 256);
+            }
+          }
+          if constexpr (ks2 == 0 && b == 0 && tp >= 4 && tp <= 7) {   // dY fragments of k-step 1: co block tp - 4
+            constexpr int ca = tp - 4;
+            TR_RD(A[1][ca][0], au_, (ca >> 1) * SUBB + (ca & 1) * 32 + 2048);
+            TR_RD(A[1][ca][1], au_, (ca >> 1) * SUBB + (ca & 1) * 32 + 2048 + 256);
+          }
+        });
+#undef A_RD
+      } else if constexpr (!(ABL & 8)) {
         const int slot = (t + LEADS) & (XR - 1);                        // X stage t+LEADS is the centre of the window
         const int base_row = (slot < LEADS ? slot + XR : slot) * KP;    // mirrored position when the window would wrap
         unsigned a_u = (unsigned)(uintptr_t)(lds_char*)dYb + (t % DYRING) * (4 * SUBB) + (cb * 2) * SUBB + krow_l * 64 + chan_b;
@@ -324,6 +401,18 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3(const W3Group g) {
     // ---- flush the partial tile: [tap][128 co][64 ci] fp32, always whole (inactive blocks hold zeros).
     // The asm MFMAs are invisible to hipcc's hazard recogniser: pad their write -> VMEM-read distance by hand.
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if constexpr (MF16) {   // block (c, b): rows = co 16 c + 4 (lane >> 4) + r, columns = ci 16 b + (lane & 15)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp) {
+            float* base = out + ((long)tp * TCO + cb * 64 + c * 16 + 4 * lq) * TCI + ib * 32 + b * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) base[r * TCI] = (tp < 8) ? acc16[c][b][tp < 8 ? tp : 0][r] : accv16[c][b][r];
+          }
+    } else {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -333,6 +422,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3(const W3Group g) {
         for (int r = 0; r < 16; ++r)
           base[((r & 3) + 8 * (r >> 2) + 4 * lhi) * TCI] = (tp < 8) ? acc[i][tp < 8 ? tp : 0][r] : accv[i][r];
       }
+    }
     pos += nst;
     if (pos >= g.L[li].stage0 + (long)g.L[li].ngroups * g.L[li].nst) ++li;
     // every wave must be past its LDS reads before the next segment's prologue overwrites the rings
@@ -560,18 +650,21 @@ extern "C" int edm_wgrad3_group(const edm_wgrad3_item* items, int n, void* works
       case 22: go(k_wgrad3<1, 22>); break;
       default: go(k_wgrad3<1, 14>); break;
     }
-  } else if (P.leads == 1) {
-    if (!set1) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      set1 = true;
-    }
-    hipLaunchKernelGGL(k_wgrad3<1>, dim3(P.wg.nwg), dim3(256), Ring<1>::LDS, st, P.wg);
   } else {
-    if (!set2) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      set2 = true;
-    }
-    hipLaunchKernelGGL(k_wgrad3<2>, dim3(P.wg.nwg), dim3(256), Ring<2>::LDS, st, P.wg);
+    // MFMA shape (see the kernel): 16x16x32 by default (32x32 layers +4 %, 16x16 +2 %, 8x8 -2 % inside a group; the
+    // training step gains 0.03 ms -- the kernel waits on its LDS-DMA issue, not on the matrix pipe); EDM_W3_MFMA16=0 keeps
+    // v_mfma_f32_32x32x16_bf16
+    static const int mf16 = [] { const char* e = getenv("EDM_W3_MFMA16"); return e ? atoi(e) : 1; }();
+    auto go = [&](auto kern, size_t lds, bool& once) {
+      if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        once = true;
+      }
+      hipLaunchKernelGGL(kern, dim3(P.wg.nwg), dim3(256), lds, st, P.wg);
+    };
+    static bool set1m = false, set2m = false;
+    if (P.leads == 1) { if (mf16) go(k_wgrad3<1, 0, true>, Ring<1>::LDS, set1m); else go(k_wgrad3<1>, Ring<1>::LDS, set1); }
+    else { if (mf16) go(k_wgrad3<2, 0, true>, Ring<2>::LDS, set2m); else go(k_wgrad3<2>, Ring<2>::LDS, set2); }
   }
   EDM_CHECK_LAUNCH("wgrad3");
   if (!setf) {
