@@ -95,7 +95,30 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
 }
 __device__ __forceinline__ float u32_to_unit(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }  // [0,1)
 
-__device__ __forceinline__ bool keep_elem(uint32_t r, float p) { return u32_to_unit(r) >= p; }
+// Dropout keep mask of the 8 elements of 16-byte chunk i8 (bit j = element j kept), shared by the forward and backward
+// kernels and edm_dropout_mask: ONE Philox4x32-10 call per chunk, 16 random bits per element compared with
+// round(p * 65536) (p = 0.13 -> 8520/65536; the rescale uses the same quantised p).  Round 1 drew 32 bits per
+// element, two Philox calls per chunk: 25 us of a 170-us fused forward conv at 32x32.
+struct Keep8 {
+  uint32_t bits;
+  float scale;
+  __device__ __forceinline__ bool operator[](int j) const { return (bits >> j) & 1u; }
+};
+__device__ __forceinline__ Keep8 dropout_keep8(long i8, float p, uint32_t sub, uint32_t step, uint32_t seed_lo,
+                                               uint32_t seed_hi) {
+  Keep8 k{0xFFu, 1.0f};
+  if (p > 0.f) {
+    const Philox4 r = philox4x32_10((uint32_t)i8, (uint32_t)(i8 >> 32), sub, step, seed_lo, seed_hi);
+    const uint32_t thr = (uint32_t)(p * 65536.0f + 0.5f);
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+    uint32_t m = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m |= (((w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) >= thr ? 1u : 0u) << j;
+    k.bits = m;
+    k.scale = 65536.0f / (float)(65536u - thr);
+  }
+  return k;
+}
 
 // Optional second epilogue output of the implicit-GEMM kernels: the embedding modulation + mp_silu + dropout that
 // follows the first 3x3 conv of every block (networks.py:255-260 / 319-324), a2 = dropout(mp_silu(u*(lin*gain+1))),
@@ -150,20 +173,15 @@ __device__ __forceinline__ u32x4 mod_silu_drop_bwd8(const u32x4& garaw, const u3
                                                     const float* __restrict__ lp, float g, const ModEpilogue& m,
                                                     float (&part)[8]) {
   const bf16x8 gv = __builtin_bit_cast(bf16x8, garaw), uv = __builtin_bit_cast(bf16x8, uraw);
-  Philox4 r0, r1;
-  if (m.pdrop > 0.f) {
-    r0 = philox4x32_10((uint32_t)(2 * i8), (uint32_t)((2 * i8) >> 32), m.sub, m.step, m.seed_lo, m.seed_hi);
-    r1 = philox4x32_10((uint32_t)(2 * i8 + 1), (uint32_t)((2 * i8 + 1) >> 32), m.sub, m.step, m.seed_lo, m.seed_hi);
-  }
-  const uint32_t rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-  const float keep_scale = m.pdrop > 0.f ? 1.0f / (1.0f - m.pdrop) : 1.0f;
+  const Keep8 keep = dropout_keep8(i8, m.pdrop, m.sub, m.step, m.seed_lo, m.seed_hi);
+  const float keep_scale = keep.scale;
   bf16x8 o;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const float mm = lp[j] * g + 1.0f;
     const float u = (float)uv[j];
     float gu = (float)gv[j] * mp_silu_grad_f(u * mm);
-    if (m.pdrop > 0.f) gu = keep_elem(rr[j], m.pdrop) ? gu * keep_scale : 0.f;
+    if (m.pdrop > 0.f) gu = keep[j] ? gu * keep_scale : 0.f;
     part[j] += gu * u;
     o[j] = (bf16)(gu * mm);
   }
@@ -172,19 +190,14 @@ __device__ __forceinline__ u32x4 mod_silu_drop_bwd8(const u32x4& garaw, const u3
 __device__ __forceinline__ u32x4 mod_silu_drop8(const u32x4& uraw, long i8, const float* __restrict__ lp, float g,
                                                 const ModEpilogue& m) {
   const bf16x8 uv = __builtin_bit_cast(bf16x8, uraw);
-  Philox4 r0, r1;
-  if (m.pdrop > 0.f) {
-    r0 = philox4x32_10((uint32_t)(2 * i8), (uint32_t)((2 * i8) >> 32), m.sub, m.step, m.seed_lo, m.seed_hi);
-    r1 = philox4x32_10((uint32_t)(2 * i8 + 1), (uint32_t)((2 * i8 + 1) >> 32), m.sub, m.step, m.seed_lo, m.seed_hi);
-  }
-  const uint32_t rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-  const float keep_scale = m.pdrop > 0.f ? 1.0f / (1.0f - m.pdrop) : 1.0f;
+  const Keep8 keep = dropout_keep8(i8, m.pdrop, m.sub, m.step, m.seed_lo, m.seed_hi);
+  const float keep_scale = keep.scale;
   bf16x8 o;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const float mm = lp[j] * g + 1.0f;
     float v = mp_silu_f((float)uv[j] * mm);
-    if (m.pdrop > 0.f) v = keep_elem(rr[j], m.pdrop) ? v * keep_scale : 0.f;
+    if (m.pdrop > 0.f) v = keep[j] ? v * keep_scale : 0.f;
     o[j] = (bf16)v;
   }
   return __builtin_bit_cast(u32x4, o);

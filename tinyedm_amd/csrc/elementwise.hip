@@ -237,7 +237,6 @@ __global__ void k_mod_silu_drop_fwd(const bf16* __restrict__ r, const float* __r
   if (dyn) { step = dyn->step; seed_lo = dyn->seed_lo; seed_hi = dyn->seed_hi; }
   const int CL = C >> 3;
   const float g = *gain;
-  const float keep_scale = pdrop > 0.f ? 1.0f / (1.0f - pdrop) : 1.0f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
     const int c8 = (int)(i % CL);
     const long pix = i / CL;
@@ -245,17 +244,13 @@ __global__ void k_mod_silu_drop_fwd(const bf16* __restrict__ r, const float* __r
     float v[8];
     load8(r + i * 8, v);
     const float* lp = lin + (long)b * lin_stride + c8 * 8;
-    Philox4 r0, r1;
-    if (pdrop > 0.f) {
-      r0 = philox4x32_10((uint32_t)(2 * i), (uint32_t)((2 * i) >> 32), sub, step, seed_lo, seed_hi);
-      r1 = philox4x32_10((uint32_t)(2 * i + 1), (uint32_t)((2 * i + 1) >> 32), sub, step, seed_lo, seed_hi);
-    }
-    uint32_t rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    const Keep8 keep = dropout_keep8(i, pdrop, sub, step, seed_lo, seed_hi);
+    const float keep_scale = keep.scale;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float m = lp[j] * g + 1.0f;
       float o = mp_silu_f(v[j] * m);
-      if (pdrop > 0.f) o = keep_elem(rr[j], pdrop) ? o * keep_scale : 0.f;
+      if (pdrop > 0.f) o = keep[j] ? o * keep_scale : 0.f;
       v[j] = o;
     }
     store8(a + i * 8, v);
@@ -278,7 +273,6 @@ __global__ void k_mod_silu_drop_bwd(const bf16* __restrict__ r, const float* __r
   const int p_begin = blockIdx.y * PIXW;
   const int p_end = min(HW, p_begin + PIXW);
   const float g = *gain;
-  const float keep_scale = pdrop > 0.f ? 1.0f / (1.0f - pdrop) : 1.0f;
   float m[8], acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -290,16 +284,12 @@ __global__ void k_mod_silu_drop_bwd(const bf16* __restrict__ r, const float* __r
     float v[8], gg[8];
     load8(r + i * 8, v);
     load8(ga + i * 8, gg);
-    Philox4 r0, r1;
-    if (pdrop > 0.f) {
-      r0 = philox4x32_10((uint32_t)(2 * i), (uint32_t)((2 * i) >> 32), sub, step, seed_lo, seed_hi);
-      r1 = philox4x32_10((uint32_t)(2 * i + 1), (uint32_t)((2 * i + 1) >> 32), sub, step, seed_lo, seed_hi);
-    }
-    uint32_t rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    const Keep8 keep = dropout_keep8(i, pdrop, sub, step, seed_lo, seed_hi);
+    const float keep_scale = keep.scale;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float gu = gg[j] * mp_silu_grad_f(v[j] * m[j]);
-      if (pdrop > 0.f) gu = keep_elem(rr[j], pdrop) ? gu * keep_scale : 0.f;
+      if (pdrop > 0.f) gu = keep[j] ? gu * keep_scale : 0.f;
       acc[j] += gu * v[j];
       gg[j] = gu * m[j];
     }
@@ -382,11 +372,9 @@ extern "C" int edm_mod_finish(const float* gm, const float* lin, long lin_stride
 __global__ void k_dropout_mask(uint8_t* __restrict__ mask, long n8, float pdrop, uint32_t seed_lo, uint32_t seed_hi,
                                uint32_t sub, uint32_t step) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
-    Philox4 r0 = philox4x32_10((uint32_t)(2 * i), (uint32_t)((2 * i) >> 32), sub, step, seed_lo, seed_hi);
-    Philox4 r1 = philox4x32_10((uint32_t)(2 * i + 1), (uint32_t)((2 * i + 1) >> 32), sub, step, seed_lo, seed_hi);
-    uint32_t rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    const Keep8 keep = dropout_keep8(i, pdrop, sub, step, seed_lo, seed_hi);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) mask[i * 8 + j] = keep_elem(rr[j], pdrop) ? 1 : 0;
+    for (int j = 0; j < 8; ++j) mask[i * 8 + j] = keep[j] ? 1 : 0;
   }
 }
 extern "C" int edm_dropout_mask(unsigned char* mask, long n, float pdrop, unsigned long long seed, unsigned sub,
