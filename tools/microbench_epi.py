@@ -41,7 +41,10 @@ cases = {
     "fwd mod p=0 (a2 only, eval)": lambda: ops.conv3x3_mod(x, wp, lin, gain, 0.0, 1, 2, 3, want_u=False),
     "dgrad + mod bwd p=0.13": lambda: ops.conv3x3_modbwd(x, wp, 0.8, r, lin, gain, 0.13, 1, 2, 3),
     "dgrad + silu bwd (+add)": lambda: ops.conv3x3_silubwd(x, wp, r, r, 0.5),
+    "UNFUSED fwd: conv, then mod/silu/drop": lambda: ops.mod_silu_drop_fwd(ops.conv_igemm(x, wp, 9), lin, gain, 0.13, 1, 2, 3),
+    "UNFUSED bwd: dgrad, then mod bwd": lambda: ops.mod_silu_drop_bwd(r, lin, gain, ops.conv_igemm(x, wp, 9, alpha=0.8), 0.13, 1, 2, 3),
+    "UNFUSED bwd: dgrad, then silu bwd": lambda: ops.silu_bwd(r, ops.conv_igemm(x, wp, 9), r, 0.5),
 }
 for name, fn in cases.items():
     ms = timeit(fn)
-    print(f"{name:32s} {ms * 1e3:7.1f} us  {fl / ms / 1e9:7.1f} TF/s", flush=True)
+    print(f"{name:40s} {ms * 1e3:7.1f} us  {fl / ms / 1e9:7.1f} TF/s", flush=True)
