@@ -106,6 +106,33 @@ def test_conv_igemm_forward(ops, igemm_version, B, H, W, Cin, Cout, k):
     close_bf16(nchw(y), ref)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,imgs", [
+    (4, 32, 32, 64, 128, None),        # images aligned to tiles, W = 32: static border registers, 64-channel tile
+    (3, 16, 32, 128, 64, None),        # one tile per image: zero halo above AND below
+    (2, 64, 64, 64, 64, None),         # W = 64: 6-slot slab, four blocks per image row
+    (5, 16, 16, 64, 192, None),        # 16x16 images, two per tile (ragged last tile), per-wave top / bottom registers
+    (1, 48, 16, 64, 64, None),         # W = 16 but H != 16: the general per-lane validity bits
+    (2, 24, 48, 64, 64, None),         # W = 48 (multiple of 16, images not aligned to tiles): general path
+    (32, 64, 64, 64, 256, [0, 17, 31]),  # W = 64 with the 128-channel tile (512 x 128 workgroups)
+])
+def test_conv3x3_v6_border_paths(ops, B, H, W, Cin, Cout, imgs):
+    """k_conv3x3_v6 (16x16x32 MFMA form) handles image borders four different ways depending on the shape; every one
+    against an fp64 convolution of the same bf16 operands."""
+    g = torch.Generator().manual_seed(H * 100 + W + Cout)
+    x = q(torch.randn(B, Cin, H, W, generator=g))
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9))
+    old = ops.IGEMM_VERSION
+    ops.IGEMM_VERSION = 6
+    try:
+        assert ops._igemm_entry(B * H * W, W, Cout, 9, Cin) == "edm_conv_igemm_v6"
+        y = ops.conv_igemm(nhwc(x), pack_fwd(w), 9)
+    finally:
+        ops.IGEMM_VERSION = old
+    sel = list(range(B)) if imgs is None else imgs
+    ref = F.conv2d(x[sel].double(), w.double(), padding=1)
+    close_bf16(nchw(y)[sel], ref)
+
+
 def test_conv_full_size_layer_properties(ops):
     """BASELINE-size layer (B=128, 32x32, 256->256): too big for an fp64 CPU reference in a test, so check
     size-independent properties of the kernels the dispatcher picks there: linearity of conv in its input,

@@ -372,17 +372,21 @@ int edm_conv_igemm_v6_ex(const void* X, const void* Wp, void* Y, const void* R, 
   // images aligned to the 512-pixel tiles (W = 32 / 64), or 16x16 images (two per tile): border handling without
   // per-fragment instructions
   const int wb = ((H * W) % BM == 0 && (W == 32 || W == 64)) ? W / 16 : (H == 16 && W == 16) ? 1 : 0;
-#define L6W(NXV, EPIV, NIV)                                                                                  \
-  (wb == 1   ? launch6<NXV, EPIV, NIV, 1>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)          \
-   : wb == 2 ? launch6<NXV, EPIV, NIV, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)          \
-   : wb == 4 ? launch6<NXV, EPIV, NIV, 4>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)          \
-             : launch6<NXV, EPIV, NIV, 0>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st))
-#define L6(NXV, EPIV) (wide ? L6W(NXV, EPIV, 4) : L6W(NXV, EPIV, 2))
-  if (mod.mode == 1) { if (nx5) L6(5, 1); else L6(6, 1); }
-  else if (mod.mode == 2) { if (nx5) L6(5, 2); else L6(6, 2); }
-  else { if (nx5) L6(5, 0); else L6(6, 0); }
+  // (W = 64 needs the 6-slot slab, W = 16 / 32 fit the 5-slot one: only the combinations that can occur are built)
+#define L6A(EPIV, NIV)                                                                                     \
+  (wb == 1   ? launch6<5, EPIV, NIV, 1>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)          \
+   : wb == 2 ? launch6<5, EPIV, NIV, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)          \
+             : launch6<5, EPIV, NIV, 0>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st))
+#define L6B(EPIV, NIV)                                                                                     \
+  (wb == 4 ? launch6<6, EPIV, NIV, 4>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)            \
+           : launch6<6, EPIV, NIV, 0>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st))
+#define L6(EPIV) (nx5 ? (wide ? L6A(EPIV, 4) : L6A(EPIV, 2)) : (wide ? L6B(EPIV, 4) : L6B(EPIV, 2)))
+  if (mod.mode == 1) L6(1);
+  else if (mod.mode == 2) L6(2);
+  else L6(0);
 #undef L6
-#undef L6W
+#undef L6A
+#undef L6B
   EDM_CHECK_LAUNCH("conv_igemm_v6");
   return EDM_OK;
 }
