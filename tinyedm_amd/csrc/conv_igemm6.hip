@@ -59,7 +59,7 @@ __device__ __forceinline__ void lgkm_wait() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int NX, int EPI = 0, int NI = 4, bool WPTR64 = true, int WB = 0>
+template <int NX, int EPI = 0, int NI = 4, bool WPTR64 = true, int WB = 0, bool LATE_DMA = false>
 __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ X, const bf16* __restrict__ Wp,
                                                          bf16* __restrict__ Y, const bf16* __restrict__ R,
                                                          const char* __restrict__ zeros, float alpha, float beta,
@@ -91,6 +91,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = pixel octant of this wave
   const int l15 = lane & 15, lq = lane >> 4;
   const int drow = lane >> 2, dp = lane & 3;  // DMA lane -> (row in 16-row slot, physical 16-B piece)
+  const bool late = LATE_DMA && wave >= 4;    // see the DMA issue in the step body
 
   // ---- DMA sources (as k_conv3x3_v4: per lane, computed once, advancing by constants)
   constexpr int WROWS = NI == 4 ? 16 : 8;
@@ -261,7 +262,12 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
         }
       }
       __builtin_amdgcn_s_barrier();
-      {
+      // ---- this step's DMAs: weight tile t+D into the ring slot read at step t-1, and (tap 0) the next slab.  An LDS-DMA
+      // instruction holds the issuing wave for 60-180 cycles and the two waves of a SIMD leave the barrier together.
+      // LATE_DMA (waves 4-7 issue in the middle of the step instead, so that one partner multiplies while the other
+      // issues; per-wave issue ORDER unchanged, so the counted vmcnt waits hold) was measured in round 2: 0.5 % SLOWER in
+      // the training step (14.78 vs 14.68 ms), mixed in isolation -- off.
+      auto issue_dma = [&]() {
         constexpr int tq = tap + D;
         constexpr int cq = cpar + (tq >= TAPS ? 1 : 0);
         constexpr int tapq = tq >= TAPS ? tq - TAPS : tq;
@@ -275,12 +281,13 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
                                          // 64-bit vector pointers hoisted out of the loop
           dma16(ub + woff, Wb + ((u + D) % WRING) * WTILE + wave * (WROWS * ROWB));
         }
-      }
-      if (tap == 0 && more_chunks) {
+        if (tap == 0 && more_chunks) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i)
-          dma16(xsrc[i] + (long)(chunk + 1) * (KC * 2), Xb + (cpar ^ 1) * XBYTES + (wave + 8 * i) * 1024);
-      }
+          for (int i = 0; i < NX; ++i)
+            dma16(xsrc[i] + (long)(chunk + 1) * (KC * 2), Xb + (cpar ^ 1) * XBYTES + (wave + 8 * i) * 1024);
+        }
+      };
+      if (!late) issue_dma();
       // ---- 8 NI MFMAs.  LDS reads in issue order: A1(u) | A0(u+1) | B(u+1, 0..3); at the first step A0(0), B(0, *) first.
       if (u == 0 && chunk2 == 0) {
         READ_A(0, 0);
@@ -293,6 +300,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
       lgkm_wait<2 + NAH>(); MFMA_BLOCK(0, 1);
       lgkm_wait<1 + NAH>(); MFMA_BLOCK(0, 2);
       lgkm_wait<0 + NAH>(); MFMA_BLOCK(0, 3);
+      if (late) issue_dma();
+      __builtin_amdgcn_sched_barrier(0);
       constexpr int tapn = (tap + 1) % TAPS, cparn = (u + 1) / TAPS % 2, slotn = (u + 1) % WRING;
       if constexpr (NI == 2 && WPTR64) {
         // 64-channel tile (registers to spare): the last step skips its prefetch
