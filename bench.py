@@ -193,33 +193,38 @@ def train_bench(args, rank, world, device):
         raise RuntimeError(f"bench: loss {final_loss}, |weights| {wnorm} after the timed region -- the step is broken")
     note(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
 
-    # ---- roofline of the dominant kernel (3x3 implicit-GEMM conv): one extra, instrumented EAGER step AFTER the
+    # ---- roofline of the dominant kernel (3x3 implicit-GEMM conv): extra, instrumented EAGER steps AFTER the
     # timed region: HIP events around every launch on the launch stream; algorithmic FLOPs from the shapes.
-    # Every rank runs the extra step (it contains the gradient all-reduce); only rank 0 instruments it.  Kernels run
+    # Every rank runs the extra steps (they contain the gradient all-reduce); only rank 0 instruments them.  Kernels run
     # back to back on one stream (the weight-gradient side stream is off by default since round 2); when it is enabled
     # (EDM_WGRAD_STREAM=1) a second instrumented step records the per-kernel durations under that overlap too.
     from tinyedm_amd import networks as _nets
     roof = None
     roofs = {}
+    INSTR = 5          # instrumented steps per mode, behind 2 uninstrumented ones: a single step right after the
+    nstep = [args.warmup + args.steps]   # synchronisation ran the big kernels 8 % slower than their steady state (clock ramp)
     for overlapped in ((False, True) if _nets.WGRAD_STREAM else (False,)):
         saved = _nets.WGRAD_STREAM
         _nets.WGRAD_STREAM = saved and overlapped
+        for _ in range(2):
+            eager_step(nstep[0]); nstep[0] += 1
         if rank == 0:
             ops.PROFILE = {}
-        eager_step(args.warmup + args.steps + int(overlapped))
+        for _ in range(INSTR):
+            eager_step(nstep[0]); nstep[0] += 1
         torch.cuda.synchronize()
         _nets.WGRAD_STREAM = saved
         if rank == 0:
             roofs[overlapped], ops.PROFILE = ops.PROFILE, None
     if rank == 0:
         roof = {}
-        for name, recs in roofs[False].items():
-            ms = sum(s.elapsed_time(e) for s, e, _, _ in recs)
-            roof[name] = {"launches": len(recs), "ms": ms, "gflop": sum(f for _, _, f, _ in recs) / 1e9,
-                          "gbytes": sum(b for _, _, _, b in recs) / 1e9}
+        for name, recs in roofs[False].items():           # per-step figures: sums over the INSTR steps / INSTR
+            ms = sum(s.elapsed_time(e) for s, e, _, _ in recs) / INSTR
+            roof[name] = {"launches": len(recs) // INSTR, "ms": ms, "gflop": sum(f for _, _, f, _ in recs) / 1e9 / INSTR,
+                          "gbytes": sum(b for _, _, _, b in recs) / 1e9 / INSTR}
         for name, recs in roofs.get(True, {}).items():
             if name in roof:
-                roof[name]["ms_overlapped"] = sum(s.elapsed_time(e) for s, e, _, _ in recs)
+                roof[name]["ms_overlapped"] = sum(s.elapsed_time(e) for s, e, _, _ in recs) / INSTR
     return model, B * world * args.steps / dt, dt / args.steps * 1e3, final_loss, roof, launch_info
 
 
