@@ -102,6 +102,7 @@ def train_bench(args, rank, world, device):
     model.train()
     opt_cfg = model.configure_optimizers()
     base = opt_cfg["optimizer"]
+    base.fuse_zero_grad = True            # as Trainer.fit: the gradient arena is cleared by the Adam pass that reads it
     gamma = tinyedm.sigma_rel_to_gamma(model.ema_length)
     opt = EMAOptimizer(base, device=device, gamma=gamma, every_n_steps=model.every_n_steps)
     reducer = GradReducer(base.arena)

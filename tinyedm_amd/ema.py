@@ -80,7 +80,17 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_count = 0
         self.grad_scale = 1.0
 
+    # fuse_zero_grad = True: `step()` clears the gradient arena in the pass that reads it (it is the last reader) and the
+    # `zero_grad()` that follows is free -- instead of a separate 142 MB fill (Trainer.fit and bench.py switch it on;
+    # off by default because torch optimizers leave .grad intact after step()).
+    fuse_zero_grad = False
+    _cleared = False
+
     def zero_grad(self, set_to_none: bool = False):
+        if self._cleared:           # step() just cleared it; any later call (after a backward) clears for real
+            self._cleared = False
+            self.arena.rebind_grads()
+            return
         self.arena.zero_grad()
 
     @torch.no_grad()
@@ -90,7 +100,8 @@ class FusedAdam(torch.optim.Optimizer):
         self.arena.rebind_grads()
         self.step_count += 1
         ops.adam_ema(self.arena.theta, self.arena.grad, self.m, self.v, ema, g["lr"], g["betas"][0], g["betas"][1],
-                     g["eps"], self.step_count, ema_beta, self.grad_scale)
+                     g["eps"], self.step_count, ema_beta, self.grad_scale, zero_grad=self.fuse_zero_grad)
+        self._cleared = bool(self.fuse_zero_grad)
         from .networks import bump_weight_epoch
         bump_weight_epoch()
         return loss

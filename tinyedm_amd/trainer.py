@@ -153,6 +153,8 @@ class Trainer:
         opt = self.optimizers[0]
         base = opt.optimizer if isinstance(opt, EMAOptimizer) else opt
         model.train()
+        if isinstance(base, FusedAdam):
+            base.fuse_zero_grad = True        # step() is always followed by zero_grad() here
         opt.zero_grad()
         captured = None
         if (self.use_graph and self.world_size == 1 and self.accumulate_grad_batches == 1 and isinstance(base, FusedAdam)
