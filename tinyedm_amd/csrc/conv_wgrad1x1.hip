@@ -12,6 +12,7 @@
 //    one k-step ahead of the MFMAs, retired by counted lgkmcnt; all LDS addresses are register + immediate;
 //  * counted `s_waitcnt vmcnt(6)` + raw s_barrier keep the next stage in flight across the barrier.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -168,7 +169,8 @@ extern "C" int edm_conv_wgrad_1x1_nsplit(long npix, int Cin, int Cout) {
   long S = (256 + tiles - 1) / tiles;            // ~one workgroup per CU
   const long max_s = (npix + 4 * KP - 1) / (4 * KP);  // at least 4 stages per workgroup
   if (S > max_s) S = max_s;
-  if (S > 64) S = 64;  // more splits buy no kernel time (r01 sweep) but every slab is re-read by the finish pass
+  static const long max_split = [] { const char* e = getenv("EDM_W1_MAXSPLIT"); return e ? atol(e) : 64L; }();
+  if (S > max_split) S = max_split;  // more splits buy no kernel time (r01 sweep) but every slab is re-read by the finish pass
   if (S < 1) S = 1;
   return (int)S;
 }
