@@ -467,24 +467,29 @@ __global__ __launch_bounds__(256) void k_reduce_hw_det(const bf16* __restrict__ 
   const bool cok = c < C;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const long base = (long)b * HW;
-  constexpr int UN = 8;   // loads in flight per thread: the pass is latency-bound (one sample slice per workgroup)
+  constexpr int UN = 16;  // 16-byte loads in flight per thread and operand: the pass is latency-bound (one sample slice
+                          // per workgroup, two workgroups per CU), so the 32x32 slice (1024 rows) is two round trips
   for (int p0 = pl; p0 < HW; p0 += 32 * UN) {
-    float v[UN][8], u[UN][8];
+    u32x4 v[UN], u[UN];
 #pragma unroll
     for (int k = 0; k < UN; ++k) {
       const int p = p0 + 32 * k;
       const bool ok = cok && p < HW;
-      if (ok) load8(x + (base + p) * xs + c, v[k]);
-      if (ok && y) load8(y + (base + p) * ys + c, u[k]);
-      if (!ok) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[k][j] = 0.f;
-      }
+      v[k] = ok ? *reinterpret_cast<const u32x4*>(x + (base + p) * xs + c) : u32x4{0u, 0u, 0u, 0u};
+      if (y) u[k] = ok ? *reinterpret_cast<const u32x4*>(y + (base + p) * ys + c) : u32x4{0u, 0u, 0u, 0u};
     }
 #pragma unroll
-    for (int k = 0; k < UN; ++k)
+    for (int k = 0; k < UN; ++k) {
+      const bf16x8 a = __builtin_bit_cast(bf16x8, v[k]);
+      if (y) {
+        const bf16x8 b = __builtin_bit_cast(bf16x8, u[k]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += (y && cok && p0 + 32 * k < HW) ? v[k][j] * u[k][j] : v[k][j];
+        for (int j = 0; j < 8; ++j) acc[j] += (float)a[j] * (float)b[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += (float)a[j];
+      }
+    }
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) red[pl][cl * 8 + j] = acc[j];
