@@ -26,6 +26,10 @@ def main():
     ap.add_argument("--images", type=int, default=2)
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--bf16-oracle", action="store_true", help="also integrate the oracle with bf16 rounding points")
+    ap.add_argument("--no-tf32-oracle", action="store_true",
+                    help="skip the leg that rounds every convolution operand of the fp32 oracle to TF32 (10-bit mantissa): "
+                         "what cuDNN does by default for fp32 convolutions on the GPUs the reference targets "
+                         "(torch.backends.cudnn.allow_tf32 = True; generate.py does not change it)")
     a = ap.parse_args()
     import tinyedm_amd as T
     dev = torch.device("cuda", 0)
@@ -65,9 +69,23 @@ def main():
                 print(f"[sampler_parity] oracle evaluation {calls[0]} ({time.time() - t0:.0f} s)", flush=True)
             return O.edm_forward(P, ecfg, dcfg, x, t, l, bf16=bf16)
         return f
+    def tf32(t):
+        """round-to-nearest-even to a 10-bit mantissa (the TF32 operand format)"""
+        i = t.contiguous().view(torch.int32)
+        i = (i + 0x0FFF + ((i >> 13) & 1)) & ~0x1FFF
+        return i.view(torch.float32)
+
     with torch.no_grad():
         x_f32 = O.heun_solve(net(False), x0, ts, None)
         x_bf = O.heun_solve(net(True), x0, ts, None) if a.bf16_oracle else x_f32
+        x_tf = None
+        if not a.no_tf32_oracle:
+            conv = O.F.conv2d
+            O.F.conv2d = lambda x, w, *aa, **kk: conv(tf32(x.float()), tf32(w.float()), *aa, **kk)
+            try:
+                x_tf = O.heun_solve(net(False), x0, ts, None)
+            finally:
+                O.F.conv2d = conv
     cpu_s = time.time() - t0
 
     def rel(u, v):
@@ -77,6 +95,8 @@ def main():
            "hip_bf16net_vs_fp32_oracle_rel_l2": rel(x_hip, x_f32),
            "hip_bf16net_vs_bf16_oracle_rel_l2": rel(x_hip, x_bf) if a.bf16_oracle else None,
            "bf16_oracle_vs_fp32_oracle_rel_l2": rel(x_bf, x_f32) if a.bf16_oracle else None,
+           "tf32conv_oracle_vs_fp32_oracle_rel_l2": rel(x_tf, x_f32) if x_tf is not None else None,
+           "hip_bf16net_vs_tf32conv_oracle_rel_l2": rel(x_hip, x_tf) if x_tf is not None else None,
            "final_image_rms": x_f32.pow(2).mean().sqrt().item(),
            "max_abs_diff_vs_fp32": (x_hip - x_f32).abs().max().item(),
            "note": "state integrated in fp32 on both sides; only the network evaluation differs (bf16 operands, fp32 "
