@@ -55,8 +55,7 @@ int edm_conv_igemm_v3(const void* X, const void* Wp, void* Y, const void* R, flo
  * masks folded into addresses, incremental DMA pointers); -3 for shapes it does not cover (taps != 9, Cin % 64 != 0) */
 int edm_conv_igemm_v4(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
                       int W, int Cin, int Cout, int taps, edm_stream_t stream);
-/* the fourth generation on v_mfma_f32_16x16x32_bf16 (the device holds a higher clock on this MFMA shape); additionally
- * needs W % 16 == 0; -3 otherwise */
+/* the fourth generation on v_mfma_f32_16x16x32_bf16 (the device holds a higher clock on this MFMA shape); same shapes */
 int edm_conv_igemm_v6(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
                       int W, int Cin, int Cout, int taps, edm_stream_t stream);
 /* small feature maps (8x8 layers; W <= 16, Cin % 256 == 0), 3x3 only: 128x64 tile whose reduction dimension is split

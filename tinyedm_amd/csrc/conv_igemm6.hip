@@ -362,14 +362,15 @@ void launch6(const void* X, const void* Wp, void* Y, const void* R, float alpha,
 
 }  // namespace
 
-// Shapes this kernel covers: those of edm_conv_igemm_v4_ex with, in addition, W % 16 == 0 (a 16-pixel block in one image
-// row), H*W % 16 == 0 and 49 spare zero rows in the slab buffer.  Returns EDM_ERR_UNSUPPORTED (-3) otherwise.
+// Shapes this kernel covers: those of edm_conv_igemm_v4_ex with 49 spare zero rows in the slab buffer (any W <= 64: the
+// static border forms need W = 32 / 64 with images aligned to the tiles, or 16x16 images; everything else takes the
+// per-lane validity bits).  Returns EDM_ERR_UNSUPPORTED (-3) otherwise.
 int edm_conv_igemm_v6_ex(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
                          int W, int Cin, int Cout, int taps, const ModEpilogue& mod, hipStream_t st) {
   EDM_REQUIRE(X && Wp && (Y || mod.Y2), "conv_igemm_v6: null pointer");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && (long)B * H * W < (1L << 31), "conv_igemm_v6: bad B/H/W");
   EDM_REQUIRE(Cout > 0 && Cout % 8 == 0, "conv_igemm_v6: Cout %% 8 required");
-  if (taps != 9 || Cin <= 0 || Cin % 64 != 0 || Cin * 2 + 64 > ZERO_PAGE || W > 64 || W % 16 != 0) return EDM_ERR_UNSUPPORTED;
+  if (taps != 9 || Cin <= 0 || Cin % 64 != 0 || Cin * 2 + 64 > ZERO_PAGE || W > 64) return EDM_ERR_UNSUPPORTED;
   EDM_ZERO_PAGE(zero_page_, "conv_igemm_v6");
   (void)zero_page_;
   const int Npix = B * H * W;

@@ -392,7 +392,7 @@ def _igemm_entry(npix, W, Cout, taps, Cin=0):
     if IGEMM_VERSION == 4:
         return "edm_conv_igemm_v4" if (taps == 9 and Cin % 64 == 0 and Cin <= 2016) else "edm_conv_igemm_v3"
     if IGEMM_VERSION == 6:      # v4's geometry on the 16x16x32 MFMA shape
-        ok = taps == 9 and Cin % 64 == 0 and Cin <= 2016 and W % 16 == 0
+        ok = taps == 9 and Cin % 64 == 0 and Cin <= 2016 and W <= 64
         return "edm_conv_igemm_v6" if ok else "edm_conv_igemm"
     if IGEMM_VERSION == 5:
         return "edm_conv_igemm_s" if (taps == 9 and Cin % 256 == 0 and Cin <= 2016 and W <= 16) else "edm_conv_igemm"
