@@ -225,14 +225,17 @@ int edm_diffuse_given(const float* clean, const float* eps, const float* noise, 
 int edm_weighted_mse(const float* D, const float* clean, const float* sigma, const float* weight_override,
                      float sigma_data, float* loss, float* dD, int B, long CHW, float* acc_sum, long long* acc_total,
                      edm_stream_t stream);
-/* zero_grad != 0: the gradient arena is cleared in the same pass (optimizer.zero_grad()) */
+/* zero_grad != 0: the gradient arena is cleared in the same pass (optimizer.zero_grad()).
+ * health (nullable device word, sticky): bit 0 is OR-ed in when a non-finite gradient / updated weight passed through
+ * the step, bit 1 (Heun updates) when the sampler state went non-finite -- the sentinel a replayed hipGraph leaves for
+ * the host (Trainer.fit reads it at its log interval, the solver after a solve) so a corrupted replay fails loudly. */
 int edm_adam_ema(float* theta, float* grad, float* m, float* v, float* ema, long n, float lr, float b1, float b2,
                  float eps, int step, float ema_beta, float grad_scale, const void* dyn, int zero_grad,
-                 edm_stream_t stream);
-int edm_heun_euler(const float* x, const float* D, float t0, float t1, float* dx, float* x1, long n,
+                 unsigned* health, edm_stream_t stream);
+int edm_heun_euler(const float* x, const float* D, float t0, float t1, float* dx, float* x1, long n, unsigned* health,
                    edm_stream_t stream);
 int edm_heun_correct(const float* x, const float* dx, const float* x1, const float* D1, float t0, float t1, float* out,
-                     long n, edm_stream_t stream);
+                     long n, unsigned* health, edm_stream_t stream);
 int edm_scale_f32(const float* x, float s, float* y, long n, edm_stream_t stream);
 
 /* ---------------------------------------------------------------- data formats either side of the path */

@@ -2,7 +2,7 @@
 
 Replays the captured CIFAR-10 training step with finite-ness probes recorded INSIDE the graph, with a device
 synchronisation between replays.  On ROCm 7.2 with the runtime's default AQL-packet-capture path the first replay
-after the synchronisation runs nodes with clobbered kernel arguments (this very sequence fails every time);
+after the synchronisation ran nodes with clobbered kernel arguments;
 tinyedm_amd/_runtime_env.py switches that path off at import.  Prints `CLEAN <n>` or `CORRUPT <row>`."""
 import os
 import sys

@@ -1,5 +1,6 @@
 """Collects the parity error every GPU test measured (test -> worst rel-L2, its limit) so the margins are visible:
-written at session end to gpurun_out/parity_r02.json (copied into profiles/ for the record)."""
+written at session end to gpurun_out/parity_r03.json (copied into profiles/ for the record).  EDM_PARITY_LOG=0 (child
+pytest processes that re-run a subset under another kernel selection) keeps a session from writing."""
 import json
 import os
 
@@ -14,12 +15,12 @@ def record(name: str, err: float, limit: float) -> None:
 
 
 def dump() -> None:
-    if not _records:
+    if not _records or os.environ.get("EDM_PARITY_LOG") == "0":
         return
     out_dir = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out_dir, exist_ok=True)
-        path = os.path.join(out_dir, "parity_r02.json")
+        path = os.path.join(out_dir, "parity_r03.json")
         old = {}
         if os.path.exists(path):
             with open(path) as f:

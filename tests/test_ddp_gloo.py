@@ -123,3 +123,51 @@ def test_bf16_gradient_transport_is_equivalent_to_fp32_up_to_bf16_rounding():
     rel = ((b0 - f0).norm() / f0.norm()).item()
     assert 0 < rel <= 2 ** -7, rel
     assert (b0 - f0).abs().max() <= 2 ** -6 * f0.abs().max()
+
+
+# ---------------------------------------------------------------------------------------------- per-rank RNG across a resume
+def _worker_resume(rank, world, port, q, ckpt):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from tinyedm_amd import networks
+    from tinyedm_amd.trainer import Trainer
+    networks.manual_seed(42)
+    model = _model()
+    model.hparams = {}
+    tr = Trainer(max_epochs=1)
+    tr._setup_distributed(model)                 # gloo group + per-rank Philox offset
+    seed_fresh = networks.rng.seed
+    tr._model = model
+    networks.rng.step = 17
+    tr.save_checkpoint(ckpt, model)              # rank 0 writes; every rank would write the same base seed
+    dist.barrier()
+    # ---- a new run resumes: same launch sequence as Trainer.fit (setup, then load_checkpoint)
+    networks.manual_seed(42)
+    tr2 = Trainer(max_epochs=1)
+    tr2._setup_distributed(model)
+    tr2.load_checkpoint(ckpt, model)
+    q.put((rank, seed_fresh, networks.rng.seed, networks.rng.step))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_keep_distinct_philox_seeds_across_a_resume(tmp_path):
+    """Trainer._setup_distributed offsets every rank's Philox seed; the checkpoint stores the BASE seed and
+    load_checkpoint re-applies the rank offset -- after fit(ckpt_path=...) the ranks must still differ (and each rank
+    must continue ITS OWN stream: same seed as before the checkpoint, same step)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ckpt = str(tmp_path / "resume.ckpt")
+    procs = [ctx.Process(target=_worker_resume, args=(r, world, port, q, ckpt)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=60) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, fresh0, resumed0, step0), (_, fresh1, resumed1, step1) = res
+    assert fresh0 != fresh1 and resumed0 != resumed1
+    assert resumed0 == fresh0 and resumed1 == fresh1
+    assert step0 == step1 == 17
+    assert torch.load(ckpt, weights_only=False)["tinyedm_amd"]["rng_seed"] == 42

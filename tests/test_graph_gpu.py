@@ -110,8 +110,10 @@ def test_replays_draw_fresh_noise():
 
 def test_replay_after_stream_sync_is_not_corrupted():
     """ROCm 7.2 runtime bug (tinyedm_amd/_runtime_env.py): the first hipGraph replay after a stream / device
-    synchronisation ran with clobbered kernel arguments.  tests/graph_sync_probe.py is the sequence that failed every
-    time; it runs in its own process so that the flag is set by the package import alone."""
+    synchronisation ran with clobbered kernel arguments under the runtime's default packet-capture path.
+    tests/graph_sync_probe.py replays across synchronisations with in-graph probes; it runs in its own process so that
+    the safe setting is the one the package import alone puts in place.  Only the safe setting is ever exercised: the
+    failing configuration launches kernels with garbage pointers and is never provoked on purpose."""
     import os
     import subprocess
     import sys
@@ -123,12 +125,6 @@ def test_replay_after_stream_sync_is_not_corrupted():
     last = out.stdout.strip().splitlines()[-1]
     record("graph/replay_after_sync_clean", 0.0 if last.startswith("CLEAN") else 1.0, 0.0)
     assert last.startswith("CLEAN"), last
-    # informational: the same sequence with the runtime's default path (documents whether the bug is still there)
-    env["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "1"
-    out = subprocess.run([sys.executable, os.path.join(here, "graph_sync_probe.py")], env=env, capture_output=True,
-                         text=True, timeout=300)
-    lines = out.stdout.strip().splitlines()
-    print("default runtime path:", lines[-1][:200] if lines else out.stderr[-300:])
 
 
 def test_graph_paths_refuse_when_the_runtime_flag_is_unsafe(monkeypatch):
@@ -136,3 +132,82 @@ def test_graph_paths_refuse_when_the_runtime_flag_is_unsafe(monkeypatch):
     monkeypatch.setattr(_runtime_env, "GRAPH_REPLAY_SAFE", False)
     with pytest.raises(RuntimeError, match="hipGraph replay is unsafe"):
         _runtime_env.require_graph_replay_safe("test")
+
+
+def test_package_import_before_gpu_init_is_graph_safe_and_late_import_is_not():
+    """fail-closed witness (_runtime_env.hip_runtime_live): importing the package before the first HIP call reports
+    safe; after the runtime is up (torch.cuda.is_available() initialises it WITHOUT setting torch's lazy-init flag) an
+    import without the inherited variable must report unsafe"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+    early = "import sys; sys.path.insert(0, %r); import torch, tinyedm_amd; print(tinyedm_amd._runtime_env.GRAPH_REPLAY_SAFE)" % root
+    late = ("import sys; sys.path.insert(0, %r); import torch; torch.cuda.is_available(); torch.zeros(1, device='cuda'); "
+            "import tinyedm_amd; print(tinyedm_amd._runtime_env.GRAPH_REPLAY_SAFE)" % root)
+    out_e = subprocess.run([sys.executable, "-c", early], env=env, capture_output=True, text=True, timeout=300)
+    out_l = subprocess.run([sys.executable, "-c", late], env=env, capture_output=True, text=True, timeout=300)
+    assert out_e.stdout.strip().splitlines()[-1] == "True", out_e.stderr[-1000:]
+    assert out_l.stdout.strip().splitlines()[-1] == "False", out_l.stderr[-1000:]
+    env["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"         # inherited safe value: safe however late the import is
+    out_i = subprocess.run([sys.executable, "-c", late], env=env, capture_output=True, text=True, timeout=300)
+    assert out_i.stdout.strip().splitlines()[-1] == "True", out_i.stderr[-1000:]
+
+
+def test_health_sentinel_trips_on_a_poisoned_replay():
+    """a NaN fed into the REPLAYED step (what a replay with corrupted arguments amounts to) leaves the in-graph sentinel
+    bit behind and the host read point raises; a clean replay does not"""
+    from tinyedm_amd import ops
+    from tinyedm_amd.graph import CapturedTrainStep
+    g = torch.Generator().manual_seed(2)
+    b = ((0.5 * torch.randn(8, 3, 16, 16, generator=g)).to(DEV), torch.randint(0, 10, (8,), generator=g).to(DEV))
+    model, _ = _build(seed=4)
+    opt, base, _ = _opt(model)
+    for pg in base.param_groups:
+        pg["lr"] = 0.0
+    opt.zero_grad()
+    step = CapturedTrainStep(model, opt)
+    for _ in range(CapturedTrainStep.WARMUP + 2):
+        step(b)
+    ops.check_health(DEV, "clean replays")                  # does not raise
+    bad = (b[0].clone(), b[1])
+    bad[0][3, 1, 5, 5] = float("nan")
+    theta = base.arena.theta.clone()
+    step(bad)                                               # replay of the SAME graph with a poisoned input
+    with pytest.raises(ops.GraphCorruptionError, match="non-finite gradient"):
+        ops.check_health(DEV, "poisoned replay")
+    ops.check_health(DEV, "cleared")                        # the word is cleared by the failed check
+    base.arena.theta.copy_(theta)                           # (the poisoned step wrote NaN weights; put them back)
+
+
+def test_trainer_fit_raises_on_nonfinite_step(tmp_path):
+    """Trainer.fit reads the sentinel at its log interval: a batch with a NaN makes fit() raise instead of training on"""
+    import tinyedm_amd as T
+    from tinyedm_amd import ops
+    model, _ = _build(seed=6)
+    g = torch.Generator().manual_seed(8)
+    xs = 0.5 * torch.randn(4, 8, 3, 16, 16, generator=g)
+    xs[2, 0, 0, 0, 0] = float("nan")
+    loader = [(xs[i], torch.randint(0, 10, (8,), generator=g)) for i in range(4)]
+    tr = T.Trainer(max_epochs=1, log_every_n_steps=1)
+    with pytest.raises(ops.GraphCorruptionError):
+        tr.fit(model, train_dataloaders=loader)
+    ops.health(DEV).zero_()
+
+
+def test_sampler_sentinel_trips_on_nonfinite_state():
+    import tinyedm_amd as T
+    from tinyedm_amd import ops
+    model, _ = _build(seed=5)
+    model.eval()
+    solver = T.DeterministicSolver(num_steps=4)
+    g = torch.Generator().manual_seed(1)
+    x0 = torch.randn(4, 3, 16, 16, generator=g).to(DEV)
+    lab = torch.randint(0, 10, (4,), generator=g).to(DEV)
+    out = solver.solve(model, x0, lab, graph=True)
+    assert torch.isfinite(out).all()
+    x0b = x0.clone()
+    x0b[1, 0, 2, 2] = float("inf")
+    with pytest.raises(ops.GraphCorruptionError, match="non-finite sampler state"):
+        solver.solve(model, x0b, lab, graph=True)

@@ -247,7 +247,8 @@ def test_conv_wgrad_1x1_ragged(ops, B, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,pdrop", [(2, 8, 8, 64, 128, 0.0), (3, 16, 16, 128, 64, 0.25), (1, 5, 7, 64, 72, 0.1),
-                                                   (128, 32, 32, 256, 256, 0.13)])
+                                                   (128, 32, 32, 256, 256, 0.13),
+                                                   (512, 8, 8, 64, 256, 0.1)])    # W = 8 through k_conv3x3_v6's validity-bit path
 def test_conv3x3_mod_epilogue_is_bit_identical_to_separate_kernels(ops, B, H, W, Cin, Cout, pdrop):
     """Fused modulation epilogue (edm_conv3x3_mod) == conv_igemm followed by mod_silu_drop_fwd, bit for bit (same bf16
     rounding of u, same Philox counters), on a small-tile shape, ragged shapes and the full-size 32x32 layer (v4)."""
@@ -268,7 +269,8 @@ def test_conv3x3_mod_epilogue_is_bit_identical_to_separate_kernels(ops, B, H, W,
 
 
 @pytest.mark.parametrize("B,H,W,C1,C2,pdrop", [(2, 8, 8, 64, 128, 0.0), (3, 16, 16, 128, 64, 0.25), (2, 4, 8, 64, 72, 0.1),
-                                                 (128, 32, 32, 256, 256, 0.13)])
+                                                 (128, 32, 32, 256, 256, 0.13),
+                                                 (512, 8, 8, 64, 256, 0.1)])      # W = 8 through k_conv3x3_v6 (validity bits)
 def test_conv3x3_modbwd_epilogue_matches_separate_kernels(ops, B, H, W, C1, C2, pdrop):
     """Fused modulation backward (edm_conv3x3_modbwd + edm_mod_finish) == conv_igemm (dgrad) then mod_silu_drop_bwd:
     gr bit for bit, glin / ggain up to fp32 summation order (both paths accumulate with atomics)."""
@@ -297,6 +299,23 @@ def test_conv3x3_silubwd_epilogue_is_bit_identical(ops, B, H, W, C1, C2, with_ex
     ref = ops.silu_bwd(xpre, ops.conv_igemm(gr, wd, 9), extra, 0.7)
     got = ops.conv3x3_silubwd(gr, wd, xpre, extra, 0.7)
     assert torch.equal(got, ref)
+
+
+def test_v4_32x32x16_fallback_is_covered():
+    """EDM_V4_MFMA16=0 keeps k_conv3x3_v4 on v_mfma_f32_32x32x16_bf16 (the documented fallback of k_conv3x3_v6).  The C
+    side reads the variable once per process, so the forced-v4 parity cases of this file run again in ONE child process
+    with it set (forward on every shape, the residual epilogue, and the three fused epilogues)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, EDM_V4_MFMA16="0", EDM_PARITY_LOG="0")
+    sel = ("(test_conv_igemm_forward and igemm-v4) or (test_conv_igemm_residual_epilogue and igemm-v4) or "
+           "test_conv3x3_mod_epilogue or test_conv3x3_modbwd_epilogue or test_conv3x3_silubwd_epilogue")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_kernels_gpu.py"), "-x", "-q", "-m", "gpu",
+                          "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout, out.stdout[-500:]
 
 
 def test_weight_prep_padding_and_perm(ops):

@@ -73,9 +73,9 @@ SIGNATURES = {
     "edm_diffuse": [P, P, P, F, F, I, L, U64, U, P, P],
     "edm_diffuse_given": [P, P, P, P, P, F, F, I, L, P],
     "edm_weighted_mse": [P, P, P, P, F, P, P, I, L, P, P, P],
-    "edm_adam_ema": [P, P, P, P, P, L, F, F, F, F, I, F, F, P, I, P],
-    "edm_heun_euler": [P, P, F, F, P, P, L, P],
-    "edm_heun_correct": [P, P, P, P, F, F, P, L, P],
+    "edm_adam_ema": [P, P, P, P, P, L, F, F, F, F, I, F, F, P, I, P, P],
+    "edm_heun_euler": [P, P, F, F, P, P, L, P, P],
+    "edm_heun_correct": [P, P, P, P, F, F, P, L, P, P],
     "edm_scale_f32": [P, F, P, L, P],
     # weights.hip
     "edm_weight_prep": [P, I, I, I, I, P, P, P, P, I, P],

@@ -289,10 +289,10 @@ void launch4(const void* X, const void* Wp, void* Y, const void* R, float alpha,
   auto kern = k_conv3x3_v4<NX, EPI, NI, ABL, NJ>;
   // wave stagger (see the kernel): measured null on this kernel (+-1 % in A/B runs on one device), off by default
   static const int stagger = [] { const char* e = getenv("EDM_V4_STAGGER"); return e ? atoi(e) : 0; }();
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<bool> attr_set{false};  // (idempotent call: a race only repeats it)
+  if (!attr_set.load(std::memory_order_acquire)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    attr_set.store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const bf16*)X, (const bf16*)Wp, (bf16*)Y, (const bf16*)R,
                      (const char*)edm_zero_page(), alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n, stagger, mod);

@@ -187,10 +187,10 @@ extern "C" int edm_conv_wgrad_1x1(const void* X, const void* dY, float* slabs, l
   long L = (npix + nsplit - 1) / nsplit;
   L = (L + KP - 1) / KP * KP;
   const int tiles_co = (Cout + TCO - 1) / TCO, tiles_ci = (Cin + TCI - 1) / TCI;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<bool> attr_set{false};  // (idempotent call: a race only repeats it)
+  if (!attr_set.load(std::memory_order_acquire)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad1x1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    attr_set.store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL(k_wgrad1x1, dim3(tiles_co * tiles_ci, nsplit), dim3(512), (size_t)RING * STAGE, st, (const bf16*)X,
                      (const bf16*)dY, slabs, (const bf16*)edm_zero_page(), npix, Cin, Cout, tiles_ci, L);

@@ -629,7 +629,7 @@ extern "C" int edm_wgrad3_group(const edm_wgrad3_item* items, int n, void* works
   P.wg.work = (float*)workspace;
   P.wg.zeros = zeros;
   P.fg.work = (const float*)workspace;
-  static bool set1 = false, set2 = false, setf = false;
+  static std::atomic<bool> set1{false}, set2{false}, setf{false};   // (idempotent calls: a race only repeats them)
   static const int abl = [] { const char* e = getenv("EDM_W3_ABLATE"); return e ? atoi(e) : 0; }();   // tools only
   if (P.leads == 1 && abl) {
     auto go = [&](auto kern) {
@@ -655,14 +655,14 @@ extern "C" int edm_wgrad3_group(const edm_wgrad3_item* items, int n, void* works
     // training step gains 0.03 ms -- the kernel waits on its LDS-DMA issue, not on the matrix pipe); EDM_W3_MFMA16=0 keeps
     // v_mfma_f32_32x32x16_bf16
     static const int mf16 = [] { const char* e = getenv("EDM_W3_MFMA16"); return e ? atoi(e) : 1; }();
-    auto go = [&](auto kern, size_t lds, bool& once) {
+    auto go = [&](auto kern, size_t lds, std::atomic<bool>& once) {
       if (!once) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         once = true;
       }
       hipLaunchKernelGGL(kern, dim3(P.wg.nwg), dim3(256), lds, st, P.wg);
     };
-    static bool set1m = false, set2m = false;
+    static std::atomic<bool> set1m{false}, set2m{false};
     if (P.leads == 1) { if (mf16) go(k_wgrad3<1, 0, true>, Ring<1>::LDS, set1m); else go(k_wgrad3<1>, Ring<1>::LDS, set1); }
     else { if (mf16) go(k_wgrad3<2, 0, true>, Ring<2>::LDS, set2m); else go(k_wgrad3<2>, Ring<2>::LDS, set2); }
   }

@@ -98,9 +98,10 @@ struct AdamArgs {
 // zero_grad: the gradient arena is cleared in the same pass (saves the separate fill of optimizer.zero_grad()).
 __global__ void k_adam_ema(float* __restrict__ theta, float* __restrict__ grad, float* __restrict__ m,
                            float* __restrict__ v, float* __restrict__ ema, long n4, long n, AdamArgs a,
-                           const StepParams* __restrict__ dyn, int zero_grad) {
+                           const StepParams* __restrict__ dyn, int zero_grad, unsigned* __restrict__ health) {
   if (dyn) { a.lr = dyn->lr; a.ema_beta = dyn->ema_beta; a.grad_scale = dyn->grad_scale; a.bc1 = dyn->bc1; a.bc2sqrt = dyn->bc2sqrt; }
   const float step_size = a.lr / a.bc1;
+  bool bad = false;     // health word (nullable): bit 0 = a non-finite gradient or weight passed through this step
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     if (i * 4 + 3 < n) {
       f32x4 t = *reinterpret_cast<f32x4*>(theta + i * 4);
@@ -117,6 +118,7 @@ __global__ void k_adam_ema(float* __restrict__ theta, float* __restrict__ grad, 
         vv[j] = a.b2 * vv[j] + (1.f - a.b2) * gj * gj;
         t[j] -= step_size * mm[j] / (sqrtf(vv[j]) / a.bc2sqrt + a.eps);
         if (ema) ee[j] = a.ema_beta * ee[j] + (1.f - a.ema_beta) * t[j];
+        bad |= !(fabsf(gj) <= 3.0e38f) || !(fabsf(t[j]) <= 3.0e38f);
       }
       *reinterpret_cast<f32x4*>(theta + i * 4) = t;
       *reinterpret_cast<f32x4*>(m + i * 4) = mm;
@@ -133,27 +135,38 @@ __global__ void k_adam_ema(float* __restrict__ theta, float* __restrict__ grad, 
         theta[e] = tj;
         if (zero_grad) grad[e] = 0.f;
         if (ema) ema[e] = a.ema_beta * ema[e] + (1.f - a.ema_beta) * tj;
+        bad |= !(fabsf(gj) <= 3.0e38f) || !(fabsf(tj) <= 3.0e38f);
       }
     }
   }
+  if (health && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(health, 1u);
 }
 
 // dx = (x-D)/t0 ; x1 = x + (t1-t0)*dx
 __global__ void k_heun_euler(const float* __restrict__ x, const float* __restrict__ Dn, float t0, float t1,
-                             float* __restrict__ dx, float* __restrict__ x1, long n) {
+                             float* __restrict__ dx, float* __restrict__ x1, long n, unsigned* __restrict__ health) {
+  bool bad = false;     // health word (nullable): bit 1 = a non-finite sampler state
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float d = (x[i] - Dn[i]) / t0;
     dx[i] = d;
-    x1[i] = x[i] + (t1 - t0) * d;
+    const float o = x[i] + (t1 - t0) * d;
+    x1[i] = o;
+    bad |= !(fabsf(o) <= 3.0e38f);
   }
+  if (health && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(health, 2u);
 }
 // dxp = (x1-D1)/t1 ; out = x + (t1-t0)*(0.5*dx + 0.5*dxp)
 __global__ void k_heun_correct(const float* __restrict__ x, const float* __restrict__ dx, const float* __restrict__ x1,
-                               const float* __restrict__ D1, float t0, float t1, float* __restrict__ out, long n) {
+                               const float* __restrict__ D1, float t0, float t1, float* __restrict__ out, long n,
+                               unsigned* __restrict__ health) {
+  bool bad = false;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float dp = (x1[i] - D1[i]) / t1;
-    out[i] = x[i] + (t1 - t0) * (0.5f * dx[i] + 0.5f * dp);
+    const float o = x[i] + (t1 - t0) * (0.5f * dx[i] + 0.5f * dp);
+    out[i] = o;
+    bad |= !(fabsf(o) <= 3.0e38f);
   }
+  if (health && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(health, 2u);
 }
 __global__ void k_scale_f32(const float* __restrict__ x, float s, float* __restrict__ y, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = x[i] * s;
@@ -198,10 +211,12 @@ extern "C" int edm_weighted_mse(const float* D, const float* clean, const float*
   return EDM_OK;
 }
 // step is 1-based (bias corrections use it); ema may be null.  dyn (nullable, device edm_step_params) overrides lr,
-// ema_beta, grad_scale and the two bias corrections; zero_grad != 0 clears `grad` in the same pass.
+// ema_beta, grad_scale and the two bias corrections; zero_grad != 0 clears `grad` in the same pass.  health (nullable
+// device word): bit 0 is OR-ed in when a non-finite gradient or updated weight was seen -- the in-graph sentinel a
+// replayed step leaves behind for the host to read at its log interval.
 extern "C" int edm_adam_ema(float* theta, float* grad, float* m, float* v, float* ema, long n, float lr, float b1,
                             float b2, float eps, int step, float ema_beta, float grad_scale, const void* dyn,
-                            int zero_grad, hipStream_t st) {
+                            int zero_grad, unsigned* health, hipStream_t st) {
   EDM_REQUIRE(theta && grad && m && v && n > 0 && step >= 1, "adam_ema: bad args");
   EDM_REQUIRE(((uintptr_t)theta % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
                   ((uintptr_t)v % 16 == 0) && (!ema || (uintptr_t)ema % 16 == 0),
@@ -214,21 +229,22 @@ extern "C" int edm_adam_ema(float* theta, float* grad, float* m, float* v, float
   a.grad_scale = grad_scale;
   const long n4 = (n + 3) / 4;
   hipLaunchKernelGGL(k_adam_ema, dim3(grid_for(n4, 256)), dim3(256), 0, st, theta, grad, m, v, ema, n4, n, a,
-                     (const StepParams*)dyn, zero_grad);
+                     (const StepParams*)dyn, zero_grad, health);
   EDM_CHECK_LAUNCH("adam_ema");
   return EDM_OK;
 }
+// health (nullable device word): bit 1 is OR-ed in when the new state holds a non-finite value
 extern "C" int edm_heun_euler(const float* x, const float* D, float t0, float t1, float* dx, float* x1, long n,
-                              hipStream_t st) {
+                              unsigned* health, hipStream_t st) {
   EDM_REQUIRE(x && D && dx && x1 && n > 0 && t0 != 0.f, "heun_euler: bad args");
-  hipLaunchKernelGGL(k_heun_euler, dim3(grid_for(n, 256)), dim3(256), 0, st, x, D, t0, t1, dx, x1, n);
+  hipLaunchKernelGGL(k_heun_euler, dim3(grid_for(n, 256)), dim3(256), 0, st, x, D, t0, t1, dx, x1, n, health);
   EDM_CHECK_LAUNCH("heun_euler");
   return EDM_OK;
 }
 extern "C" int edm_heun_correct(const float* x, const float* dx, const float* x1, const float* D1, float t0, float t1,
-                                float* out, long n, hipStream_t st) {
+                                float* out, long n, unsigned* health, hipStream_t st) {
   EDM_REQUIRE(x && dx && x1 && D1 && out && n > 0 && t1 != 0.f, "heun_correct: bad args");
-  hipLaunchKernelGGL(k_heun_correct, dim3(grid_for(n, 256)), dim3(256), 0, st, x, dx, x1, D1, t0, t1, out, n);
+  hipLaunchKernelGGL(k_heun_correct, dim3(grid_for(n, 256)), dim3(256), 0, st, x, dx, x1, D1, t0, t1, out, n, health);
   EDM_CHECK_LAUNCH("heun_correct");
   return EDM_OK;
 }

@@ -6,6 +6,9 @@
 // call (a cold call under stream capture used to hipMalloc) -- and is looked up per device, under a mutex.
 #include "common.h"
 #include <cstdlib>
+#include <dirent.h>
+#include <unistd.h>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 
@@ -19,18 +22,43 @@ std::mutex g_mu;
 // hipGraph replay on ROCm 7.2: with the runtime's default AQL-packet-capture path the first replay after a
 // hipStreamSynchronize / hipDeviceSynchronize runs graph nodes with clobbered kernel arguments (measured round 2,
 // tools/nan_hunt.py; see tinyedm_amd/_runtime_env.py).  The runtime reads DEBUG_CLR_GRAPH_PACKET_CAPTURE at its
-// initialisation, so the library's load-time constructor sets it to 0 when the host has not chosen a value: a host
-// that loads libtinyedm_hip.so before its first HIP call (and captures these entry points into graphs) is covered.
+// initialisation, so the library's load-time constructor sets it to 0 when the host has not chosen a value -- and
+// records whether that can still have taken effect: FAIL CLOSED, the answer is yes only when the variable was already
+// "0" when the library was loaded, or the process had not initialised the HIP runtime yet (it did not hold /dev/kfd
+// open: runtime initialisation opens it).
 namespace {
-__attribute__((constructor)) void edm_runtime_ctor() { (void)setenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0", /*overwrite=*/0); }
+int g_graph_safe = 0;
+bool kfd_open() {
+  DIR* d = opendir("/proc/self/fd");
+  if (!d) return true;  // cannot tell: assume the runtime is live
+  bool live = false;
+  char path[64], target[64];
+  while (struct dirent* e = readdir(d)) {
+    if (e->d_name[0] == '.') continue;
+    snprintf(path, sizeof path, "/proc/self/fd/%s", e->d_name);
+    const ssize_t n = readlink(path, target, sizeof target - 1);
+    if (n > 0) {
+      target[n] = 0;
+      if (strcmp(target, "/dev/kfd") == 0) { live = true; break; }
+    }
+  }
+  closedir(d);
+  return live;
+}
+__attribute__((constructor)) void edm_runtime_ctor() {
+  const char* e = getenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE");
+  if (e) {
+    g_graph_safe = strcmp(e, "0") == 0;
+  } else if (!kfd_open()) {
+    (void)setenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0", /*overwrite=*/0);
+    g_graph_safe = 1;
+  }
+}
 }  // namespace
 
-// 1 when the environment holds the graph-safe runtime setting (it takes effect only if it was in place before the
-// first HIP call of the process), 0 otherwise.
-extern "C" int edm_graph_replay_safe(void) {
-  const char* e = getenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE");
-  return e && strcmp(e, "0") == 0;
-}
+// 1 when the graph-safe runtime setting was in place before the HIP runtime initialised (as far as the library can
+// witness: see the constructor above), 0 otherwise.
+extern "C" int edm_graph_replay_safe(void) { return g_graph_safe; }
 
 // Allocate the device-side constants of `device` (idempotent, thread-safe).  Must be called once per device before
 // the first kernel entry point, outside any stream capture; tinyedm_amd._lib does so when it binds the library.

@@ -87,10 +87,14 @@ class FusedAdam(torch.optim.Optimizer):
     _cleared = False
 
     def zero_grad(self, set_to_none: bool = False):
-        if self._cleared:           # step() just cleared it; any later call (after a backward) clears for real
+        # step() cleared the arena itself (fuse_zero_grad) and nothing has been written into it since: free.  "Since"
+        # is tracked by the Denoiser forward (networks.note_backward_pending, via reset_backward_state), the one place
+        # every gradient-producing pass goes through -- a step(); backward(); zero_grad() sequence clears for real.
+        if self._cleared and not _grads_written_since_clear(self):
             self._cleared = False
             self.arena.rebind_grads()
             return
+        self._cleared = False
         self.arena.zero_grad()
 
     @torch.no_grad()
@@ -102,8 +106,9 @@ class FusedAdam(torch.optim.Optimizer):
         ops.adam_ema(self.arena.theta, self.arena.grad, self.m, self.v, ema, g["lr"], g["betas"][0], g["betas"][1],
                      g["eps"], self.step_count, ema_beta, self.grad_scale, zero_grad=self.fuse_zero_grad)
         self._cleared = bool(self.fuse_zero_grad)
-        from .networks import bump_weight_epoch
-        bump_weight_epoch()
+        from . import networks
+        self._fwd_epoch_at_clear = networks.FORWARD_EPOCH
+        networks.bump_weight_epoch()
         return loss
 
     @torch.no_grad()
@@ -146,6 +151,12 @@ class FusedAdam(torch.optim.Optimizer):
             raise KeyError("optimizer state dict has neither this build's {m, v, step} nor torch Adam's {state, param_groups}")
         for g, s in zip(self.param_groups, sd["param_groups"]):
             g.update({k: v for k, v in s.items() if k != "params"})
+
+
+def _grads_written_since_clear(opt: "FusedAdam") -> bool:
+    """a training-mode network forward (the start of every gradient-producing pass) ran after the clearing step()"""
+    from . import networks
+    return networks.FORWARD_EPOCH != getattr(opt, "_fwd_epoch_at_clear", -1)
 
 
 class EMAOptimizer:

@@ -52,6 +52,9 @@ def manual_seed(seed: int) -> None:
 _WEIGHT_EPOCH = 0
 
 
+FORWARD_EPOCH = 0       # training-mode Denoiser forwards so far (FusedAdam.zero_grad: "was a gradient written since step()?")
+
+
 def bump_weight_epoch() -> None:
     """Called by anything that rewrites parameters through raw pointers (the fused optimizer)."""
     global _WEIGHT_EPOCH
@@ -1101,6 +1104,9 @@ class Denoiser(nn.Module):
         if not noisy_image.is_cuda:
             raise RuntimeError("tinyedm_amd.Denoiser: inputs must be GPU tensors (there is no CPU path)")
         reset_backward_state()
+        if self.training and torch.is_grad_enabled():
+            global FORWARD_EPOCH
+            FORWARD_EPOCH += 1
         with torch.no_grad():
             self._prep_all()
         noisy = noisy_image.float().contiguous()

@@ -105,6 +105,38 @@ def capture_begin():
 capture_end = capture_begin
 
 
+class GraphCorruptionError(RuntimeError):
+    """raised by check_health(): a training step or a sampler solve produced non-finite values"""
+
+
+_HEALTH = {}
+
+
+def health(device):
+    """Per-device sticky 32-bit health word.  The optimizer kernel ORs bit 0 into it when a non-finite gradient or
+    weight passes through a step, the Heun update kernels bit 1 when the sampler state goes non-finite.  It is the
+    in-graph sentinel of the hipGraph paths: a replay that ran with corrupted kernel arguments (tinyedm_amd/_runtime_env.py)
+    leaves the bit behind, and check_health() turns it into an exception at the next host read point."""
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    h = _HEALTH.get(idx)
+    if h is None:
+        h = _HEALTH[idx] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
+    return h
+
+
+def check_health(device, what: str):
+    """Read (one host sync) and clear the health word of `device`; raise GraphCorruptionError if a bit is set."""
+    h = health(device)
+    v = int(h.item())
+    if v:
+        h.zero_()
+        bits = [n for b, n in ((1, "non-finite gradient/weight in an optimizer step"), (2, "non-finite sampler state")) if v & b]
+        raise GraphCorruptionError(f"{what}: {' and '.join(bits)} (health word {v:#x}).  The values computed on the GPU are "
+                                   "garbage: a diverged run, NaN inputs, or a corrupted hipGraph replay "
+                                   "(see tinyedm_amd/_runtime_env.py); nothing after this point can be trusted")
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -414,13 +446,19 @@ def _igemm_entry(npix, W, Cout, taps, Cin=0):
     return "edm_conv_igemm_v2" if tiles2 >= 1024 else "edm_conv_igemm"
 
 
+# the static-schedule 3x3 kernel runs on v_mfma_f32_16x16x32_bf16 (k_conv3x3_v6) unless EDM_V4_MFMA16=0 selects the
+# 32x32x16 form (k_conv3x3_v4); the C side reads the same variable (csrc/conv_igemm4.hip)
+V46 = "_v6" if os.environ.get("EDM_V4_MFMA16", "1") != "0" else "_v4"
+
+
 def _v4_suffix(entry, npix, Cout):
-    """profile-key suffix naming the kernel instantiation: _v4 = 512x128 tiles, _v4s = 512x64 tiles (small maps)"""
+    """profile-key suffix naming the kernel that runs: _v6 / _v4 = k_conv3x3_v6 / _v4 with 512x128 tiles, _v6s / _v4s =
+    the same kernel with 512x64 tiles (16x16 layers), _s = k_conv3x3_s (8x8 layers)"""
     if entry == "edm_conv_igemm_s":
         return "_s"
     if entry != "edm_conv_igemm_v4":
         return entry[len("edm_conv_igemm"):]
-    return "_v4" if ((npix + 511) // 512) * ((Cout + 127) // 128) >= 512 else "_v4s"
+    return V46 if ((npix + 511) // 512) * ((Cout + 127) // 128) >= 512 else V46 + "s"
 
 
 def conv_igemm(x, wp, taps, residual=None, alpha=1.0, beta=0.0):
@@ -817,21 +855,24 @@ def adam_ema(theta, grad, m, v, ema, lr, b1, b2, eps, step, ema_beta, grad_scale
     if ema is not None:
         _chk(ema, f32, "ema")
     _lib.call("edm_adam_ema", _p(theta), _p(grad), _p(m), _p(v), _p(ema), theta.numel(), float(lr), float(b1), float(b2),
-              float(eps), int(step), float(ema_beta), float(grad_scale), _dyn(dyn), int(bool(zero_grad)), _stream())
+              float(eps), int(step), float(ema_beta), float(grad_scale), _dyn(dyn), int(bool(zero_grad)),
+              _p(health(theta.device)), _stream())
 
 
 def heun_euler(x, D, t0, t1):
     _chk(x, f32, "x")
     _chk(D, f32, "D", x.shape)
     dx, x1 = torch.empty_like(x), torch.empty_like(x)
-    _lib.call("edm_heun_euler", _p(x), _p(D), float(t0), float(t1), _p(dx), _p(x1), x.numel(), _stream())
+    _lib.call("edm_heun_euler", _p(x), _p(D), float(t0), float(t1), _p(dx), _p(x1), x.numel(), _p(health(x.device)),
+              _stream())
     return dx, x1
 
 
 def heun_correct(x, dx, x1, D1, t0, t1):
     _chk(x, f32, "x")
     out = torch.empty_like(x)
-    _lib.call("edm_heun_correct", _p(x), _p(dx), _p(x1), _p(D1), float(t0), float(t1), _p(out), x.numel(), _stream())
+    _lib.call("edm_heun_correct", _p(x), _p(dx), _p(x1), _p(D1), float(t0), float(t1), _p(out), x.numel(),
+              _p(health(x.device)), _stream())
     return out
 
 

@@ -1,4 +1,6 @@
 """2nd-order Heun sampler (reference solvers.py:4-59) with the loop optionally captured in a hipGraph."""
+import weakref
+
 import torch
 
 from . import _runtime_env, ops
@@ -25,7 +27,7 @@ class DeterministicSolver:
         i = torch.arange(num_steps, dtype=torch.float32)
         t = (sigma_max ** (1 / rho) + i / (num_steps - 1) * (sigma_min ** (1 / rho) - sigma_max ** (1 / rho))) ** rho
         self.t_steps = torch.cat([t, torch.zeros(1)])
-        self._graphs = {}
+        self._graphs = weakref.WeakKeyDictionary()      # model -> {(shapes, device): captured solve}
 
     # ------------------------------------------------------------------ eager
     def _loop(self, model, x0, class_labels, t_dev):
@@ -50,12 +52,22 @@ class DeterministicSolver:
         if not graph:
             t_dev = self.t_steps.to(x0.device)
             return self._loop(model, x0, class_labels, t_dev).to(in_dtype)
-        return self._solve_graphed(model, x0, class_labels).to(in_dtype)
+        out = self._solve_graphed(model, x0, class_labels).to(in_dtype)
+        # the Heun kernels leave a bit in the device health word when the state went non-finite: a replay that ran
+        # with corrupted arguments fails HERE, loudly (one host sync per solve of 2N-1 network evaluations)
+        ops.check_health(x0.device, "DeterministicSolver.solve(graph=True)")
+        return out
 
     # ------------------------------------------------------------------ hipGraph
     def _solve_graphed(self, model, x0, class_labels):
-        key = (id(model), tuple(x0.shape), None if class_labels is None else tuple(class_labels.shape), x0.device.index)
-        ent = self._graphs.get(key)
+        # graphs are cached PER MODEL OBJECT (weakly: a new model allocated at a dead one's address must not replay the
+        # dead one's graph, which id(model) as a key allowed)
+        owner = getattr(model, "__self__", model)        # a bound method is a fresh object per access: key on its object
+        per_model = self._graphs.get(owner)
+        if per_model is None:
+            per_model = self._graphs[owner] = {}
+        key = (tuple(x0.shape), None if class_labels is None else tuple(class_labels.shape), x0.device.index)
+        ent = per_model.get(key)
         if ent is None:
             _runtime_env.require_graph_replay_safe("DeterministicSolver.solve(graph=True)")
             t_dev = self.t_steps.to(x0.device)
@@ -73,7 +85,7 @@ class DeterministicSolver:
                     out = self._loop(model, sx, sl, t_dev)
             finally:
                 ops.capture_end()
-            ent = self._graphs[key] = (g, sx, sl, out, t_dev)
+            ent = per_model[key] = (g, sx, sl, out, t_dev)
         g, sx, sl, out, _ = ent
         # the captured evaluations read the persistent eval-mode weight packs: refresh them (a no-op unless the
         # master weights changed since the last solve: optimizer steps, EMA swap, load_state_dict) before replaying

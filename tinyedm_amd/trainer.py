@@ -102,8 +102,15 @@ class Trainer:
             # per rank or all ranks would noise their different shards with identical draws
             from . import networks
             if not getattr(self, "_rank_seeded", False):
-                networks.rng.seed = (networks.rng.seed + 0x9E3779B97F4A7C15 * self.global_rank) & 0xFFFFFFFFFFFFFFFF
+                self._base_seed = networks.rng.seed
+                networks.rng.seed = self._rank_seed(self._base_seed)
                 self._rank_seeded = True
+
+    def _rank_seed(self, base_seed: int) -> int:
+        """Philox seed of this rank for a run whose (rank-independent) seed is `base_seed`"""
+        if self.world_size <= 1:
+            return base_seed
+        return (base_seed + 0x9E3779B97F4A7C15 * self.global_rank) & 0xFFFFFFFFFFFFFFFF
 
     def _call(self, hook: str, *args):
         for cb in self.callbacks:
@@ -198,6 +205,8 @@ class Trainer:
                     self.global_step += 1
                     if self.scheduler_interval == "step":
                         self.lr_scheduler.step()
+                    if self.global_step % self.log_every_n_steps == 0:
+                        self._check_health(model, loss)
                     if self.global_rank == 0 and self.global_step % self.log_every_n_steps == 0:
                         print(f"[fit] epoch {epoch} step {self.global_step} loss {float(loss.detach()):.4f} "
                               f"{imgs / (time.time() - t0):.1f} img/s", flush=True)
@@ -210,12 +219,27 @@ class Trainer:
             if hasattr(model, "train_mse") and int(model.train_mse.total) > 0:
                 self.callback_metrics["train_loss"] = float(model.train_mse.compute())
                 model.train_mse.reset()
+            if torch.cuda.is_available() and "loss" in locals():
+                self._check_health(model, loss)          # before callbacks that write checkpoints / sample images
             self._epoch_complete = True
             self._call("on_train_epoch_end", model)
             if val is not None and (epoch + 1) % self.check_val_every_n_epoch == 0:
                 self.validate(model, val)
             self._epoch_complete = False
+        if isinstance(base, FusedAdam):
+            base.fuse_zero_grad = False       # back to torch semantics: step() leaves .grad for the caller to clear
         self._call("on_fit_end", model)
+
+    def _check_health(self, model, loss=None):
+        """The sentinel of the (graph-replayed or eager) step: the optimizer kernel leaves a bit in the device health
+        word when a non-finite gradient / weight went through it; read here, at the log interval and at epoch ends,
+        it turns a diverged or corrupted run into an exception instead of a checkpoint full of NaN."""
+        if not torch.cuda.is_available():
+            return
+        from . import ops
+        ops.check_health(model.device, f"Trainer.fit (epoch {self.current_epoch}, step {self.global_step})")
+        if loss is not None and not bool(torch.isfinite(loss.detach()).all()):
+            raise ops.GraphCorruptionError(f"Trainer.fit: loss is not finite at step {self.global_step}")
 
     @torch.no_grad()
     def validate(self, model, val):
@@ -245,7 +269,9 @@ class Trainer:
                 "lr_schedulers": [self.lr_scheduler.state_dict()] if hasattr(self.lr_scheduler, "state_dict") else [],
                 # what Lightning keeps in its loop state / torch RNG state: where in the epoch the run was, and the
                 # counter-based RNG position (the Philox streams are a pure function of (seed, step))
-                "tinyedm_amd": {"rng_seed": networks.rng.seed, "rng_step": networks.rng.step,
+                # rng_seed is the run's BASE seed (without the per-rank offset of _setup_distributed): every rank re-applies
+                # its own offset when it resumes, so the ranks keep drawing different noise for their different shards
+                "tinyedm_amd": {"rng_seed": getattr(self, "_base_seed", networks.rng.seed), "rng_step": networks.rng.step,
                                 "epoch_complete": bool(getattr(self, "_epoch_complete", False)),
                                 "batch_in_epoch": int(getattr(self, "_batch_in_epoch", 0))}}
         if self.global_rank == 0:
@@ -269,7 +295,8 @@ class Trainer:
         self.current_epoch, self.global_step = ckpt.get("epoch", 0), ckpt.get("global_step", 0)
         priv = ckpt.get("tinyedm_amd", {})
         if "rng_step" in priv:
-            networks.rng.seed, networks.rng.step = priv["rng_seed"], priv["rng_step"]
+            self._base_seed = int(priv["rng_seed"])
+            networks.rng.seed, networks.rng.step = self._rank_seed(self._base_seed), priv["rng_step"]
         # Lightning semantics: a checkpoint written at the end of epoch e continues with epoch e+1; one written
         # mid-epoch re-enters epoch e after the batches it had already consumed
         if priv.get("epoch_complete", True):
@@ -280,8 +307,19 @@ class Trainer:
 
     # ------------------------------------------------------------------ predict
     @torch.no_grad()
-    def predict(self, model, datamodule=None, dataloaders=None, ckpt_path=None, distributed: bool = True):
-        """``distributed=False``: replicas-only sampling (no process group; each rank runs its own loader)."""
+    def predict(self, model, datamodule=None, dataloaders=None, return_predictions: Optional[bool] = None, ckpt_path=None,
+                distributed: bool = True):
+        """Lightning's signature as the reference calls it (generate.py:45-47: ``predict(model, datamodule=...,
+        return_predictions=False, ckpt_path=None)``).  ``return_predictions=False`` keeps nothing (the writer callback
+        consumes each batch) and returns None; ``ckpt_path`` loads the weights first.
+        ``distributed=False``: replicas-only sampling (no process group; each rank runs its own loader)."""
+        if ckpt_path is not None:
+            ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+            model.load_state_dict(ckpt["state_dict"], strict=False)
+            from . import networks
+            networks.bump_weight_epoch()
+        if return_predictions is None:
+            return_predictions = True
         if distributed:
             self._setup_distributed(model)
         elif torch.cuda.is_available():
@@ -300,8 +338,9 @@ class Trainer:
                 fn = getattr(cb, "write_on_batch_end", None)
                 if fn is not None:
                     fn(self, model, out, None, batch, bi, 0)
-            outs.append(out)
-        return outs
+            if return_predictions:
+                outs.append(out)
+        return outs if return_predictions else None
 
 
 def _cpu_tree(x):
