@@ -71,16 +71,23 @@ int edm_conv3x3_mod(const void* X, const void* Wp, void* Y, void* Y2, const floa
                     int W, int Cin, int Cout, const void* dyn, edm_stream_t stream);
 /* backward counterpart: dgrad of the block's second 3x3 conv (ga = alpha*conv3x3(dY, Wd), never written) with the
  * modulation backward in the epilogue: GR = ga*keep*mp_silu'(u*m)*m, gm[b,c] += sum_px ga*keep*mp_silu'(u*m)*u (gm
- * zero-filled [B][Cout] fp32); finish with edm_mod_finish.  -3 when H*W % 32 != 0 (use the separate kernels). */
+ * zero-filled fp32, rows of gm_stride floats, 0 = Cout); finish with edm_mod_finish, or -- when gm is a column slice of a
+ * buffer shared by all blocks -- with ONE edm_mod_finish_multi at the end of the backward pass.  -3 when H*W % 32 != 0
+ * (use the separate kernels). */
 int edm_conv3x3_modbwd(const void* dY, const void* Wd, float alpha, const void* U, const float* lin, long lin_stride,
-                       const float* gain, void* GR, float* gm, float pdrop, unsigned long long seed, unsigned sub,
-                       unsigned step, int B, int H, int W, int Cin, int Cout, const void* dyn, edm_stream_t stream);
+                       const float* gain, void* GR, float* gm, long gm_stride, float pdrop, unsigned long long seed,
+                       unsigned sub, unsigned step, int B, int H, int W, int Cin, int Cout, const void* dyn,
+                       edm_stream_t stream);
 /* dgrad of a block's first 3x3 conv with the mp_silu backward of the block input in its epilogue
  * (g = conv3x3(dY, Wd) never written): GX = mp_silu'(Xpre)*g + add_scale*ADD (ADD may be NULL). */
 int edm_conv3x3_silubwd(const void* dY, const void* Wd, const void* Xpre, const void* ADD, float add_scale, void* GX,
                         int B, int H, int W, int Cin, int Cout, edm_stream_t stream);
 int edm_mod_finish(const float* gm, const float* lin, long lin_stride, const float* gain, float* glin, long glin_stride,
                    float* ggain, int B, int C, edm_stream_t stream);
+/* every block's finish in one launch: gm_all / lin_all / glin_all are [B][stride] fp32, items a DEVICE array of
+ * {const float* gain; float* ggain; int col0, C;}: glin[:, col0:col0+C] += gm * *gain, *ggain += sum gm * lin */
+int edm_mod_finish_multi(const float* gm_all, const float* lin_all, float* glin_all, long stride, const void* items_dev,
+                         int n_items, int B, edm_stream_t stream);
 /* weight gradient: slabs[s,tap,co,ci] (fp32, nsplit = edm_conv_wgrad_nsplit(...)) partial sums over pixels. */
 int edm_conv_wgrad_nsplit(int B, int H, int W, int Cin, int Cout, int taps);
 int edm_conv_wgrad(const void* X, const void* dY, float* slabs, int B, int H, int W, int Cin, int Cout, int taps,
@@ -182,6 +189,15 @@ int edm_scalelong_fwd(const float* mean, const float* W1h, const float* W2h, flo
 int edm_scalelong_bwd(const float* mean, const float* W1h, const float* W2h, const float* gate, const float* z1save,
                       const float* ggate, float* gmean, float* gW1h, float* gW2h, int B, int C, int R,
                       edm_stream_t stream);
+/* The two steps above in ONE launch per direction (one workgroup per sample: mean over H*W in a fixed order, then the
+ * sample's gate MLP from LDS).  fwd: skip [B*HW][C] bf16 -> mean, gate [B][C], z1save [B][R].  bwd: channels
+ * [c_off, c_off+C) of gcat (rows of gcat_stride elements) are d loss / d (skip*gate); ggate = sum_hw gcat*skip is formed
+ * and consumed in place; gW1h / gW2h are accumulated (caller zero-fills), gmean written. */
+int edm_skip_gate_fwd(const void* skip, const float* W1h, const float* W2h, float* mean, float* gate, float* z1save,
+                      int B, int HW, int C, int R, edm_stream_t stream);
+int edm_skip_gate_bwd(const void* gcat, long gcat_stride, int c_off, const void* skip, const float* mean,
+                      const float* W1h, const float* W2h, const float* gate, const float* z1save, float* gmean,
+                      float* gW1h, float* gW2h, int B, int HW, int C, int R, edm_stream_t stream);
 /* cat = [inp, skip*gate] (networks.py:311) and backward */
 int edm_concat_gate_fwd(const void* inp, const void* skip, const float* gate, void* cat, void* silu_out, int B, int HW,
                         int Ci, int Cs, edm_stream_t stream);

@@ -16,10 +16,22 @@ def _free_port():
     return p
 
 
+class _Gain(torch.nn.Module):
+    """a 0-dim parameter between tensor parameters: lands in the arena's scalar tail (FlatArena layout 2), i.e. in the
+    reducer's last bucket"""
+
+    def __init__(self):
+        super().__init__()
+        self.g = torch.nn.Parameter(torch.tensor(1.3))
+
+    def forward(self, x):
+        return x * self.g
+
+
 def _model():
     torch.manual_seed(0)
-    return torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 32), torch.nn.Tanh(),
-                               torch.nn.Linear(32, 4))
+    return torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), _Gain(), torch.nn.Linear(32, 32), torch.nn.Tanh(),
+                               _Gain(), torch.nn.Linear(32, 4))
 
 
 def _worker(rank, world, port, q):
@@ -34,7 +46,10 @@ def _worker(rank, world, port, q):
                 p.add_(1.0)
     arena = FlatArena(list(model.parameters()))
     red = GradReducer(arena, bucket_bytes=2048)  # several buckets
-    assert len(red.buckets) > 1
+    assert len(red.buckets) > 2
+    assert red.buckets[-1]["lo"] == arena.scalar_lo and len(red.buckets[-1]["params"]) == 2     # the scalar tail
+    assert sorted(i for b in red.buckets for i in b["params"]) == list(range(len(arena.params)))
+    assert sum(b["hi"] - b["lo"] for b in red.buckets) == arena.numel
     red.broadcast_parameters()
     g = torch.Generator().manual_seed(123)
     X, Y = torch.randn(8, 16, generator=g), torch.randn(8, 4, generator=g)

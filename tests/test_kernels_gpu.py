@@ -436,6 +436,41 @@ def test_scalelong_concat(ops):
         assert rel(gw.cpu(), P[name].grad.view(gwh.shape)) < 5e-3, name
 
 
+@pytest.mark.parametrize("B,Ci,Cs,H,W", [(2, 64, 128, 8, 8), (3, 192, 192, 5, 7), (128, 256, 256, 32, 32), (4, 64, 768, 16, 16),
+                                          (2, 32, 1024, 4, 4)])
+def test_skip_gate_fused(ops, B, Ci, Cs, H, W):
+    """edm_skip_gate_fwd / _bwd (mean over H*W + gate MLP and their backward in ONE launch each, one workgroup per sample)
+    against the two-launch path (k_reduce_hw_det + k_scalelong_*) it replaces -- bit for bit in the forward (same fixed
+    summation tree is NOT required: compared at 1e-6) -- and against fp64 torch math; deterministic across calls."""
+    g = torch.Generator().manual_seed(B + Cs + H)
+    R = Cs // 16
+    skd = torch.randn(B, H, W, Cs, generator=g).to(torch.bfloat16).to(DEV)
+    gcd = torch.randn(B, H, W, Ci + Cs, generator=g).to(torch.bfloat16).to(DEV)
+    w1h = (torch.randn(R, Cs + 1, generator=g) / math.sqrt(Cs + 1)).to(DEV)
+    w2h = (torch.randn(Cs, R, generator=g) / math.sqrt(R)).to(DEV)
+    mean, gate, z1 = ops.skip_gate_fwd(skd, w1h, w2h)
+    mean2, gate2, z12 = ops.skip_gate_fwd(skd, w1h, w2h)
+    assert torch.equal(mean, mean2) and torch.equal(gate, gate2) and torch.equal(z1, z12)      # bit-reproducible
+    mean_ref = skd.double().mean(dim=(1, 2))
+    assert rel(mean, mean_ref) < 1e-6
+    m1 = torch.cat([mean_ref, torch.ones(B, 1, device=DEV, dtype=torch.float64)], 1)
+    z1_ref = m1 @ w1h.double().t()
+    gate_ref = torch.sigmoid((torch.nn.functional.silu(z1_ref) / 0.596) @ w2h.double().t())
+    assert rel(z1, z1_ref) < 1e-5 and rel(gate, gate_ref) < 1e-5
+    mean_o = ops.reduce_hw(skd, scale=1.0 / (H * W))
+    gate_o, z1_o = ops.scalelong_fwd(mean_o, w1h, w2h)
+    assert rel(mean, mean_o) < 1e-6 and rel(gate, gate_o) < 1e-6 and rel(z1, z1_o) < 1e-6
+    # backward
+    gmean, gw1, gw2 = ops.skip_gate_bwd(gcd, Ci, skd, mean, w1h, w2h, gate, z1)
+    ggate_o = ops.reduce_hw(gcd, C=Cs, c_off=Ci, y=skd)
+    gmean_o, gw1_o, gw2_o = ops.scalelong_bwd(mean_o, w1h, w2h, gate_o, z1_o, ggate_o)
+    assert rel(gmean, gmean_o) < 1e-5 and rel(gw1, gw1_o) < 1e-4 and rel(gw2, gw2_o) < 1e-4
+    ggate_ref = (gcd[..., Ci:].double() * skd.double()).sum(dim=(1, 2))
+    gz2 = ggate_ref * gate_ref * (1 - gate_ref)
+    gw2_ref = gz2.t() @ (torch.nn.functional.silu(z1_ref) / 0.596)
+    assert rel(gw2, gw2_ref) < 1e-4
+
+
 def test_precond_and_conv_out(ops):
     g = torch.Generator().manual_seed(9)
     B, C, H, W = 3, 128, 8, 8

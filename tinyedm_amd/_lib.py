@@ -33,6 +33,8 @@ SIGNATURES = {
     "edm_reduce_hw": [P, L, P, L, P, I, I, I, F, P],
     "edm_scalelong_fwd": [P, P, P, P, P, I, I, I, P],
     "edm_scalelong_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "edm_skip_gate_fwd": [P, P, P, P, P, P, I, I, I, I, P],
+    "edm_skip_gate_bwd": [P, L, I, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     "edm_concat_gate_fwd": [P, P, P, P, P, I, I, I, I, P],
     "edm_concat_gate_bwd": [P, P, P, P, P, I, I, I, I, P],
     "edm_precond_in": [P, P, I, F, P, I, I, I, I, P],
@@ -48,7 +50,8 @@ SIGNATURES = {
     "edm_conv_igemm_v6": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_s": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv3x3_mod": [P, P, P, P, P, L, P, F, U64, U, U, I, I, I, I, I, P, P],
-    "edm_conv3x3_modbwd": [P, P, F, P, P, L, P, P, P, F, U64, U, U, I, I, I, I, I, P, P],
+    "edm_conv3x3_modbwd": [P, P, F, P, P, L, P, P, P, L, F, U64, U, U, I, I, I, I, I, P, P],
+    "edm_mod_finish_multi": [P, P, P, L, P, I, I, P],
     "edm_conv3x3_silubwd": [P, P, P, P, F, P, I, I, I, I, I, P],
     "edm_mod_finish": [P, P, L, P, P, L, P, I, I, P],
     "edm_conv_wgrad_nsplit": [I, I, I, I, I, I],

@@ -151,6 +151,7 @@ struct ModEpilogue {
   float add_scale;
   int mode;           // 0: none / forward modulation (Y2 set), 1: modulation backward, 2: mp_silu backward
   const StepParams* dyn;  // non-null: step / seed of the Philox stream come from device memory (captured steps)
+  long gm_stride;         // row stride of gm in floats; 0 = Cout (a private contiguous [B][Cout] buffer)
 };
 __device__ __forceinline__ void apply_dyn(ModEpilogue& m) {
   if (m.dyn) {
@@ -264,7 +265,7 @@ __device__ __forceinline__ void store_tile_core(Put&& put, char* stage, bf16* __
         for (int off = CPR; off < 64; off <<= 1) part[j8] += __shfl_xor(part[j8], off, 64);
       }
       if (prow == 0 && mb < Npix && co_c < Cout) {
-        float* gp = mod.gm + (mb / mod.HW) * Cout + co_c;
+        float* gp = mod.gm + (mb / mod.HW) * (mod.gm_stride ? mod.gm_stride : (long)Cout) + co_c;
 #pragma unroll
         for (int j8 = 0; j8 < 8; ++j8) atomicAdd(gp + j8, part[j8]);
       }

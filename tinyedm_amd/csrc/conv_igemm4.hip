@@ -401,16 +401,19 @@ extern "C" int edm_conv3x3_mod(const void* X, const void* Wp, void* Y, void* Y2,
 // where m = lin*gain + 1 and u = U is the forward's pre-activation.  gm must be zero-filled [B][Cout]; follow with
 // edm_mod_finish.  Same values as edm_conv_igemm + edm_mod_silu_drop_bwd (gm up to summation order).
 // Returns EDM_ERR_UNSUPPORTED (-3) when H*W is not a multiple of 32 (a 32-pixel block would straddle images).
+// gm_stride: row stride of gm in floats (>= Cout; 0 = Cout): gm may be a column slice of a buffer shared by all blocks of
+// a network, finished by ONE edm_mod_finish_multi launch at the end of the backward pass.
 extern "C" int edm_conv3x3_modbwd(const void* dY, const void* Wd, float alpha, const void* U, const float* lin,
-                                  long lin_stride, const float* gain, void* GR, float* gm, float pdrop,
+                                  long lin_stride, const float* gain, void* GR, float* gm, long gm_stride, float pdrop,
                                   unsigned long long seed, unsigned sub, unsigned step, int B, int H, int W, int Cin,
                                   int Cout, const void* dyn, hipStream_t st) {
   EDM_REQUIRE(dY && Wd && U && lin && gain && GR && gm, "conv3x3_modbwd: null pointer");
-  EDM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0 && lin_stride >= Cout && pdrop >= 0.f && pdrop < 1.f,
+  EDM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0 && lin_stride >= Cout && pdrop >= 0.f && pdrop < 1.f &&
+                  (gm_stride == 0 || gm_stride >= Cout),
               "conv3x3_modbwd: bad args");
   if ((H * W) % 32 != 0) return EDM_ERR_UNSUPPORTED;
   ModEpilogue mod{lin, gain, (bf16*)GR, lin_stride, H * W, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), sub, step,
-                  (const bf16*)U, gm, nullptr, 0.f, 1, (const StepParams*)dyn};
+                  (const bf16*)U, gm, nullptr, 0.f, 1, (const StepParams*)dyn, gm_stride};
   if (edm_conv_v4_worthwhile((long)B * H * W, Cout)) {
     const int rc = edm_conv_igemm_v4_ex(dY, Wd, nullptr, nullptr, alpha, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
     if (rc != EDM_ERR_UNSUPPORTED) return rc;

@@ -368,6 +368,44 @@ extern "C" int edm_mod_finish(const float* gm, const float* lin, long lin_stride
   return EDM_OK;
 }
 
+// The finish of EVERY block of a network in one launch (round 3: 21 launches of 6 us -> 1).  gm_all / lin_all / glin_all
+// are [B][stride] buffers whose column ranges [col0, col0 + C) belong to one block each (the batched embed Linear's
+// layout); items is a DEVICE array.  glin += gm * gain (+=: a block that took the unfused path has written its glin
+// already and left its gm columns zero), ggain += sum gm * lin.
+struct ModFinItem {
+  const float* gain;
+  float* ggain;
+  int col0, C;
+};
+__global__ void k_mod_finish_multi(const float* __restrict__ gm, const float* __restrict__ lin, float* __restrict__ glin,
+                                   long stride, const ModFinItem* __restrict__ items, int B) {
+  const ModFinItem it = items[blockIdx.x];
+  const float g = *it.gain;
+  const long n = (long)B * it.C;
+  float part = 0.f;
+  for (long i = (long)blockIdx.y * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.y * blockDim.x) {
+    const long b = i / it.C;
+    const long e = b * stride + it.col0 + (i - b * it.C);
+    const float v = gm[e];
+    glin[e] += v * g;
+    part += v * lin[e];
+  }
+  __shared__ float red[4];
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(it.ggain, red[0] + red[1] + red[2] + red[3]);
+}
+extern "C" int edm_mod_finish_multi(const float* gm_all, const float* lin_all, float* glin_all, long stride,
+                                    const void* items_dev, int n_items, int B, hipStream_t st) {
+  EDM_REQUIRE(gm_all && lin_all && glin_all && items_dev && n_items > 0 && n_items <= 4096 && B > 0 && stride > 0,
+              "mod_finish_multi: bad args");
+  hipLaunchKernelGGL(k_mod_finish_multi, dim3(n_items, 8), dim3(256), 0, st, gm_all, lin_all, glin_all, stride,
+                     (const ModFinItem*)items_dev, B);
+  EDM_CHECK_LAUNCH("mod_finish_multi");
+  return EDM_OK;
+}
+
 // exported for tests: the keep-mask the two kernels above derive from (seed, sub, step)
 __global__ void k_dropout_mask(uint8_t* __restrict__ mask, long n8, float pdrop, uint32_t seed_lo, uint32_t seed_hi,
                                uint32_t sub, uint32_t step) {
@@ -593,6 +631,162 @@ extern "C" int edm_scalelong_bwd(const float* mean, const float* W1h, const floa
   hipLaunchKernelGGL(k_scalelong_bwd, dim3(B), dim3(256), (2 * C + 1 + 2 * R) * sizeof(float), st, mean, W1h, W2h,
                      gate, z1save, ggate, gmean, gW1h, gW2h, C, R);
   EDM_CHECK_LAUNCH("scalelong_bwd");
+  return EDM_OK;
+}
+
+// ---- the skip gate in ONE launch per direction (round 3).  The mean over H*W and the gate MLP were two launches each way
+// (k_reduce_hw_det + k_scalelong_*: 36 launches, 0.48 ms of the CIFAR-10 step, every one latency-bound: 512 small
+// workgroups, then 128 tiny ones).  Here ONE workgroup of 1024 threads owns ONE sample: C/8 lanes cover a pixel row's
+// channels 16 B each, blockDim / (C/8) rows are in flight per pass (x 8 unrolled loads per thread: 128 KiB of loads in
+// flight per CU), the row groups meet in LDS in a fixed order (bit-reproducible, as k_reduce_hw_det), and the same
+// workgroup then runs the sample's gate MLP from LDS -- no second launch, no cross-workgroup hand-off.
+template <bool MUL>
+__device__ __forceinline__ void sample_reduce(const bf16* __restrict__ x, long xs, const bf16* __restrict__ y, long ys,
+                                              int HW, int C, float* red, float* out_lds, float scale) {
+  const int lpr = C >> 3;                       // lanes per pixel row
+  const int rpp = blockDim.x / lpr;             // rows per pass
+  const int cl = threadIdx.x % lpr, rg = threadIdx.x / lpr;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rg < rpp) {
+    constexpr int UN = 8;
+    for (int p0 = rg; p0 < HW; p0 += rpp * UN) {
+      u32x4 v[UN], u[UN];
+#pragma unroll
+      for (int k = 0; k < UN; ++k) {
+        const int p = p0 + rpp * k;
+        const bool ok = p < HW;
+        v[k] = ok ? *reinterpret_cast<const u32x4*>(x + (long)p * xs + cl * 8) : u32x4{0u, 0u, 0u, 0u};
+        if (MUL) u[k] = ok ? *reinterpret_cast<const u32x4*>(y + (long)p * ys + cl * 8) : u32x4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int k = 0; k < UN; ++k) {
+        const bf16x8 a = __builtin_bit_cast(bf16x8, v[k]);
+        if (MUL) {
+          const bf16x8 b = __builtin_bit_cast(bf16x8, u[k]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += (float)a[j] * (float)b[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += (float)a[j];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[rg * C + cl * 8 + j] = acc[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int q = 0; q < rpp; ++q) s += red[q * C + c];
+    out_lds[c] = s * scale;
+  }
+  __syncthreads();
+}
+
+// forward: mean[b,:] = mean_hw skip[b];  gate = sigmoid(W2 mp_silu(W1 [mean;1]))   (networks.py:112-118)
+__global__ __launch_bounds__(1024) void k_skip_gate_fwd(const bf16* __restrict__ skip, const float* __restrict__ W1,
+                                                          const float* __restrict__ W2, float* __restrict__ mean,
+                                                          float* __restrict__ gate, float* __restrict__ z1save, int HW,
+                                                          int C, int R) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // red[rpp*C] | m[C+1] | h[R]
+  const int rpp = blockDim.x / (C >> 3);
+  float* red = sm;
+  float* m = sm + rpp * C;
+  float* h = m + C + 1;
+  const int b = blockIdx.x;
+  sample_reduce<false>(skip + (long)b * HW * C, C, nullptr, 0, HW, C, red, m, 1.0f / (float)HW);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) mean[(long)b * C + c] = m[c];
+  if (threadIdx.x == 0) m[C] = 1.0f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int r = wave; r < R; r += nw) {
+    float s = 0.f;
+    for (int c = lane; c <= C; c += 64) s += W1[(long)r * (C + 1) + c] * m[c];
+    s = wave_sum(s);
+    if (lane == 0) {
+      z1save[(long)b * R + r] = s;
+      h[r] = mp_silu_f(s);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += W2[(long)c * R + r] * h[r];
+    gate[(long)b * C + c] = sigmoidf_(s);
+  }
+}
+// backward: ggate[b,c] = sum_hw gcat[b,hw,Ci+c] * skip[b,hw,c], then the MLP backward of k_scalelong_bwd
+__global__ __launch_bounds__(1024) void k_skip_gate_bwd(const bf16* __restrict__ gcat, long gs, const bf16* __restrict__ skip,
+                                                          const float* __restrict__ mean, const float* __restrict__ W1,
+                                                          const float* __restrict__ W2, const float* __restrict__ gate,
+                                                          const float* __restrict__ z1save, float* __restrict__ gmean,
+                                                          float* __restrict__ gW1, float* __restrict__ gW2, int HW, int C,
+                                                          int R) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // red[rpp*C] | gz2[C] | m[C+1] | h[R] | gz1[R]
+  const int rpp = blockDim.x / (C >> 3);
+  float* red = sm;
+  float* gz2 = sm + rpp * C;
+  float* m = gz2 + C;
+  float* h = m + C + 1;
+  float* gz1 = h + R;
+  const int b = blockIdx.x;
+  sample_reduce<true>(gcat + (long)b * HW * gs, gs, skip + (long)b * HW * C, C, HW, C, red, gz2, 1.0f);   // gz2 <- ggate
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    m[c] = mean[(long)b * C + c];
+    const float g = gate[(long)b * C + c];
+    gz2[c] *= g * (1.0f - g);
+  }
+  if (threadIdx.x == 0) m[C] = 1.0f;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) h[r] = mp_silu_f(z1save[(long)b * R + r]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * R; i += blockDim.x) atomicAdd(gW2 + i, gz2[i / R] * h[i % R]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int r = wave; r < R; r += nw) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += W2[(long)c * R + r] * gz2[c];
+    s = wave_sum(s);
+    if (lane == 0) gz1[r] = s * mp_silu_grad_f(z1save[(long)b * R + r]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < R * (C + 1); i += blockDim.x) atomicAdd(gW1 + i, gz1[i / (C + 1)] * m[i % (C + 1)]);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += W1[(long)r * (C + 1) + c] * gz1[r];
+    gmean[(long)b * C + c] = s;
+  }
+}
+static inline int skip_gate_threads(int C) {   // a multiple of the C/8 lanes of a pixel row, <= 1024
+  const int lpr = C / 8;
+  int t = 1024 / lpr * lpr;
+  return t < 64 ? 0 : t;
+}
+// skip [B*HW][C] bf16, W1h [R][C+1], W2h [C][R] fp32 -> mean, gate [B][C], z1save [B][R]   (C % 8 == 0, C <= 4096)
+extern "C" int edm_skip_gate_fwd(const void* skip, const float* W1h, const float* W2h, float* mean, float* gate,
+                                 float* z1save, int B, int HW, int C, int R, hipStream_t st) {
+  EDM_REQUIRE(skip && W1h && W2h && mean && gate && z1save, "skip_gate_fwd: null pointer");
+  EDM_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 8 == 0 && C <= 4096 && R > 0 && R <= 1024, "skip_gate_fwd: bad args");
+  const int threads = skip_gate_threads(C);
+  EDM_REQUIRE(threads > 0, "skip_gate_fwd: C too large");
+  const size_t lds = ((size_t)(threads / (C / 8)) * C + C + 1 + R) * sizeof(float);
+  hipLaunchKernelGGL(k_skip_gate_fwd, dim3(B), dim3(threads), lds, st, (const bf16*)skip, W1h, W2h, mean, gate, z1save,
+                     HW, C, R);
+  EDM_CHECK_LAUNCH("skip_gate_fwd");
+  return EDM_OK;
+}
+// gcat rows of gcat_stride elements whose channels [c_off, c_off + C) are the gradient of skip * gate; gW1h / gW2h are
+// ACCUMULATED (zero-filled by the caller), gmean [B][C] written
+extern "C" int edm_skip_gate_bwd(const void* gcat, long gcat_stride, int c_off, const void* skip, const float* mean,
+                                 const float* W1h, const float* W2h, const float* gate, const float* z1save, float* gmean,
+                                 float* gW1h, float* gW2h, int B, int HW, int C, int R, hipStream_t st) {
+  EDM_REQUIRE(gcat && skip && mean && W1h && W2h && gate && z1save && gmean && gW1h && gW2h, "skip_gate_bwd: null pointer");
+  EDM_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 8 == 0 && C <= 4096 && R > 0 && R <= 1024 && c_off >= 0 && c_off % 8 == 0 &&
+                  gcat_stride >= c_off + C && gcat_stride % 8 == 0, "skip_gate_bwd: bad args");
+  const int threads = skip_gate_threads(C);
+  EDM_REQUIRE(threads > 0, "skip_gate_bwd: C too large");
+  const size_t lds = ((size_t)(threads / (C / 8)) * C + 2 * C + 1 + 2 * R) * sizeof(float);
+  hipLaunchKernelGGL(k_skip_gate_bwd, dim3(B), dim3(threads), lds, st, (const bf16*)gcat + c_off, gcat_stride,
+                     (const bf16*)skip, mean, W1h, W2h, gate, z1save, gmean, gW1h, gW2h, HW, C, R);
+  EDM_CHECK_LAUNCH("skip_gate_bwd");
   return EDM_OK;
 }
 

@@ -41,19 +41,27 @@ class GradReducer:
         self.enabled = True                      # False during non-final gradient-accumulation micro-batches
         self.is_cuda = arena.grad.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.is_cuda else None
-        # buckets = contiguous arena ranges, built in REVERSE parameter order (backward order)
+        # buckets = contiguous arena ranges, built in REVERSE parameter order (backward order) over the tensor parameters;
+        # the arena's tail of 0-dim parameters (block gains, gain_out: FlatArena layout 2) is ONE more bucket, the last --
+        # the block gains' gradients are final only when the backward pass ends (networks._EmbedAllFn.backward)
         per_bucket = max(1, bucket_bytes // 4)
         self.buckets: List[dict] = []
         cur = None
-        n = len(arena.params)
-        for idx in reversed(range(n)):
-            p, off = arena.params[idx], arena.offsets[idx]
-            end = arena.offsets[idx + 1] if idx + 1 < n else arena.numel
+        scalar_lo = getattr(arena, "scalar_lo", arena.numel)
+        order = sorted(range(len(arena.params)), key=lambda i: arena.offsets[i])      # by arena position
+        body = [i for i in order if arena.offsets[i] < scalar_lo]
+        tail = [i for i in order if arena.offsets[i] >= scalar_lo]
+        for k in reversed(range(len(body))):
+            idx = body[k]
+            off = arena.offsets[idx]
+            end = arena.offsets[body[k + 1]] if k + 1 < len(body) else scalar_lo
             if cur is None or cur["hi"] - off > per_bucket:
                 cur = {"lo": off, "hi": end, "params": [], "pending": 0, "work": None}
                 self.buckets.append(cur)
             cur["lo"] = off
             cur["params"].append(idx)
+        if tail:
+            self.buckets.append({"lo": scalar_lo, "hi": arena.numel, "params": tail, "pending": 0, "work": None})
         self._bucket_of = {}
         for b in self.buckets:
             for idx in b["params"]:

@@ -33,18 +33,41 @@ def _align(n: int, a: int = 64) -> int:
     return (n + a - 1) // a * a
 
 
+def sequential_offsets(params):
+    """layout 1 (rounds 1-2): every parameter in list order, 64-element aligned"""
+    offs, off = [], 0
+    for p in params:
+        offs.append(off)
+        off += _align(p.numel())
+    return offs, off
+
+
 class FlatArena:
-    """Re-homes a parameter list into one contiguous fp32 buffer (views keep names/shapes/strides)."""
+    """Re-homes a parameter list into one contiguous fp32 buffer (views keep names/shapes/strides).
+
+    Layout 2 (round 3): the tensor parameters in list order, then a TAIL holding the 0-dim parameters (block gains,
+    gain_out) -- `self.params` keeps the caller's order (index i is the i-th parameter of the optimizer, which is what
+    torch-Adam checkpoints are keyed on), only the offsets differ.  The scalar gradients are the last to become final in
+    a backward pass (the blocks' modulation finish is ONE launch at its very end), so they must not sit inside the
+    buckets of the weights around them: the data-parallel reducer gives the tail its own, last bucket."""
+    LAYOUT = 2
 
     def __init__(self, params: List[torch.nn.Parameter]):
         self.params = [p for p in params if p.requires_grad]
         dev = self.params[0].device
-        self.offsets, off = [], 0
+        self.offsets, off = [0] * len(self.params), 0
         for p in self.params:
             if p.dtype != torch.float32:
                 raise TypeError("FlatArena expects fp32 master parameters")
-            self.offsets.append(off)
-            off += _align(p.numel())
+        for i, p in enumerate(self.params):
+            if p.dim() > 0:
+                self.offsets[i] = off
+                off += _align(p.numel())
+        self.scalar_lo = off                 # [scalar_lo, numel): the 0-dim parameters
+        for i, p in enumerate(self.params):
+            if p.dim() == 0:
+                self.offsets[i] = off
+                off += _align(p.numel())
         self.numel = off
         self.theta = torch.zeros(off, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(off, device=dev, dtype=torch.float32)
@@ -122,15 +145,25 @@ class FusedAdam(torch.optim.Optimizer):
                      g["eps"], max(1, self.step_count), 0.0, 1.0, dyn=dyn, zero_grad=True)
 
     def state_dict(self):
-        return {"m": self.m, "v": self.v, "step": self.step_count,
+        return {"m": self.m, "v": self.v, "step": self.step_count, "layout": FlatArena.LAYOUT,
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
         """Accepts this class's own layout ({m, v, step}: flat arenas) or torch.optim.Adam's
         ({state: {i: {step, exp_avg, exp_avg_sq}}, param_groups}: what the reference's checkpoints hold)."""
         if "m" in sd:
-            self.m.copy_(sd["m"])
-            self.v.copy_(sd["v"])
+            if sd.get("layout", 1) == FlatArena.LAYOUT:
+                self.m.copy_(sd["m"])
+                self.v.copy_(sd["v"])
+            else:       # a checkpoint of rounds 1-2: parameters laid out in list order -- move every slice to its new home
+                a = self.arena
+                old, total = sequential_offsets(a.params)
+                if sd["m"].numel() != total:
+                    raise ValueError(f"optimizer state: flat arena of {sd['m'].numel()} elements, expected {total}")
+                for p, o_new, o_old in zip(a.params, a.offsets, old):
+                    n = p.numel()
+                    self.m[o_new:o_new + n].copy_(sd["m"][o_old:o_old + n])
+                    self.v[o_new:o_new + n].copy_(sd["v"][o_old:o_old + n])
             self.step_count = int(sd["step"])
         elif "state" in sd:
             a = self.arena

@@ -475,10 +475,14 @@ class ScaleLong(nn.Module):
         """NCHW in -> gate (B,C,1,1), as the reference module."""
         xh = ops.nchw_to_nhwc_bf16(inp.float().contiguous())
         B, H, W, C = xh.shape
-        mean = ops.reduce_hw(xh, scale=1.0 / (H * W))
         w1h, w2h = self.layer1.packs()[2], self.layer2.packs()[2]
-        gate, _ = ops.scalelong_fwd(mean, w1h, w2h)
+        _, gate, _ = ops.skip_gate_fwd(xh, w1h, w2h)
         return gate.view(B, C, 1, 1)
+
+
+# ScaleLong gate: mean over H*W + MLP (and their backward) in one launch per direction (csrc/elementwise.hip
+# k_skip_gate_*); EDM_SKIP_GATE_FUSED=0 keeps the two-launch form (A/B runs)
+SKIP_GATE_FUSED = os.environ.get("EDM_SKIP_GATE_FUSED", "1") != "0"
 
 
 class _ConcatGateFn(torch.autograd.Function):
@@ -487,8 +491,11 @@ class _ConcatGateFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)          # no zero-filled gradient tensor for the non-differentiable `sil`
         B, H, W, Cs = skip.shape
         w1h, w2h = sl.layer1.packs()[2], sl.layer2.packs()[2]
-        mean = ops.reduce_hw(skip, scale=1.0 / (H * W))
-        gate, z1 = ops.scalelong_fwd(mean, w1h, w2h)
+        if SKIP_GATE_FUSED:
+            mean, gate, z1 = ops.skip_gate_fwd(skip, w1h, w2h)     # mean over H*W + gate MLP: one launch
+        else:
+            mean = ops.reduce_hw(skip, scale=1.0 / (H * W))
+            gate, z1 = ops.scalelong_fwd(mean, w1h, w2h)
         # want_silu: also emit mp_silu(cat), the input of the block's first conv, from the same pass
         cat, sil = ops.concat_gate_fwd(inp, skip, gate, want_silu)
         ctx.sl, ctx.Ci = sl, inp.shape[-1]
@@ -503,8 +510,11 @@ class _ConcatGateFn(torch.autograd.Function):
         skip, mean, gate, z1, w1h, w2h = ctx.saved_tensors
         gcat = gcat.contiguous()
         Ci, Cs = ctx.Ci, skip.shape[-1]
-        ggate = ops.reduce_hw(gcat, C=Cs, c_off=Ci, y=skip)
-        gmean, gw1h, gw2h = ops.scalelong_bwd(mean, w1h, w2h, gate, z1, ggate)
+        if SKIP_GATE_FUSED:
+            gmean, gw1h, gw2h = ops.skip_gate_bwd(gcat, Ci, skip, mean, w1h, w2h, gate, z1)
+        else:
+            ggate = ops.reduce_hw(gcat, C=Cs, c_off=Ci, y=skip)
+            gmean, gw1h, gw2h = ops.scalelong_bwd(mean, w1h, w2h, gate, z1, ggate)
         ginp, gskip = ops.concat_gate_bwd(gcat, gate, gmean, Ci)
         gw1 = ctx.sl.layer1.finish_grad(gw1h.view(1, 1, *gw1h.shape))
         gw2 = ctx.sl.layer2.finish_grad(gw2h.view(1, 1, *gw2h.shape))
@@ -665,7 +675,8 @@ class _ResBlockFn(torch.autograd.Function):
     -> conv3x3 -> mp_add with the skip path (networks.py:246-263 encoder / 312-327 decoder)."""
 
     @staticmethod
-    def forward(ctx, u, emb, w1x1, w1, w2, wemb, gain, blk, lin_view, glin_view, token, s_pre=None, alias=False):
+    def forward(ctx, u, emb, w1x1, w1, w2, wemb, gain, blk, lin_view, glin_view, token, s_pre=None, alias=False,
+                gm_view=None):
         # alias=True: the block input u is handed back as a second output.  The Denoiser takes the U-Net skip from that
         # output, so the skip's gradient arrives in THIS backward (g_alias) and is added by the kernel that writes the
         # input gradient -- not by an autograd `add` launch per skip (9-16 ATen kernels, 0.8 GB per step, round 1).
@@ -706,7 +717,7 @@ class _ResBlockFn(torch.autograd.Function):
         out = ops.conv_igemm(a2, wf2, taps, residual=xres, alpha=b, beta=a)
         ctx.blk, ctx.enc, ctx.has1 = blk, enc, has1
         ctx.drop = (pdrop, seed, sub, step, rng.dyn)
-        ctx.batched, ctx.glin_view = batched, glin_view
+        ctx.batched, ctx.glin_view, ctx.gm_view = batched, glin_view, gm_view
         ctx.has_token = token is not None
         ctx.save_for_backward(u, xres if enc else None, dsave, s, r1, lin, a2, None if batched else emb, gain, wd1, wd2,
                               wd11, weh)
@@ -728,18 +739,26 @@ class _ResBlockFn(torch.autograd.Function):
         gp = blk.gain
         gdirect = gp.grad is not None and getattr(gp, "_edm_direct", False) and gp.grad.is_contiguous()
         ggain_out = gp.grad if gdirect else None
+        deferred = False
         if ops.FUSE_MOD and ops.IGEMM_VERSION == 0 and (gout.shape[1] * gout.shape[2]) % 32 == 0:
-            # conv2's dgrad with the modulation backward in its epilogue: ga2 never touches HBM
+            # conv2's dgrad with the modulation backward in its epilogue: ga2 never touches HBM.  With a shared gm buffer
+            # (batched mode, arena gradients) the finish (glin = gm * gain, d loss / d gain) is NOT launched per block:
+            # _EmbedAllFn.backward runs ONE edm_mod_finish_multi for all blocks; until then the gain's gradient is not
+            # final (`_edm_deferred`: the data-parallel reducer must not count it yet)
+            deferred = ctx.gm_view is not None and gdirect
             gr1, glin, ggain = ops.conv3x3_modbwd(gout, wd2, b, r1, lin, gain, pdrop, seed, sub, step, glin_out=glin_out,
-                                                     ggain_out=ggain_out, dyn=dyn)
+                                                     ggain_out=ggain_out, dyn=dyn, gm_out=ctx.gm_view if deferred else None)
+            if deferred:
+                gp._edm_deferred = True
         else:
             ga2 = ops.conv_igemm(gout, wd2, 9, alpha=b)
             gr1, glin, ggain = ops.mod_silu_drop_bwd(r1, lin, gain, ga2, pdrop, seed, sub, step, glin_out=glin_out,
                                                         ggain_out=ggain_out, dyn=dyn)
         if gdirect:
             ggain = None
-            for hook in getattr(gp, "_edm_hooks", ()):
-                hook(gp)
+            if not deferred:
+                for hook in getattr(gp, "_edm_hooks", ()):
+                    hook(gp)
         gw2 = _wgrad(blk.conv_3x3_2, a2, gout, 9, b)
         gwemb = gemb = gtoken = None
         if ctx.batched:
@@ -769,7 +788,7 @@ class _ResBlockFn(torch.autograd.Function):
                 gu = ops.conv3x3_silubwd(gr1, wd1, u, gout, a) if fuse else ops.silu_bwd(u, gs, gout, a)
         if g_alias is not None:         # decoder blocks are never asked for an alias; kept for completeness
             gu = ops.axpby(gu, 1.0, g_alias, 1.0)
-        return gu, gemb, gw11, gw1, gw2, gwemb, ggain, None, None, None, gtoken, None, None
+        return gu, gemb, gw11, gw1, gw2, gwemb, ggain, None, None, None, gtoken, None, None, None
 
 
 _rng_sub_counter = [0]
@@ -794,9 +813,9 @@ class _BlockBase(nn.Module):
             out = _ResBlockFn.apply(u, embedding, w11, self.conv_3x3_1.weight, self.conv_3x3_2.weight,
                                     self.embed.weight, self.gain, self, None, None, None, s_pre, alias)
         else:
-            lin_view, glin_view, token = lin
+            lin_view, glin_view, token, gm_view = lin
             out = _ResBlockFn.apply(u, None, w11, self.conv_3x3_1.weight, self.conv_3x3_2.weight, None, self.gain,
-                                    self, lin_view, glin_view, token, s_pre, alias)
+                                    self, lin_view, glin_view, token, s_pre, alias, gm_view)
         ualias = None
         if alias:
             out, ualias = out
@@ -962,16 +981,32 @@ class _EmbedAllFn(torch.autograd.Function):
         wcat = torch.cat(whs, 0)
         lin_all = ops.linear_fwd(emb, wcat)
         glin_all = ops.zeros_f32(lin_all.shape, lin_all.device)
-        ctx.den, ctx.glin_all = den, glin_all
+        # shared raw modulation-gradient buffer + the per-block table of ONE finish launch (only when every block gain's
+        # gradient lives in the flat arena; otherwise the blocks finish one by one)
+        table = den._modfin_table(blocks) if any(ctx.needs_input_grad) else None
+        gm_all = ops.zeros_f32(lin_all.shape, lin_all.device) if table is not None else None
+        ctx.den, ctx.glin_all, ctx.gm_all, ctx.lin_all, ctx.table = den, glin_all, gm_all, lin_all, table
         ctx.save_for_backward(emb, wcat)
         token = ops.zeros_f32((1,), emb.device)
-        ctx.mark_non_differentiable(lin_all, glin_all)
-        return lin_all, glin_all, token
+        if gm_all is not None:
+            ctx.mark_non_differentiable(lin_all, glin_all, gm_all)
+        else:
+            ctx.mark_non_differentiable(lin_all, glin_all)
+        return lin_all, glin_all, token, gm_all
 
     @staticmethod
-    def backward(ctx, _g1, _g2, _gtoken):
+    def backward(ctx, _g1, _g2, _gtoken, _g4=None):
         emb, wcat = ctx.saved_tensors
         glin_all = ctx.glin_all
+        if ctx.gm_all is not None:
+            # every block's modulation finish in one launch; the block gains' gradients are final from here on
+            ops.mod_finish_multi(ctx.gm_all, ctx.lin_all, glin_all, ctx.table, len(ctx.den._res_blocks()))
+            for b in ctx.den._res_blocks():
+                gp = b.gain
+                if getattr(gp, "_edm_deferred", False):
+                    gp._edm_deferred = False
+                    for hook in getattr(gp, "_edm_hooks", ()):
+                        hook(gp)
         dw = ops.linear_wgrad(glin_all, emb)                    # (sum C, E)
         gemb = ops.linear_dgrad(glin_all, wcat) if ctx.needs_input_grad[0] else None
         gws, off = [], 0
@@ -1092,6 +1127,25 @@ class Denoiser(nn.Module):
     def _res_blocks(self):
         return list(self.encoder_blocks) + list(self.decoder_blocks)
 
+    def _modfin_table(self, blocks):
+        """Device table of edm_mod_finish_multi ({gain ptr, d loss / d gain ptr, first column, channels} per block), or
+        None unless every block gain's gradient is a view into the flat gradient arena.  Cached on the pointers."""
+        gains = [b.gain for b in blocks]
+        if not all(g.grad is not None and getattr(g, "_edm_direct", False) and g.grad.is_contiguous() for g in gains):
+            return None
+        key = tuple((g.data_ptr(), g.grad.data_ptr()) for g in gains)
+        cached = getattr(self, "_modfin", None)
+        if cached is None or cached[0] != key:
+            rec = np.zeros(len(blocks), dtype=np.dtype([("gain", "<u8"), ("ggain", "<u8"), ("col0", "<i4"), ("C", "<i4")]))
+            assert rec.dtype.itemsize == 24
+            off = 0
+            for k, (b, g) in enumerate(zip(blocks, gains)):
+                C = b.embed.weight.shape[0]
+                rec[k] = (g.data_ptr(), g.grad.data_ptr(), off, C)
+                off += C
+            cached = self._modfin = (key, torch.from_numpy(rec.view(np.uint8).copy()).to(gains[0].device))
+        return cached[1]
+
     def _prep_all(self):
         """One multi-tensor launch for every weight of the U-Net (forced normalisation in training + packs)."""
         mods = [m for m in self.modules() if isinstance(m, _WNBase)]
@@ -1115,14 +1169,15 @@ class Denoiser(nn.Module):
         emb = _emb32(embedding, B)
 
         blocks = self._res_blocks()
-        lin_all, glin_all, token = _EmbedAllFn.apply(emb, self, *[b.embed.weight for b in blocks])
+        lin_all, glin_all, token, gm_all = _EmbedAllFn.apply(emb, self, *[b.embed.weight for b in blocks])
         lins, off = {}, 0
         for k, b in enumerate(blocks):
             C = b.embed.weight.shape[0]
             # the ordering edge goes to the FIRST block only: every other block is downstream of its output, so its
             # backward -- and with it _EmbedAllFn.backward -- runs after all of them (one edge instead of 21 that
             # autograd would sum with 20 tiny adds)
-            lins[b] = (lin_all[:, off:off + C], glin_all[:, off:off + C], token if k == 0 else None)
+            lins[b] = (lin_all[:, off:off + C], glin_all[:, off:off + C], token if k == 0 else None,
+                       None if gm_all is None else gm_all[:, off:off + C])
             off += C
 
         x = _ConvInFn.apply(noisy, sig, self.conv_in.weight, self)

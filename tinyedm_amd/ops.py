@@ -322,6 +322,41 @@ def scalelong_bwd(mean, w1h, w2h, gate, z1, ggate):
     return gmean, gw1, gw2
 
 
+def skip_gate_fwd(skip, w1h, w2h):
+    """ScaleLong gate of a skip tensor in one launch: (mean (B,C), gate (B,C), z1 (B,R)) == reduce_hw(skip)/HW followed by
+    scalelong_fwd."""
+    B, H, W, C = _nhwc(skip, "skip")
+    R = w1h.shape[0]
+    _chk(w1h, f32, "w1h", (R, C + 1))
+    _chk(w2h, f32, "w2h", (C, R))
+    mean = torch.empty(B, C, device=skip.device, dtype=f32)
+    gate = torch.empty(B, C, device=skip.device, dtype=f32)
+    z1 = torch.empty(B, R, device=skip.device, dtype=f32)
+    _lib.call("edm_skip_gate_fwd", _p(skip), _p(w1h), _p(w2h), _p(mean), _p(gate), _p(z1), B, H * W, C, R, _stream())
+    return mean, gate, z1
+
+
+def skip_gate_bwd(gcat, Ci, skip, mean, w1h, w2h, gate, z1):
+    """backward of skip_gate_fwd given the gradient of cat = [inp, skip*gate]: (gmean, gw1h, gw2h) == reduce_hw(gcat[...,
+    Ci:] * skip) followed by scalelong_bwd."""
+    B, H, W, Ct = _nhwc(gcat, "gcat")
+    Bs, Hs, Ws, C = _nhwc(skip, "skip")
+    if (Bs, Hs, Ws) != (B, H, W) or Ci + C != Ct or Ci % 8:
+        raise ValueError("skip_gate_bwd: gcat / skip shape mismatch")
+    R = w1h.shape[0]
+    _chk(mean, f32, "mean", (B, C))
+    _chk(gate, f32, "gate", (B, C))
+    _chk(z1, f32, "z1", (B, R))
+    _chk(w1h, f32, "w1h", (R, C + 1))
+    _chk(w2h, f32, "w2h", (C, R))
+    gmean = torch.empty(B, C, device=skip.device, dtype=f32)
+    gw1 = zeros_f32(w1h.shape, w1h.device)
+    gw2 = zeros_f32(w2h.shape, w2h.device)
+    _lib.call("edm_skip_gate_bwd", _p(gcat), Ct, Ci, _p(skip), _p(mean), _p(w1h), _p(w2h), _p(gate), _p(z1), _p(gmean),
+              _p(gw1), _p(gw2), B, H * W, C, R, _stream())
+    return gmean, gw1, gw2
+
+
 def concat_gate_fwd(inp, skip, gate, want_silu):
     B, H, W, Ci = _nhwc(inp, "inp")
     Bs, Hs, Ws, Cs = _nhwc(skip, "skip")
@@ -505,9 +540,13 @@ def conv3x3_mod(x, wp, lin, gain, pdrop, seed, sub, step, want_u=True, dyn=None)
     return u, a2
 
 
-def conv3x3_modbwd(gout, wd, alpha, r1, lin, gain, pdrop, seed, sub, step, glin_out=None, ggain_out=None, dyn=None):
+def conv3x3_modbwd(gout, wd, alpha, r1, lin, gain, pdrop, seed, sub, step, glin_out=None, ggain_out=None, dyn=None,
+                   gm_out=None):
     """dgrad of a block's second 3x3 conv with the modulation backward in its epilogue: returns (gr1, glin, ggain),
-    the values conv_igemm(gout, wd, 9, alpha=alpha) followed by mod_silu_drop_bwd would give (H*W % 32 == 0)."""
+    the values conv_igemm(gout, wd, 9, alpha=alpha) followed by mod_silu_drop_bwd would give (H*W % 32 == 0).
+    gm_out: a zero-filled (B, Cout) fp32 view with unit column stride (a column slice of a buffer shared by all blocks):
+    the raw modulation gradient is accumulated there and NOT finished -- returns (gr1, None, None); one
+    mod_finish_multi over the shared buffer turns it into glin / ggain for every block."""
     B, H, W, Cin = _nhwc(gout, "gout")
     _chk(wd, bf16, "wd")
     if wd.dim() != 3 or wd.shape[0] != 9 or wd.shape[2] != Cin:
@@ -519,18 +558,38 @@ def conv3x3_modbwd(gout, wd, alpha, r1, lin, gain, pdrop, seed, sub, step, glin_
     ls = _lin_view(lin, B, Cout, "lin")
     _chk(gain, f32, "gain")
     gr = torch.empty_like(r1)
-    gm = zeros_f32((B, Cout), r1.device)
-    glin = torch.empty(B, Cout, device=r1.device, dtype=f32) if glin_out is None else glin_out
-    gs = _lin_view(glin, B, Cout, "glin")
-    ggain = zeros_f32((), r1.device) if ggain_out is None else _chk(ggain_out, f32, "ggain_out", ())
+    if gm_out is not None:
+        gms = _lin_view(gm_out, B, Cout, "gm_out")
+        gm = gm_out
+    else:
+        gms = 0
+        gm = zeros_f32((B, Cout), r1.device)
+        glin = torch.empty(B, Cout, device=r1.device, dtype=f32) if glin_out is None else glin_out
+        gs = _lin_view(glin, B, Cout, "glin")
+        ggain = zeros_f32((), r1.device) if ggain_out is None else _chk(ggain_out, f32, "ggain_out", ())
     npix = B * H * W
     entry = _igemm_entry(npix, W, Cout, 9, Cin)
     pname = "conv3x3_igemm" + (_v4_suffix(entry, npix, Cout) if entry in ("edm_conv_igemm_v4", "edm_conv_igemm_s") else "") + "_modbwd"
     with _prof(pname, 2.0 * npix * Cin * Cout * 9, 2.0 * (npix * (Cin + 2 * Cout) + wd.numel())):
-        _lib.call("edm_conv3x3_modbwd", _p(gout), _p(wd), float(alpha), _p(r1), _p(lin), ls, _p(gain), _p(gr), _p(gm),
+        _lib.call("edm_conv3x3_modbwd", _p(gout), _p(wd), float(alpha), _p(r1), _p(lin), ls, _p(gain), _p(gr), _p(gm), gms,
                   float(pdrop), int(seed), int(sub), int(step), B, H, W, Cin, Cout, _dyn(dyn), _stream())
+    if gm_out is not None:
+        return gr, None, None
     _lib.call("edm_mod_finish", _p(gm), _p(lin), ls, _p(gain), _p(glin), gs, _p(ggain), B, Cout, _stream())
     return gr, glin, ggain
+
+
+def mod_finish_multi(gm_all, lin_all, glin_all, items, n_items):
+    """items: uint8 device tensor of n_items 24-byte records {gain ptr, ggain ptr, col0, C} (csrc/elementwise.hip
+    ModFinItem): glin_all[:, col0:col0+C] += gm_all * gain, ggain += sum gm_all * lin_all, for every block at once."""
+    _chk(gm_all, f32, "gm_all")
+    _chk(lin_all, f32, "lin_all", gm_all.shape)
+    _chk(glin_all, f32, "glin_all", gm_all.shape)
+    _chk(items, torch.uint8, "items")
+    if gm_all.dim() != 2 or items.numel() != 24 * n_items:
+        raise ValueError("mod_finish_multi: bad buffers")
+    _lib.call("edm_mod_finish_multi", _p(gm_all), _p(lin_all), _p(glin_all), gm_all.shape[1], _p(items), int(n_items),
+              gm_all.shape[0], _stream())
 
 
 def conv3x3_silubwd(g, wd, xpre, gextra=None, extra_scale=1.0):
