@@ -144,12 +144,12 @@ def train_bench(args, rank, world, device):
         opt.zero_grad()
         return loss.detach()
 
-    # One GPU: the whole step (fwd + bwd + Adam/EMA, side stream included) is replayed from a hipGraph; the
-    # per-step scalars come from a device record (tinyedm_amd/graph.py).  N > 1: the collective-bearing step stays
-    # eager (RCCL all-reduces issued from autograd hooks, overlapped with the backward pass).
+    # The whole step (fwd + bwd + bucketed gradient all-reduce + Adam/EMA) is replayed from a hipGraph; the per-step
+    # scalars come from a device record (tinyedm_amd/graph.py).  With N > 1 ranks (or EDM_FORCE_REDUCE=1) the RCCL
+    # all-reduces are nodes of the graph: the hooks issue them on the comm stream forked from the capture stream.
     eager_step = step
-    from tinyedm_amd import _lib as _L
-    can_graph = world == 1 and not reducer.active
+    from tinyedm_amd import _lib as _L, _runtime_env as _RE
+    can_graph = _RE.GRAPH_REPLAY_SAFE and (not reducer.active or reducer.capturable())
     mode = args.step_launch if can_graph else "eager"
     launch_info = {}
     opt.zero_grad()
@@ -159,22 +159,31 @@ def train_bench(args, rank, world, device):
     torch.cuda.synchronize()
 
     def probe(fn, n=5):
-        """(wall ms per step, host enqueue ms per step, entry-point calls per step) over n steps"""
+        """(wall ms per step, host enqueue ms per step, entry-point calls per step) over n steps.  The host figure is
+        the time one step's enqueue takes with an EMPTY device queue (a synchronisation before each of 5 extra steps):
+        in the back-to-back loop the runtime blocks the host once enough work is queued, which measures the GPU."""
         torch.cuda.synchronize()
         c0, t0 = _L.N_CALLS, time.perf_counter()
         for i in range(n):
             fn(i)
-        t1 = time.perf_counter()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        return (t2 - t0) / n * 1e3, (t1 - t0) / n * 1e3, (_L.N_CALLS - c0) / n
+        calls = (_L.N_CALLS - c0) / n
+        hs = []
+        for i in range(5):
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            fn(n + i)
+            hs.append(time.perf_counter() - a)
+        torch.cuda.synchronize()
+        return (t2 - t0) / n * 1e3, sorted(hs)[len(hs) // 2] * 1e3, calls
     if rank == 0 or world > 1:
         e_ms, e_host, e_calls = probe(eager_step, 10)
         launch_info = {"eager_probe_ms": round(e_ms, 3), "host_enqueue_ms_per_step": round(e_host, 3),
                        "entry_point_calls_per_step": round(e_calls, 1)}
     if can_graph and mode in ("auto", "graph"):
         from tinyedm_amd.graph import CapturedTrainStep
-        captured = CapturedTrainStep(model, opt)
+        captured = CapturedTrainStep(model, opt, reducer=reducer)
         for i in range(CapturedTrainStep.WARMUP + 1):        # warm-up on the capture stream, then the capture itself
             captured(batch)
         for i in range(3):                                   # the first replays upload the executable graph
@@ -182,7 +191,10 @@ def train_bench(args, rank, world, device):
         g_ms, g_host, _ = probe(lambda i: captured(batch), 10)
         launch_info.update({"graph_probe_ms": round(g_ms, 3), "graph_host_ms_per_step": round(g_host, 3)})
         if mode == "auto":
-            mode = "graph" if g_ms < launch_info["eager_probe_ms"] else "eager"
+            pair = torch.tensor([g_ms, launch_info["eager_probe_ms"]], device=device, dtype=torch.float64)
+            if world > 1:           # one decision for the whole job: the slowest rank's figures
+                dist.all_reduce(pair, op=dist.ReduceOp.MAX)
+            mode = "graph" if float(pair[0]) < float(pair[1]) else "eager"
         note(f"step launch probe: eager {launch_info['eager_probe_ms']:.2f} ms (host enqueue {e_host:.2f} ms), "
              f"hipGraph replay {g_ms:.2f} ms -> timing the {mode} step")
     if mode == "graph":
@@ -336,8 +348,8 @@ def main():
     ap.add_argument("--sampler-iters", type=int, default=2)
     ap.add_argument("--no-sampler", action="store_true")
     ap.add_argument("--step-launch", choices=["auto", "graph", "eager"], default="auto",
-                    help="one GPU: time the hipGraph replay of the step, the eager Python step, or (auto) whichever a "
-                         "5-step probe finds faster; N > 1 ranks always run the eager, hook-driven step")
+                    help="time the hipGraph replay of the step (with N > 1 ranks the RCCL all-reduces are nodes of the "
+                         "graph), the eager Python step, or (auto) whichever a 10-step probe finds faster")
     ap.add_argument("--no-graph", action="store_true", help="same as --step-launch eager")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
@@ -364,10 +376,22 @@ def main():
     if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        if one_device:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # RCCL prints a version banner on STDOUT when its communicator is created; stdout carries the ONE JSON line, so
+        # the communicator is brought up (init + a first collective) with fd 1 pointed at stderr
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if one_device:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.all_reduce(torch.zeros(1, device=device))
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     model, ips, ms, final_loss, roof, launch_info = train_bench(args, rank, world, device)

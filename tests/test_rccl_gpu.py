@@ -96,14 +96,102 @@ def test_forced_reduce_runs_rccl_allreduce_from_hooks_on_one_gpu():
     assert 1e-5 < relb <= 2 ** -7, relb                               # bf16 wire format: one rounding per element
 
 
+def _worker_graph(port, q):
+    try:
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                          HSA_ENABLE_IPC_MODE_LEGACY="0")
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import tinyedm_amd as T             # before the first GPU call: the graph-safe runtime setting
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        import time
+        from test_graph_gpu import _build, _opt
+        from tinyedm_amd import networks as N
+        from tinyedm_amd.ddp import GradReducer
+        from tinyedm_amd.graph import CapturedTrainStep
+        g = torch.Generator().manual_seed(5)
+        batches = [((0.5 * torch.randn(8, 3, 16, 16, generator=g)).to(dev), torch.randint(0, 10, (8,), generator=g).to(dev))
+                   for _ in range(6)]
+        res = {}
+        for mode in ("eager", "graph"):
+            model, _ = _build()
+            opt, base, sched = _opt(model)
+            red = GradReducer(base.arena, bucket_bytes=1 << 18, force=True)
+            red.broadcast_parameters()
+            assert red.active and red.capturable() and len(red.buckets) > 2
+            opt.zero_grad()
+            launched = []
+            orig = red._launch
+            red._launch = lambda b, _o=orig: (launched.append(b["lo"]), _o(b))[1]
+            losses, host = [], []
+            cap = CapturedTrainStep(model, opt, reducer=red) if mode == "graph" else None
+            for bt in batches:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                if cap is None:
+                    loss = model.training_step(bt, 0)
+                    loss.backward()
+                    base.grad_scale = red.finish()
+                    opt.step()
+                    opt.zero_grad()
+                else:
+                    loss = cap(bt)
+                host.append(time.perf_counter() - t0)
+                sched.step()
+                losses.append(float(loss.detach()))
+            torch.cuda.synchronize()
+            res[mode] = dict(theta=base.arena.theta.cpu().numpy(), losses=losses, launches=len(launched),
+                             buckets=len(red.buckets), host_ms=1e3 * min(host[-2:]), counters=(base.step_count, N.rng.step))
+        T.ops.check_health(dev, "captured data-parallel step")
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put(("ok", res))
+    except Exception:          # noqa: BLE001
+        import traceback
+        q.put(("err", traceback.format_exc()))
+
+
+def test_captured_data_parallel_step_has_the_collectives_in_the_graph():
+    """The collective-bearing step as ONE hipGraph (forced one-rank RCCL group): the bucket all-reduces are issued by the
+    hooks while the step is captured (comm stream forked from the capture stream) and then live in the graph -- replays
+    issue NO collective from Python, cost the host a graph launch, and give the eager reducer step's losses / weights."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_graph, args=(_free_port(), q))
+    p.start()
+    status, out = q.get(timeout=600)
+    p.join(120)
+    assert status == "ok", out
+    assert p.exitcode == 0
+    e, g = out["eager"], out["graph"]
+    assert e["launches"] == 6 * e["buckets"]                       # eager: every bucket, every step, from Python
+    # captured: 2 eager warm-up steps + the capture itself issue them; the 3 replays issue none
+    assert g["launches"] == 3 * g["buckets"], (g["launches"], g["buckets"])
+    assert g["counters"] == e["counters"]
+    worst = max(abs(a - b) / abs(b) for a, b in zip(g["losses"], e["losses"]))
+    assert worst <= 2e-3, (g["losses"], e["losses"])
+    te, tg = torch.from_numpy(e["theta"]), torch.from_numpy(g["theta"])
+    rel = ((tg - te).norm() / te.norm()).item()
+    assert rel <= 2e-3, rel
+    assert g["host_ms"] <= 5.0, g["host_ms"]                       # a replayed data-parallel step is host-cheap
+
+
 def test_bench_and_fit_through_the_nccl_backend_on_one_gpu(tmp_path):
     """bench.py with EDM_FORCE_REDUCE=1: init_process_group("nccl"), broadcast, hook-driven bucket all-reduces on
     the comm stream every step (eager step: the collectives are issued from autograd hooks), one JSON line out."""
     env = dict(os.environ, EDM_FORCE_REDUCE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--batch", "16",
-                        "--no-sampler", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+                        "--no-sampler", "--no-cpu-baseline", "--step-launch", "auto"], capture_output=True, text=True, env=env,
+                       timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["collective"] == "rccl all-reduce (forced, 1 rank)"
-    assert line["config"]["step_launch"] == "eager"
+    # the collective-bearing step is host-cheap: the all-reduces are nodes of the replayed graph
+    assert line["config"]["graph_host_ms_per_step"] <= 5.0, line["config"]
+    assert line["config"]["step_launch"] in ("hipGraph replay", "eager")

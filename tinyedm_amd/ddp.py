@@ -18,8 +18,10 @@ import torch.distributed as dist
 
 
 def _aux_streams():
-    from . import ops
-    return ops.side_streams()
+    """side streams that may hold unfinished weight-gradient kernels -- none while the side stream is switched off (a
+    captured step runs as one chain: waiting on a stream outside the capture would break its isolation)"""
+    from . import networks, ops
+    return ops.side_streams() if networks.WGRAD_STREAM else []
 
 
 class GradReducer:
@@ -40,7 +42,10 @@ class GradReducer:
             raise ValueError("GradReducer: transport must be 'fp32' or 'bf16'")
         self.enabled = True                      # False during non-final gradient-accumulation micro-batches
         self.is_cuda = arena.grad.is_cuda
-        self.comm_stream = torch.cuda.Stream() if self.is_cuda else None
+        # EDM_COMM_INLINE=1: issue the collectives on the compute stream (no comm stream, no overlap): a diagnostic / the
+        # fallback if forked capture misbehaves
+        self.inline = os.environ.get("EDM_COMM_INLINE") == "1"
+        self.comm_stream = torch.cuda.Stream() if (self.is_cuda and not self.inline) else None
         # buckets = contiguous arena ranges, built in REVERSE parameter order (backward order) over the tensor parameters;
         # the arena's tail of 0-dim parameters (block gains, gain_out: FlatArena layout 2) is ONE more bucket, the last --
         # the block gains' gradients are final only when the backward pass ends (networks._EmbedAllFn.backward)
@@ -75,6 +80,11 @@ class GradReducer:
                     p._edm_hooks.append(hook)
         self.reset()
 
+    def capturable(self) -> bool:
+        """True when the collectives of a step can be captured into a hipGraph: RCCL on GPU tensors, all-reduced in place"""
+        return bool(self.is_cuda and self.transport == "fp32" and dist.is_initialized()
+                    and dist.get_backend(self.group) == "nccl")
+
     def reset(self):
         for b in self.buckets:
             b["pending"] = len(b["params"])
@@ -97,15 +107,26 @@ class GradReducer:
         return hook
 
     def _reduce(self, b, view):
+        # GPU: the collective is issued stream-ordered on the comm stream (async_op=False does not block the host with
+        # RCCL; it only means "ordered on the current stream") -- this form is also what a hipGraph capture of the step
+        # accepts (round 3 probe, tools/rccl_capture_probe.py: a captured async_op=True work object crashes the runtime
+        # at capture end).  CPU (gloo): asynchronous work objects, waited for in finish().
+        buf = view
         if self.transport == "bf16":
-            b["wire"] = view.to(torch.bfloat16)
-            b["work"] = dist.all_reduce(b["wire"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            buf = b["wire"] = view.to(torch.bfloat16)
+        if self.is_cuda:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            b["work"] = True
         else:
-            b["work"] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            b["work"] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _launch(self, b):
         view = self.arena.grad[b["lo"]:b["hi"]]
-        if self.is_cuda:
+        if self.is_cuda and self.inline:
+            for s in _aux_streams():
+                torch.cuda.current_stream().wait_stream(s)
+            self._reduce(b, view)
+        elif self.is_cuda:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             for s in _aux_streams():          # gradients finished on the side stream (networks._wgrad)
                 self.comm_stream.wait_stream(s)
@@ -123,16 +144,15 @@ class GradReducer:
                     self._launch(b)
             for b in self.buckets:
                 if self.is_cuda:
-                    with torch.cuda.stream(self.comm_stream):
-                        b["work"].wait()      # orders the comm stream behind the collective (no host block on RCCL)
-                        if self.transport == "bf16":
+                    if self.transport == "bf16":
+                        with torch.cuda.stream(self.comm_stream or torch.cuda.current_stream()):   # behind the collective
                             self.arena.grad[b["lo"]:b["hi"]].copy_(b["wire"])
                 else:
                     b["work"].wait()
                     if self.transport == "bf16":
                         self.arena.grad[b["lo"]:b["hi"]].copy_(b["wire"])
                 b["wire"] = None
-            if self.is_cuda:
+            if self.is_cuda and self.comm_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.reset()
         return 1.0 / self.world

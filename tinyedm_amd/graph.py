@@ -59,14 +59,18 @@ class CapturedTrainStep:
     """`loss = step(batch)`: one optimisation step of `model` (an EDM) under `optimizer` (FusedAdam, optionally inside
     an EMAOptimizer), replayed from a hipGraph captured on the first call with a given batch shape.
 
-    `reducer` (GradReducer): world size 1 only -- the collective-bearing step of a multi-GPU run stays eager (its
-    RCCL calls are issued from autograd hooks).  Semantics equal the eager sequence
-        loss = model.training_step(batch, i); loss.backward(); optimizer.step(); optimizer.zero_grad()
+    `reducer` (GradReducer, optional): the data-parallel step.  Its bucket all-reduces (RCCL) are issued by the same
+    autograd hooks as in the eager step, on the comm stream forked from the capture stream, and joined before the
+    optimizer kernel -- so they become nodes of the graph and an N-rank step costs the host one graph launch too (the
+    eager step needs ~360 ctypes calls + the hook / collective launches per step from Python).  Every rank captures the
+    same sequence of collectives, in the same order.  Semantics equal the eager sequence
+        loss = model.training_step(batch, i); loss.backward(); grad_scale = reducer.finish(); optimizer.step();
+        optimizer.zero_grad()
     including the host-side counters (Philox step, Adam step, EMA step, weight epoch)."""
 
     WARMUP = 2
 
-    def __init__(self, model, optimizer, grad_scale: float = 1.0):
+    def __init__(self, model, optimizer, grad_scale: float = 1.0, reducer=None):
         self.model = model
         self.opt = optimizer
         self.base = optimizer.optimizer if isinstance(optimizer, EMAOptimizer) else optimizer
@@ -74,6 +78,12 @@ class CapturedTrainStep:
             raise TypeError("CapturedTrainStep needs the flat-arena FusedAdam")
         _runtime_env.require_graph_replay_safe("CapturedTrainStep")
         self.ema = optimizer if isinstance(optimizer, EMAOptimizer) else None
+        self.reducer = reducer if (reducer is not None and reducer.active) else None
+        if self.reducer is not None:
+            if not self.reducer.capturable():
+                raise ValueError("CapturedTrainStep: the captured data-parallel step needs the RCCL ('nccl') backend and "
+                                 "the in-place fp32 transport")
+            grad_scale = grad_scale / self.reducer.world
         self.grad_scale = grad_scale
         self.params = StepParams(self.base.arena.theta.device)
         # warm-up steps and the capture run on ONE dedicated stream: autograd's AccumulateGrad nodes remember the
@@ -119,6 +129,8 @@ class CapturedTrainStep:
             with torch.cuda.stream(self.stream):
                 loss = self.model.training_step(batch, 0)
                 loss.backward()
+                if self.reducer is not None:
+                    self.reducer.finish()   # joins the comm stream; 1/world rides in the device record (grad_scale)
                 self.base.step_dyn(self.params.dev, ema=self.ema.ema_arena if self.ema is not None else None)
                 loss = loss.detach()        # drop the autograd graph (and with it the AccumulateGrad nodes) now
         finally:
@@ -156,15 +168,26 @@ class CapturedTrainStep:
         sy = None if y is None else y.clone()
         snap = self._snapshot()
         torch.cuda.synchronize()
+        mode = "global"
+        if self.reducer is not None:
+            # torch's process-group watchdog thread polls the events of earlier (eager) collectives with hipEventQuery;
+            # under a GLOBAL-mode capture that call from another thread is an error that invalidates the capture.  The
+            # device is idle now, so give the watchdog a moment to retire what it still holds, and capture in
+            # thread-local mode (only this thread's calls are policed).
+            import time
+            time.sleep(0.5)
+            mode = "thread_local"
         ops.capture_begin()
         graph = torch.cuda.CUDAGraph()
         # the step is captured as ONE chain: a weight-gradient side branch replays slower than the chain (CIFAR-10:
         # 15.5 vs 15.1 ms) -- hipGraph schedules the branch less favourably than the host's enqueue order does
         side, networks.WGRAD_STREAM = networks.WGRAD_STREAM, False
         try:
-            with torch.cuda.graph(graph, stream=self.stream):
+            with torch.cuda.graph(graph, stream=self.stream, capture_error_mode=mode):
                 loss = self.model.training_step((sx, sy), 0)
-                loss.backward()
+                loss.backward()                 # the reducer's hooks fork the comm stream off the capture stream ...
+                if self.reducer is not None:
+                    self.reducer.finish()       # ... and this joins it: the all-reduces are nodes of the graph
                 self.base.step_dyn(self.params.dev, ema=self.ema.ema_arena if self.ema is not None else None)
                 loss = loss.detach()
         finally:

@@ -79,7 +79,7 @@ class Trainer:
         self.datamodule = None
         self.callback_metrics: dict = {}
         self._resume_skip = 0          # batches of the first epoch already consumed before the checkpoint was written
-        # EDM_GRAPH=1 (one GPU, no gradient accumulation): the step is replayed from a hipGraph.  Off by default: the
+        # EDM_GRAPH=1 (no gradient accumulation; any number of ranks): the step is replayed from a hipGraph.  Off by default: the
         # step is GPU-bound on every configuration measured (round 2: eager with the weight-gradient side stream
         # 15.2 / 18.2 / 146 ms vs replay 15.1 / 18.2 / 154 ms on CIFAR-10 / MNIST / ImageNet-64), so the replay only
         # pays on a slower host
@@ -164,12 +164,14 @@ class Trainer:
             base.fuse_zero_grad = True        # step() is always followed by zero_grad() here
         opt.zero_grad()
         captured = None
-        if (self.use_graph and self.world_size == 1 and self.accumulate_grad_batches == 1 and isinstance(base, FusedAdam)
-                and torch.cuda.is_available()):
+        if (self.use_graph and self.accumulate_grad_batches == 1 and isinstance(base, FusedAdam)
+                and torch.cuda.is_available()
+                and (self.reducer is None or not self.reducer.active or self.reducer.capturable())):
             from . import _runtime_env
             if _runtime_env.GRAPH_REPLAY_SAFE:
                 from .graph import CapturedTrainStep
-                captured = CapturedTrainStep(model, opt)
+                # N > 1 ranks: the bucket all-reduces are captured into the graph (every rank replays the same sequence)
+                captured = CapturedTrainStep(model, opt, reducer=self.reducer)
             else:       # same arithmetic through the eager loop (see _runtime_env: the GPU was initialised too early)
                 import warnings
                 warnings.warn(f"tinyedm_amd: {_runtime_env.VAR}=0 was not in place before the GPU was initialised; "
