@@ -1,6 +1,8 @@
 """CPU-side checks of the data formats either side of the hot path: the byte<->float oracle on
 every byte value, the reference's closed-form expressions, and the on-disk readers (CIFAR-10 pickles, MNIST idx)
 on tiny fabricated datasets."""
+import os
+
 import numpy as np
 import torch
 
@@ -75,3 +77,47 @@ def test_make_grid_layout():
     g = make_grid_u8(x, nrow=4, padding=1)
     assert g.shape == (1 + 2 * 3, 1 + 4 * 4, 1)
     assert np.array_equal(g[1:3, 1:4, 0], x[0, 0].numpy()) and np.array_equal(g[4:6, 1:4, 0], x[4, 0].numpy())
+
+
+def test_extract_latents_layout_and_normalisation(tmp_path):
+    """tinyedm_amd.extract_latents (reference datamodules/extract_latents.py:14-125) with a stand-in encoder: ImageFolder
+    order, ADM centre crop to the target size, [-1, 1] range, the reference's latent normalisation constants, one .npy per
+    latent / label in the layout ImageNetLatentsDataModule reads, last partial batch dropped."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from tinyedm_amd import extract_latents as E
+    rng = np.random.default_rng(0)
+    sizes = {"n01": [(70, 50), (40, 90), (33, 33)], "n02": [(64, 64), (130, 70)]}
+    for cls, ss in sizes.items():
+        (tmp_path / "img" / cls).mkdir(parents=True)
+        for k, (w, h) in enumerate(ss):
+            Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(tmp_path / "img" / cls / f"im{k}.png")
+    samples, classes = E.list_image_folder(tmp_path / "img")
+    assert classes == ["n01", "n02"] and [c for _, c in samples] == [0, 0, 0, 1, 1]
+    assert [os.path.basename(p) for p, _ in samples] == ["im0.png", "im1.png", "im2.png", "im0.png", "im1.png"]
+    seen = []
+
+    def encoder(x):                       # a fixed "VAE": 8x8 average pooling of the three channels + their mean
+        seen.append(x.clone())
+        p = torch.nn.functional.avg_pool2d(x, 8)
+        return torch.cat([p, p.mean(1, keepdim=True)], 1)
+
+    n = E.extract(tmp_path / "img", tmp_path / "lat", image_size=32, batch_size=2, encoder=encoder, seed=1, device="cpu")
+    assert n == 4                         # 5 images, batch 2: the partial last batch is dropped (drop_last=True)
+    x = torch.cat(seen)
+    assert x.shape == (4, 3, 32, 32) and x.min() >= -1 and x.max() <= 1
+    # sample 2 is already 33x33: crop only -> pixel-exact centre crop (possibly flipped)
+    with Image.open(samples[2][0]) as im:
+        ref = (np.asarray(E.center_crop_arr(im.convert("RGB"), 32), dtype=np.float32) / 255 - 0.5) / 0.5
+    got = x[2].permute(1, 2, 0).numpy()
+    assert np.allclose(got, ref, atol=1e-6) or np.allclose(got, ref[:, ::-1], atol=1e-6)
+    z = np.load(tmp_path / "lat" / "latents" / "2.npy")
+    assert z.shape == (4, 4, 4) and z.dtype == np.float32
+    raw = encoder(x[2:3])[0].numpy()
+    mean, std = np.array(E.LATENT_MEAN).reshape(4, 1, 1), np.array(E.LATENT_STD).reshape(4, 1, 1)
+    assert np.allclose(z, (raw - mean) / (2 * std), atol=1e-6)
+    assert np.allclose(E.denormalize_latents(torch.from_numpy(z)[None])[0].numpy(), raw, atol=1e-5)
+    labels = [int(np.load(tmp_path / "lat" / "labels" / f"{i}.npy")) for i in range(4)]
+    assert labels == [0, 0, 0, 1]
+    assert not (tmp_path / "lat" / "latents" / "4.npy").exists()

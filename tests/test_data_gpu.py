@@ -150,3 +150,70 @@ def test_generate_callback_inside_fit_and_checkpoint_roundtrip(ops, tmp_path):
         assert torch.equal(sol.solve(m1, x0, lab), ref_plain)
         assert torch.equal(sol.solve(m2, x0, lab), ref_ema)
     assert not torch.equal(ref_plain, ref_ema)
+
+
+@pytest.mark.parametrize("size", [32, 64])
+def test_latent_pipeline_datamodule_fit_and_generate_callback(ops, tmp_path, size):
+    """SURVEY 8f row 4 (reference datamodules/imagenet_latents_datamodule.py:8-50, callbacks.py:61-123): a latent directory
+    in the layout extract_latents writes -> ImageNetLatentsDataModule (resident, rank-sharded loader) -> two optimisation
+    steps of a latent-space EDM (4 channels, class-conditional) -> LatentsGenerateCallback at the validation epoch end:
+    Heun-samples with the EMA weights swapped in and de-normalises the latents (x * 2 std + mean); the SD-VAE decode is
+    skipped (diffusers is not installed) and the de-normalised latents are written instead.  4x32x32 and 4x64x64."""
+    import tinyedm_amd as T
+    from tinyedm_amd import extract_latents as E
+    from tinyedm_amd.callbacks import LatentsGenerateCallback
+    from tinyedm_amd.datamodules import ImageNetLatentsDataModule
+    g = torch.Generator().manual_seed(size)
+    n_train, n_val, ncls = 12, 4, 1000
+    lat = {}
+    for split, n in (("train", n_train), ("val", n_val)):
+        (tmp_path / "lat" / split / "latents").mkdir(parents=True)
+        (tmp_path / "lat" / split / "labels").mkdir(parents=True)
+        lat[split] = (0.5 * torch.randn(n, 4, size, size, generator=g)).numpy().astype(np.float32)
+        for i in range(n):
+            np.save(tmp_path / "lat" / split / "latents" / f"{i}.npy", lat[split][i])
+            np.save(tmp_path / "lat" / split / "labels" / f"{i}.npy", np.asarray((37 * i + 5) % ncls, dtype=np.int64))
+    dm = ImageNetLatentsDataModule(str(tmp_path / "lat"), size, batch_size=6, num_workers=0)
+    dm.setup("fit")
+    assert dm.num_classes == 1000
+    seen = []
+    for xb, yb in dm.train_dataloader():
+        assert xb.is_cuda and xb.dtype == torch.float32 and tuple(xb.shape[1:]) == (4, size, size) and yb.dtype == torch.int64
+        for x, y in zip(xb.cpu().numpy(), yb.cpu().numpy()):
+            j = [k for k in range(n_train) if np.array_equal(x, lat["train"][k])]
+            assert len(j) == 1 and y == (37 * j[0] + 5) % ncls          # latent and label stay paired through the shuffle
+            seen.append(j[0])
+    assert sorted(seen) == list(range(n_train))
+    # a small latent-space denoiser: two resolutions below the input so that attention runs on <= 256 tokens
+    T.manual_seed(5)
+    torch.manual_seed(5)
+    emb = T.Embedding(32, 64, ncls)
+    den = T.Denoiser(4, 4, ("Enc", "EncD", "Enc", "EncD", "EncA"), ("DecA", "Dec", "DecU", "Dec", "DecU", "Dec"),
+                     (64, 64, 64, 64, 64), (64, 64, 64, 64, 64, 64), (False, True, True, True, True, True), 0.0, 0.5, 0.3,
+                     0.3, 64, 2)
+    with torch.no_grad():
+        den.gain_out.fill_(0.5)
+    model = T.EDM(diffuser=T.Diffuser(-0.4, 1.0), embedding=emb, denoiser=den, use_ema=True, use_uncertainty=False,
+                  steady_steps=10, rampup_steps=2, scheduler_interval="step", lr=1e-3, ema_length=0.13)
+    mean, std = E.LATENT_MEAN, E.LATENT_STD
+    cb = LatentsGenerateCallback(T.DeterministicSolver(num_steps=3), (4, size, size), mean, std, num_samples_per_class=2,
+                                 num_classes=3, every_n_epochs=1, output_dir=str(tmp_path / "gen"))
+    tr = T.Trainer(max_epochs=1, callbacks=[cb], check_val_every_n_epoch=1)
+    tr.fit(model, datamodule=dm)
+    assert tr.global_step == 2                                           # 12 latents / batch 6
+    assert cb.vae is None                                                # no diffusers here: decode skipped
+    out = cb.last
+    assert out is not None and tuple(out.shape) == (6, 4, size, size) and torch.isfinite(out).all()
+    saved = np.load(tmp_path / "gen" / "latents_epoch_00000.npy")
+    assert np.array_equal(saved, out.cpu().numpy())
+    # de-normalisation == the inverse of extract_latents' normalisation, on the solver's output for the same x0 / labels.
+    # Reference semantics, kept: the EMA callback has ALREADY swapped the EMA weights in for validation (ema.py:83-100) and
+    # the callback's own `swap_ema_weights` (callbacks.py:110-113) swaps back, so this sample runs on the training weights
+    model.eval()
+    with torch.no_grad():
+        xT = T.DeterministicSolver(num_steps=3).solve(model, cb.x0, cb.class_labels)
+        with model.swap_ema_weights(tr):
+            xT_ema = T.DeterministicSolver(num_steps=3).solve(model, cb.x0, cb.class_labels)
+    assert torch.allclose(out, E.denormalize_latents(xT.float()), rtol=1e-5, atol=1e-5)
+    assert not torch.allclose(out, E.denormalize_latents(xT_ema.float()), rtol=1e-5, atol=1e-5)
+    assert "val_loss" in tr.callback_metrics and np.isfinite(tr.callback_metrics["val_loss"])

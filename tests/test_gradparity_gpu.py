@@ -1,0 +1,143 @@
+"""Whole-network gradient parity on the BENCHMARKED network (BASELINE configs[1] and [2]: the CIFAR-10 EDM2 U-Net,
+35.6 M parameters, unconditional and class-conditional), training mode with dropout 0.13.
+
+One training step's backward pass through the HIP path -- every per-parameter gradient (all 136+ tensors: 3x3 / 1x1
+conv weights through the grouped and per-layer weight-gradient kernels, embed Linears, ScaleLong MLPs, block gains,
+gain_out) -- is compared with autograd through the CPU oracle (oracle/edm_oracle.py, pinned to the reference by
+tests/test_oracle_golden.py) on the SAME inputs, the SAME noise draws and the kernel's OWN Philox dropout masks
+(ops.dropout_mask regenerates each block's mask from (seed, block stream, step), injected through the oracle's
+`dropout_masks=`), twice: with the bf16 rounding points of the HIP path (limit 3e-2 relative L2 per tensor) and in plain
+fp32 (what the reference's fp32 autograd would give; recorded, limit 6e-2).  Reference: networks.py:32-37, 246-329,
+edm.py:205-236.  Every per-tensor figure goes to gpurun_out/grad_parity_r03.json (copied to profiles/)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import edm_oracle as O
+from parity_log import record
+
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def _block_shapes(den, B, H):
+    """(prefix, block, (B, h, w, C)) of every residual block's dropout site (the output of its first 3x3 conv)"""
+    out = []
+    h = H
+    for i, (blk, t) in enumerate(zip(den.encoder_blocks, den.encoder_block_types)):
+        if t.endswith("D"):
+            h //= 2
+        out.append((f"denoiser.encoder_blocks.{i}.", blk, (B, h, h, blk.conv_3x3_2.weight.shape[1])))
+    for i, (blk, t) in enumerate(zip(den.decoder_blocks, den.decoder_block_types)):
+        if t.endswith("U"):
+            h *= 2
+        out.append((f"denoiser.decoder_blocks.{i}.", blk, (B, h, h, blk.conv_3x3_2.weight.shape[1])))
+    return out
+
+
+@pytest.mark.parametrize("conditional", [False, True], ids=["cifar10", "cifar10_cond"])
+def test_whole_network_gradients_vs_oracle(conditional):
+    import tinyedm_amd as T
+    from tinyedm_amd import metric, networks as N, ops
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ecfg, dcfg = O.cifar10_cfg(10 if conditional else None)
+    assert dcfg.dropout_rate == 0.13
+    P = O.init_params(ecfg, dcfg, torch.Generator().manual_seed(21), gains_nonzero=True)
+    N._rng_sub_counter[0] = 0
+    T.manual_seed(1234)
+    emb = T.Embedding(ecfg.fourier_dim, ecfg.embedding_dim, ecfg.num_classes, ecfg.add_factor)
+    den = T.Denoiser(dcfg.in_channels, dcfg.out_channels, tuple(dcfg.encoder_block_types),
+                     tuple(dcfg.decoder_block_types), tuple(dcfg.encoder_out_channels),
+                     tuple(dcfg.decoder_out_channels), tuple(dcfg.skip_connections), dcfg.dropout_rate,
+                     dcfg.sigma_data, dcfg.encoder_add_factor, dcfg.decoder_add_factor, dcfg.embedding_dim, dcfg.num_heads)
+    emb.load_state_dict({k[len("embedding."):]: v for k, v in P.items() if k.startswith("embedding.")})
+    den.load_state_dict({k[len("denoiser."):]: v for k, v in P.items() if k.startswith("denoiser.")})
+    emb, den = emb.to(DEV).train(), den.to(DEV).train()
+    named = {("embedding." + k): v for k, v in emb.named_parameters()}
+    named.update({("denoiser." + k): v for k, v in den.named_parameters()})
+    # the benchmarked configuration keeps gradients in the flat arena (FusedAdam): direct accumulation by the kernels,
+    # grouped 3x3 weight gradients, one modulation finish per step
+    opt = T.FusedAdam(list(named.values()), lr=1e-3)
+    opt.zero_grad()
+
+    g = torch.Generator().manual_seed(77)
+    B = 4
+    clean = 0.5 * torch.randn(B, 3, 32, 32, generator=g)
+    eps, noise = torch.randn(B, generator=g), torch.randn(B, 3, 32, 32, generator=g)
+    labels = torch.randint(0, 10, (B,), generator=g) if conditional else None
+    noisy, sigma = O.diffuse(clean, eps, noise, -1.2, 1.2)
+
+    seed, step0 = N.rng.seed, N.rng.step
+    _, e = emb(sigma.to(DEV), None if labels is None else labels.to(DEV))
+    D = den(noisy.to(DEV), sigma.to(DEV), e)
+    w = (sigma ** 2 + 0.25) / (sigma * 0.5) ** 2
+    loss = metric.weighted_mse_loss(w.to(DEV), D, clean.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert N.rng.step == step0 + 1
+
+    # the kernel's own dropout masks, block by block (NHWC element order -> NCHW for the oracle)
+    masks = {}
+    kept = []
+    for prefix, blk, (b, h, w_, c) in _block_shapes(den, B, 32):
+        m = ops.dropout_mask(b * h * w_ * c, blk.dropout_rate, seed, blk.rng_sub, step0, DEV)
+        masks[prefix] = m.view(b, h, w_, c).permute(0, 3, 1, 2).float().cpu().contiguous()
+        kept.append(masks[prefix].mean().item())
+    assert abs(float(np.mean(kept)) - 0.87) < 5e-3, np.mean(kept)
+
+    out = {}
+    for tag, bf16, lim in (("bf16_oracle", True, 3e-2), ("fp32_autograd", False, 6e-2)):
+        Pb = {k: v.clone() for k, v in P.items()}
+        keys = O.trainable_keys(Pb)
+        for k in keys:
+            Pb[k].requires_grad_(True)
+        lo = O.training_loss(Pb, ecfg, dcfg, clean, eps, noise, -1.2, 1.2, labels, bf16=bf16, dropout_masks=masks)
+        lo.backward()
+        assert sorted(keys) == sorted(named), set(keys) ^ set(named)
+        lrel = abs(loss.item() - lo.item()) / abs(lo.item())
+        record(f"gradparity/{'cond' if conditional else 'uncond'}/loss_vs_{tag}", lrel, 2e-2)
+        assert lrel <= 2e-2, (loss.item(), lo.item())
+        scal = [Pb[k].grad.abs().item() for k in keys if Pb[k].numel() == 1]
+        scal_rms = float(np.sqrt(np.mean(np.square(scal))))
+        per = {}
+        for k in keys:
+            gr, go = named[k].grad, Pb[k].grad
+            assert gr is not None and torch.isfinite(gr).all(), k
+            if gr.numel() == 1:     # scalar gains: sums with heavy cancellation -> judged against the scale of the scalar grads
+                per[k] = abs(gr.item() - go.item()) / max(abs(go.item()), scal_rms)
+            else:
+                per[k] = rel(gr, go)
+        worst = max(per, key=per.get)
+        out[tag] = {"worst_tensor": worst, "worst": per[worst], "limit": lim, "median": float(np.median(list(per.values()))),
+                    "n_tensors": len(per), "per_tensor": {k: round(v, 6) for k, v in sorted(per.items())}}
+        record(f"gradparity/{'cond' if conditional else 'uncond'}/worst_tensor_vs_{tag}[{worst}]", per[worst], lim)
+        assert per[worst] <= lim, f"{tag}: {worst} rel {per[worst]:.3e} (limit {lim})"
+        # the in-place weight normalisation of the training forward agrees too (networks.py:32-34)
+        for k in keys:
+            if Pb[k].dim() >= 2:
+                assert rel(named[k].detach(), Pb[k].detach()) <= 1e-5, k
+    path = os.path.join(ROOT, "gpurun_out", "grad_parity_r03.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        old = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                old = json.load(f)
+        old["cifar10_cond" if conditional else "cifar10"] = {"batch": B, "dropout": dcfg.dropout_rate, "n_params": int(
+            sum(v.numel() for v in named.values())), **out}
+        with open(path, "w") as f:
+            json.dump(old, f, indent=1)
+    except OSError:
+        pass
