@@ -264,24 +264,41 @@ def train_bench(args, rank, world, device):
     return model, B * world * args.steps / dt, dt / args.steps * 1e3, final_loss, roof, launch_info
 
 
-def sampler_bench(args, model, device):
+F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md chip table (= the fp32 vector rate)
+
+
+def sampler_bench(args, model, device, network_dtype="bf16"):
+    """32-step Heun solve (63 network evaluations) of the CIFAR-10 net, hipGraph-captured.  network_dtype "bf16": the
+    training path's kernels; "f32": the reference-precision evaluation (exact-fp32 kernels, csrc/eval_f32.hip) -- the
+    reference itself samples in fp32 (generate.py:39-44)."""
     import tinyedm
+    from tinyedm_amd import _runtime_env as _RE
     model.eval()
+    model.denoiser.set_eval_dtype(network_dtype)
     solver = tinyedm.DeterministicSolver(num_steps=32)
-    B = args.sampler_batch
+    f32 = network_dtype == "f32"
+    B = args.sampler_f32_batch if f32 else args.sampler_batch
+    iters = 1 if f32 else args.sampler_iters
+    graph = _RE.GRAPH_REPLAY_SAFE
     g = torch.Generator().manual_seed(7)
     x0 = torch.randn(B, 3, 32, 32, generator=g).to(device)
-    note("sampler: warm-up + hipGraph capture")
-    solver.solve(model, x0, None, graph=True)          # capture + first replay
+    note(f"sampler ({network_dtype} network): warm-up" + (" + hipGraph capture" if graph else ""))
+    solver.solve(model, x0, None, graph=graph)         # capture + first replay
     torch.cuda.synchronize()
-    note("sampler: captured, timing replays")
+    note(f"sampler ({network_dtype} network): timing")
     t0 = time.perf_counter()
-    for _ in range(args.sampler_iters):
-        solver.solve(model, x0, None, graph=True)
+    for _ in range(iters):
+        out = solver.solve(model, x0, None, graph=graph)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.sampler_iters
+    dt = (time.perf_counter() - t0) / iters
+    if not bool(torch.isfinite(out).all()):
+        raise RuntimeError("bench: the sampler produced non-finite images")
+    model.denoiser.set_eval_dtype("bf16")
+    peak = F32_MFMA_PEAK_TFLOPS if f32 else MFMA_PEAK_TFLOPS
     return {"img_per_s": B / dt, "batch": B, "heun_steps": 32, "nfe": 63, "ms_per_solve": dt * 1e3,
-            "hipgraph": True, "state_dtype": "f32", "network_dtype": "bf16"}
+            "hipgraph": bool(graph), "state_dtype": "f32", "network_dtype": network_dtype,
+            "mfma_frac": round(B / dt * 63 * FWD_GFLOP_PER_IMG / 1e3 / peak, 4),
+            "mfma_peak_tflops": peak}
 
 
 def cpu_baseline(args):
@@ -347,6 +364,8 @@ def main():
     ap.add_argument("--sampler-batch", type=int, default=512)
     ap.add_argument("--sampler-iters", type=int, default=2)
     ap.add_argument("--no-sampler", action="store_true")
+    ap.add_argument("--no-sampler-fp32", action="store_true", help="skip the reference-precision (fp32 network) sampler leg")
+    ap.add_argument("--sampler-f32-batch", type=int, default=256)
     ap.add_argument("--step-launch", choices=["auto", "graph", "eager"], default="auto",
                     help="time the hipGraph replay of the step (with N > 1 ranks the RCCL all-reduces are nodes of the "
                          "graph), the eager Python step, or (auto) whichever a 10-step probe finds faster")
@@ -455,7 +474,9 @@ def main():
         # hipGraph capture beside a live RCCL communicator is avoided)
         if not args.no_sampler and world == 1:
             out["sampler"] = sampler_bench(args, model, device)
-            out["sampler"]["mfma_frac"] = round(out["sampler"]["img_per_s"] * 63 * FWD_GFLOP_PER_IMG / 1e3 / MFMA_PEAK_TFLOPS, 4)
+            if not args.no_sampler_fp32:
+                # the reference-faithful figure: the reference samples in fp32; priced against the f32-input MFMA peak
+                out["sampler_fp32"] = sampler_bench(args, model, device, "f32")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
     if dist.is_initialized():

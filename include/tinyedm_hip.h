@@ -254,6 +254,35 @@ int edm_heun_correct(const float* x, const float* dx, const float* x1, const flo
                      long n, unsigned* health, edm_stream_t stream);
 int edm_scale_f32(const float* x, float s, float* y, long n, edm_stream_t stream);
 
+/* ---------------------------------------------------------------- reference-precision evaluation (eval_f32.hip)
+ * The reference samples / validates in fp32 (generate.py:39-44, callbacks.py:41-49, solvers.py:43-59).  These entry
+ * points are the exact-fp32 forward: NHWC fp32 activations [pixels][channels], fp32 effective weights (the w_hat arrays
+ * of edm_weight_prep: [Cout][I*taps], master OIHW order), every convolution on v_mfma_f32_32x32x2_f32 (fp32 products,
+ * fp32 sums).  Forward only, eval semantics (no dropout, no in-place weight normalisation). */
+/* Y = alpha*conv(X, w_hat) + beta*R, or (lin != NULL) the block's modulation epilogue Y = mp_silu(alpha*conv *
+ * (lin[b,:]*gain + 1)) (networks.py:253-260).  taps in {1,9}; Cin % 8 (3x3) / % 32 (1x1); I <= Cin (X zero-padded). */
+int edm_f32_conv(const float* X, const float* w_hat, float* Y, const float* R, float alpha, float beta, const float* lin,
+                 long lin_stride, const float* gain, int B, int H, int W, int Cin, int I, int Cout, int taps,
+                 edm_stream_t stream);
+/* cosine attention (networks.py:194-202) on the qkv conv's own output order: channel head*3d + 3*dd + {q,k,v};
+ * y [B*N][C] with channel head*d + dd.  head_dim in {32, 64, 128}; 2*N*d*4 bytes of LDS. */
+int edm_f32_attention(const float* qkv, float* y, int B, int N, int C, int heads, edm_stream_t stream);
+int edm_f32_pixelnorm_silu(const float* x, float* xn, float* s, long P, int C, edm_stream_t stream);
+int edm_f32_silu(const float* x, float* s, long n, edm_stream_t stream);
+int edm_f32_pool2(const float* x, float* y, int B, int Hout, int Wout, int C, edm_stream_t stream);
+int edm_f32_up2(const float* x, float* y, int B, int Hout, int Wout, int C, edm_stream_t stream);
+/* ScaleLong gate of a skip tensor (networks.py:112-118): mean over H*W in a fixed order + the gate MLP, per sample */
+int edm_f32_skip_gate(const float* skip, const float* W1h, const float* W2h, float* gate, int B, int HW, int C, int R,
+                      edm_stream_t stream);
+int edm_f32_concat_gate(const float* inp, const float* skip, const float* gate, float* cat, float* silu_out, int B,
+                        int HW, int Ci, int Cs, edm_stream_t stream);
+int edm_f32_precond_in(const float* noisy, const float* sigma, int sigma_stride, float sigma_data, float* out, int B,
+                       int Cimg, int HW, int CP, edm_stream_t stream);
+int edm_f32_conv_out(const float* x, const float* w_hat, const float* gain_out, const float* noisy, const float* sigma,
+                     int sigma_stride, float sigma_data, float* D, int B, int HW, int C, int Co, edm_stream_t stream);
+int edm_f32_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, edm_stream_t stream);
+int edm_f32_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, edm_stream_t stream);
+
 /* ---------------------------------------------------------------- data formats either side of the path */
 /* resident uint8 dataset [N][C][H][W] -> fp32 NCHW batch: sample b = image index[b]; (x/255 - mean)/std with the
  * optional per-sample horizontal flip (datamodules/cifar10datamodule.py:18-32, mnistdatamodule.py:18-30). */

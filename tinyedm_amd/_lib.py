@@ -85,6 +85,19 @@ SIGNATURES = {
     "edm_weight_prep_multi": [P, P, I, I, I, P],
     "edm_wgrad_finish": [P, I, P, P, P, I, I, I, I, F, I, P],
     "edm_wgrad_finish_multi": [P, I, P],
+    # eval_f32.hip (reference-precision evaluation path)
+    "edm_f32_conv": [P, P, P, P, F, F, P, L, P, I, I, I, I, I, I, I, P],
+    "edm_f32_attention": [P, P, I, I, I, I, P],
+    "edm_f32_pixelnorm_silu": [P, P, P, L, I, P],
+    "edm_f32_silu": [P, P, L, P],
+    "edm_f32_pool2": [P, P, I, I, I, I, P],
+    "edm_f32_up2": [P, P, I, I, I, I, P],
+    "edm_f32_skip_gate": [P, P, P, P, I, I, I, I, P],
+    "edm_f32_concat_gate": [P, P, P, P, P, I, I, I, I, P],
+    "edm_f32_precond_in": [P, P, I, F, P, I, I, I, I, P],
+    "edm_f32_conv_out": [P, P, P, P, P, I, F, P, I, I, I, I, P],
+    "edm_f32_nchw_to_nhwc": [P, P, I, I, I, P],
+    "edm_f32_nhwc_to_nchw": [P, P, I, I, I, P],
     # data.hip
     "edm_u8_gather_normalize": [P, P, P, I, I, I, I, L, F, F, I, U64, U, P],
     "edm_denormalize_u8": [P, P, L, F, F, P],

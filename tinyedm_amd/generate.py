@@ -5,7 +5,9 @@ signature and the same command-line flags (`--ckpt_path --load_ema --output_dir 
     python -m tinyedm.generate --ckpt_path last.ckpt --load_ema --output_dir samples --num_samples 50000 \\
         --image_size 32 --num_classes 10 --batch_size 512
 
-Extensions (all optional): `--in_channels` (the reference's noise dataset hard-codes 3; default = the checkpoint's
+Extensions (all optional): `--network_dtype f32` evaluates the denoiser at the reference's precision (the reference samples
+in fp32, generate.py:39-44; default bf16: the training path's kernels, ~10x faster, 1.3e-3 from the fp32 trajectory),
+`--in_channels` (the reference's noise dataset hard-codes 3; default = the checkpoint's
 denoiser.in_channels), `--mean/--std` (default: the reference's CIFAR-10 constants), `--seed`, `--no_graph`, and
 `--config_name` to sample from random-init weights of a config instead of a checkpoint (plumbing runs).
 Multi-GPU = replicas only: under `python -m torch.distributed.run --nproc-per-node N` every rank samples
@@ -23,7 +25,8 @@ CIFAR_STD = (0.24703223, 0.24348513, 0.26158784)
 
 
 def generate(ckpt_path, load_ema, output_dir, num_samples, image_size, num_classes, batch_size, num_workers=16,
-             num_steps=32, *, in_channels=None, mean=None, std=None, seed=0, graph=True, model=None) -> None:
+             num_steps=32, *, in_channels=None, mean=None, std=None, seed=0, graph=True, model=None,
+             network_dtype="bf16") -> None:
     from .callbacks import PreditionWriter
     from .datamodules import RandomNoiseDataModule
     from .edm import EDM
@@ -36,6 +39,7 @@ def generate(ckpt_path, load_ema, output_dir, num_samples, image_size, num_class
     if model is None:
         model = EDM.load_from_checkpoint(ckpt_path, load_ema=load_ema)
     model = model.to(dev)
+    model.denoiser.set_eval_dtype(network_dtype)
     model.solver = DeterministicSolver(num_steps=num_steps)
     from . import _runtime_env
     if graph and _runtime_env.GRAPH_REPLAY_SAFE:      # otherwise the eager Heun loop: same values
@@ -73,6 +77,8 @@ def main(argv=None):
     parser.add_argument("--std", type=float, nargs="+", default=None)
     parser.add_argument("--seed", type=int, default=0)
     parser.add_argument("--no_graph", action="store_true", help="eager Heun loop instead of the captured hipGraph")
+    parser.add_argument("--network_dtype", choices=["bf16", "f32"], default="bf16",
+                        help="denoiser evaluation precision: f32 = the reference's (exact-fp32 kernels), bf16 = fast")
     parser.add_argument("--config_name", type=str, default=None,
                         help="sample from random-init weights of experiments/conf/<name>.yaml (no checkpoint)")
     parser.add_argument("--config_path", type=str, default=None)
@@ -90,7 +96,7 @@ def main(argv=None):
         model = instantiate(cfg.model)
     generate(args.ckpt_path, args.load_ema, args.output_dir, args.num_samples, args.image_size, args.num_classes,
              args.batch_size, args.num_workers, args.num_steps, in_channels=args.in_channels, mean=args.mean,
-             std=args.std, seed=args.seed, graph=not args.no_graph, model=model)
+             std=args.std, seed=args.seed, graph=not args.no_graph, model=model, network_dtype=args.network_dtype)
 
 
 if __name__ == "__main__":

@@ -639,6 +639,13 @@ class CosineAttention(nn.Module):
         y = self.forward_nhwc(ops.nchw_to_nhwc_bf16(x.float().contiguous()))
         return ops.nhwc_bf16_to_nchw(y).to(x.dtype)
 
+    def forward_f32(self, x: Tensor) -> Tensor:
+        """reference-precision evaluation (NHWC fp32 in / out): qkv conv in the master row order, exact-fp32 attention"""
+        qkv = ops.f32_conv(x, self.qkv_conv.packs()[2], 1)
+        y = ops.f32_attention(qkv, self.num_heads)
+        a, b = _mp_coeffs(0.5)
+        return ops.f32_conv(y, self.out_conv.packs()[2], 1, residual=x, alpha=b, beta=a)
+
 
 class _AttnFn(torch.autograd.Function):
     @staticmethod
@@ -824,6 +831,17 @@ class _BlockBase(nn.Module):
         return (out, ualias) if alias else out
 
 
+def _res_f32(blk, xres: Tensor, s: Tensor, lin: Tensor) -> Tensor:
+    """the residual branch of a block in the reference-precision evaluation path: conv3x3 -> modulation + mp_silu (fused
+    epilogue; eval: no dropout) -> conv3x3 + mp_add with the skip path (networks.py:253-263 / 317-327)"""
+    a2 = ops.f32_conv(s, blk.conv_3x3_1.packs()[2], 9, lin=lin, gain=blk.gain.detach())
+    a, b = _mp_coeffs(blk.add_factor)
+    out = ops.f32_conv(a2, blk.conv_3x3_2.packs()[2], 9, residual=xres, alpha=b, beta=a)
+    if isinstance(blk.attention, CosineAttention):
+        out = blk.attention.forward_f32(out)
+    return out
+
+
 def _as_nhwc(x: Tensor):
     """Accept the reference's NCHW float tensors at module boundaries; internal tensors are NHWC bf16."""
     if x.dtype == bf16 and getattr(x, "_edm_nhwc", False):
@@ -868,6 +886,15 @@ class EncoderBlock(_BlockBase):
         out = ops.nhwc_bf16_to_nchw(out).to(input.dtype) if conv else _tag(out)
         return (out, _tag(ualias)) if _alias else out
 
+    def forward_f32(self, x: Tensor, lin: Tensor) -> Tensor:
+        """networks.py:246-265 on NHWC fp32 activations (evaluation only); lin = this block's embed Linear output (B, C)"""
+        if isinstance(self.resample, DownSample):
+            x = ops.f32_pool2(x)
+        if isinstance(self.conv_1x1, Conv2d):
+            x = ops.f32_conv(x, self.conv_1x1.packs()[2], 1)
+        xn, s = ops.f32_pixelnorm_silu(x)
+        return _res_f32(self, xn, s, lin)
+
 
 class DecoderBlock(_BlockBase):
     """networks.py:268-329."""
@@ -901,6 +928,21 @@ class DecoderBlock(_BlockBase):
             s_pre = None
         out = self._res(x, None if _lin is not None else _emb32(embedding, x.shape[0]), _lin, s_pre)
         return ops.nhwc_bf16_to_nchw(out).to(input.dtype) if conv else _tag(out)
+
+    def forward_f32(self, x: Tensor, lin: Tensor, skip: Tensor | None = None) -> Tensor:
+        """networks.py:306-329 on NHWC fp32 activations (evaluation only)"""
+        s = None
+        if skip is not None:
+            cf = self.cat_factor
+            gate = ops.f32_skip_gate(skip, cf.layer1.packs()[2], cf.layer2.packs()[2])
+            x, s = ops.f32_concat_gate(x, skip, gate, not isinstance(self.resample, UpSample))
+        if isinstance(self.resample, UpSample):
+            x = ops.f32_up2(x)
+            s = None
+        xres = ops.f32_conv(x, self.conv_1x1.packs()[2], 1) if isinstance(self.conv_1x1, Conv2d) else x
+        if s is None:
+            s = ops.f32_silu(x)
+        return _res_f32(self, xres, s, lin)
 
 
 def _emb32(embedding: Tensor, B: int) -> Tensor:
@@ -1154,9 +1196,55 @@ class Denoiser(nn.Module):
             plan = self._plan = _PrepPlan(mods)
         plan.run(self.training)
 
+    # ---- reference-precision evaluation (round 3): the reference samples / validates in fp32 (generate.py:39-44,
+    # callbacks.py:41-49).  eval_dtype "f32" routes EVAL-mode forwards (no grad) through the exact-fp32 kernels of
+    # csrc/eval_f32.hip (fp32 activations, fp32 effective weights, v_mfma_f32_32x32x2_f32); training is unaffected.
+    eval_dtype = "bf16"
+
+    def set_eval_dtype(self, dtype: str) -> "Denoiser":
+        """"bf16" (default: the training path's kernels) or "f32" (reference precision, ~10x slower)"""
+        dtype = {"float32": "f32", "fp32": "f32", "bfloat16": "bf16"}.get(str(dtype).replace("torch.", ""), str(dtype))
+        if dtype not in ("bf16", "f32"):
+            raise ValueError("Denoiser.set_eval_dtype: 'bf16' or 'f32'")
+        if dtype == "f32":          # every conv also keeps its fp32 effective weight ("hat") from now on
+            for m in self.modules():
+                if isinstance(m, _WNBase) and "hat" not in m._want:
+                    m._want = tuple(m._want) + ("hat",)
+                    m._cache = None
+            self._plan = None
+        self.eval_dtype = dtype
+        return self
+
+    def _forward_f32(self, noisy: Tensor, sig: Tensor, emb: Tensor) -> Tensor:
+        blocks = self._res_blocks()
+        lin_all = ops.linear_fwd(emb, torch.cat([b.embed.packs()[2] for b in blocks], 0))
+        lins, off = {}, 0
+        for b in blocks:
+            C = b.embed.weight.shape[0]
+            lins[b] = lin_all[:, off:off + C]
+            off += C
+        cp = 8 * ((self.in_channels + 1 + 7) // 8)
+        x = ops.f32_conv(ops.f32_precond_in(noisy, sig, self.sigma_data, cp), self.conv_in.packs()[2], 9)
+        skips = [x]
+        for block in self.encoder_blocks:
+            x = block.forward_f32(x, lins[block])
+            skips.append(x)
+        for block, has_skip in zip(self.decoder_blocks, self.skip_connections):
+            x = block.forward_f32(x, lins[block], skips.pop() if has_skip else None)
+        return ops.f32_conv_out(x, self.conv_out.packs()[2], self.gain_out.detach(), noisy, sig, self.sigma_data)
+
     def forward(self, noisy_image: Tensor, sigma: Tensor, embedding: Tensor):
         if not noisy_image.is_cuda:
             raise RuntimeError("tinyedm_amd.Denoiser: inputs must be GPU tensors (there is no CPU path)")
+        if self.eval_dtype == "f32" and not self.training:
+            if torch.is_grad_enabled() and (noisy_image.requires_grad or embedding.requires_grad):
+                raise RuntimeError("tinyedm_amd.Denoiser: the fp32 evaluation path is forward-only (use torch.no_grad())")
+            with torch.no_grad():
+                self._prep_all()
+                noisy = noisy_image.float().contiguous()
+                D = self._forward_f32(noisy, sigma.detach().float().flatten().contiguous(),
+                                      _emb32(embedding.detach(), noisy.shape[0]))
+            return D.to(noisy_image.dtype)
         reset_backward_state()
         if self.training and torch.is_grad_enabled():
             global FORWARD_EPOCH

@@ -942,6 +942,137 @@ def scale_f32(x, s):
     return y
 
 
+# ------------------------------------------------------------------ reference-precision evaluation (csrc/eval_f32.hip)
+def _nhwc32(t, name):
+    _chk(t, f32, name)
+    if t.dim() != 4:
+        raise ValueError(f"{name}: expected (B,H,W,C)")
+    return t.shape
+
+
+def f32_conv(x, w_hat, taps, residual=None, alpha=1.0, beta=0.0, lin=None, gain=None):
+    """x (B,H,W,Cin) fp32 NHWC, w_hat (Cout, I*taps) fp32 (master OIHW order, I <= Cin) -> (B,H,W,Cout) fp32:
+    alpha*conv + beta*residual, or with lin/gain the block's modulation epilogue mp_silu(alpha*conv*(lin*gain+1))."""
+    B, H, W, Cin = _nhwc32(x, "x")
+    _chk(w_hat, f32, "w_hat")
+    if w_hat.dim() != 2 or w_hat.shape[1] % taps:
+        raise ValueError(f"f32_conv: w_hat {tuple(w_hat.shape)} does not match taps={taps}")
+    Cout, I = w_hat.shape[0], w_hat.shape[1] // taps
+    if I > Cin:
+        raise ValueError(f"f32_conv: weight has {I} input channels, x only {Cin}")
+    if residual is not None:
+        _chk(residual, f32, "residual", (B, H, W, Cout))
+    ls = 0
+    if lin is not None:
+        ls = _lin_view(lin, B, Cout, "lin")
+        _chk(gain, f32, "gain")
+    y = torch.empty(B, H, W, Cout, device=x.device, dtype=f32)
+    with _prof("f32_conv3x3" if taps == 9 else "f32_conv1x1", 2.0 * B * H * W * I * Cout * taps,
+               4.0 * (B * H * W * (Cin + Cout * (2 if residual is not None else 1)) + w_hat.numel())):
+        _lib.call("edm_f32_conv", _p(x), _p(w_hat), _p(y), _p(residual), float(alpha), float(beta), _p(lin), ls, _p(gain),
+                  B, H, W, Cin, I, Cout, taps, _stream())
+    return y
+
+
+def f32_attention(qkv, heads):
+    B, H, W, C3 = _nhwc32(qkv, "qkv")
+    C = C3 // 3
+    y = torch.empty(B, H, W, C, device=qkv.device, dtype=f32)
+    N = H * W
+    with _prof("f32_attention", 4.0 * B * N * N * C, 4.0 * B * N * 4 * C):
+        _lib.call("edm_f32_attention", _p(qkv), _p(y), B, N, C, heads, _stream())
+    return y
+
+
+def f32_pixelnorm_silu(x):
+    B, H, W, C = _nhwc32(x, "x")
+    xn, s = torch.empty_like(x), torch.empty_like(x)
+    _lib.call("edm_f32_pixelnorm_silu", _p(x), _p(xn), _p(s), B * H * W, C, _stream())
+    return xn, s
+
+
+def f32_silu(x):
+    _chk(x, f32, "x")
+    s = torch.empty_like(x)
+    _lib.call("edm_f32_silu", _p(x), _p(s), x.numel(), _stream())
+    return s
+
+
+def f32_pool2(x):
+    B, H, W, C = _nhwc32(x, "x")
+    if H % 2 or W % 2:
+        raise ValueError("f32_pool2: H and W must be even")
+    y = torch.empty(B, H // 2, W // 2, C, device=x.device, dtype=f32)
+    _lib.call("edm_f32_pool2", _p(x), _p(y), B, H // 2, W // 2, C, _stream())
+    return y
+
+
+def f32_up2(x):
+    B, H, W, C = _nhwc32(x, "x")
+    y = torch.empty(B, 2 * H, 2 * W, C, device=x.device, dtype=f32)
+    _lib.call("edm_f32_up2", _p(x), _p(y), B, 2 * H, 2 * W, C, _stream())
+    return y
+
+
+def f32_skip_gate(skip, w1h, w2h):
+    B, H, W, C = _nhwc32(skip, "skip")
+    R = w1h.shape[0]
+    _chk(w1h, f32, "w1h", (R, C + 1))
+    _chk(w2h, f32, "w2h", (C, R))
+    gate = torch.empty(B, C, device=skip.device, dtype=f32)
+    _lib.call("edm_f32_skip_gate", _p(skip), _p(w1h), _p(w2h), _p(gate), B, H * W, C, R, _stream())
+    return gate
+
+
+def f32_concat_gate(inp, skip, gate, want_silu):
+    B, H, W, Ci = _nhwc32(inp, "inp")
+    Bs, Hs, Ws, Cs = _nhwc32(skip, "skip")
+    if (Bs, Hs, Ws) != (B, H, W):
+        raise ValueError("f32_concat_gate: inp/skip spatial mismatch")
+    _chk(gate, f32, "gate", (B, Cs))
+    cat = torch.empty(B, H, W, Ci + Cs, device=inp.device, dtype=f32)
+    sil = torch.empty_like(cat) if want_silu else None
+    _lib.call("edm_f32_concat_gate", _p(inp), _p(skip), _p(gate), _p(cat), _p(sil), B, H * W, Ci, Cs, _stream())
+    return cat, sil
+
+
+def f32_precond_in(noisy, sigma, sigma_data, CP):
+    _chk(noisy, f32, "noisy")
+    B, Cimg, H, W = noisy.shape
+    ss = _sigma_arg(sigma, B)
+    out = torch.empty(B, H, W, CP, device=noisy.device, dtype=f32)
+    _lib.call("edm_f32_precond_in", _p(noisy), _p(sigma), ss, float(sigma_data), _p(out), B, Cimg, H * W, CP, _stream())
+    return out
+
+
+def f32_conv_out(x, w_hat, gain_out, noisy, sigma, sigma_data):
+    B, H, W, C = _nhwc32(x, "x")
+    Co = w_hat.shape[0]
+    _chk(w_hat, f32, "w_hat", (Co, C))
+    _chk(noisy, f32, "noisy", (B, Co, H, W))
+    _chk(gain_out, f32, "gain_out")
+    ss = _sigma_arg(sigma, B)
+    D = torch.empty(B, Co, H, W, device=x.device, dtype=f32)
+    _lib.call("edm_f32_conv_out", _p(x), _p(w_hat), _p(gain_out), _p(noisy), _p(sigma), ss, float(sigma_data), _p(D), B,
+              H * W, C, Co, _stream())
+    return D
+
+
+def f32_nchw_to_nhwc(x):
+    _chk(x, f32, "x")
+    B, C, H, W = x.shape
+    y = torch.empty(B, H, W, C, device=x.device, dtype=f32)
+    _lib.call("edm_f32_nchw_to_nhwc", _p(x), _p(y), B, C, H * W, _stream())
+    return y
+
+
+def f32_nhwc_to_nchw(x):
+    B, H, W, C = _nhwc32(x, "x")
+    y = torch.empty(B, C, H, W, device=x.device, dtype=f32)
+    _lib.call("edm_f32_nhwc_to_nchw", _p(x), _p(y), B, C, H * W, _stream())
+    return y
+
+
 # ------------------------------------------------------------------ data formats (csrc/data.hip)
 def u8_gather_normalize(data, index, mean=0.5, std=0.5, flip=False, seed=0, epoch=0):
     """data uint8 (N,C,H,W) resident on the device, index int64 (B,) -> fp32 (B,C,H,W) = (x/255-mean)/std,
