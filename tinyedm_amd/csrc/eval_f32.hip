@@ -30,23 +30,28 @@ inline int gridf(long work, int block, int cap = 256 * 16) {
 // 32 x 32.  MFMA roles: A = pixels (rows of the result), B = weights, so a lane holds ONE channel of 16 pixels and a
 // store instruction covers two 128-byte row segments.  Operands are staged K-MAJOR in LDS ([k][row]): a fragment read
 // is 64 consecutive words.  The pixel slab of a chunk (tile + halo rows) is staged once and shared by the nine taps as a
-// constant row shift (border taps masked per lane); both operands are register-prefetched one chunk ahead.
-constexpr int BM = 256, BN = 128;
+// constant row shift (border taps masked per lane); both operands are register-prefetched one chunk ahead.  WM = pixel
+// quarters per workgroup: 4 (256-pixel tile, 512 threads) or 2 (128-pixel tile, 256 threads: small feature maps, where
+// the big tile would leave CUs without a workgroup).  Weight rows are padded to BN + 1 words so that the scattered
+// staging stores of one master row (18 lanes, same column, different (tap, k)) land in different banks.
+constexpr int BN = 128, BNP = BN + 1;
 
-template <int TAPS, int KC>
-__global__ __launch_bounds__(512) void k_conv_f32(const float* __restrict__ X, const float* __restrict__ Wh,
+template <int TAPS, int KC, int WM>
+__global__ __launch_bounds__(128 * WM) void k_conv_f32(const float* __restrict__ X, const float* __restrict__ Wh,
                                                     float* __restrict__ Y, const float* __restrict__ R, float alpha,
                                                     float beta, const float* __restrict__ lin, long lin_stride,
                                                     const float* __restrict__ gain, int HW, int Npix, int H, int W,
                                                     int Cin, int I, int Cout, int tiles_m, int tiles_n, int XR) {
+  constexpr int BM = 64 * WM, NT = 128 * WM;
   constexpr int UPRW = KC * TAPS / 4;                 // float4 units per weight row and chunk
-  constexpr int NWU = (BN * UPRW + 511) / 512;        // weight units per thread
+  constexpr int NWU = (BN * UPRW + NT - 1) / NT;      // weight units per thread
+  constexpr int NXU = TAPS == 9 ? (WM == 4 ? 2 : 3) : 4;   // slab units per thread: (BM + 2*65) * XQ <= NXU * NT
   constexpr int XQ = KC / 4;                          // float4 units per slab row
   extern __shared__ __attribute__((aligned(16))) float smf[];
   const int HALO = TAPS == 9 ? W + 1 : 0;
   const int xrows = BM + 2 * HALO;
   float* const Xs = smf;                              // [2][KC][XR]
-  float* const Ws = smf + 2 * KC * XR;                // [2][TAPS][KC][BN]
+  float* const Ws = smf + 2 * KC * XR;                // [2][TAPS][KC][BNP]
 
   const int id = blockIdx.x;
   const int xcd = id & 7, kk = id >> 3;
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(512) void k_conv_f32(const float* __restrict__ X, c
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int wm = wave & 3, wn = wave >> 2;
+  const int wm = wave % WM, wn = wave / WM;
   const bool full_w = (I % KC == 0) && (I == Cin);   // weight rows hold whole chunks: aligned float4 loads
 
   // border masks of this lane's two pixels (bit t = tap t stays inside the image)
@@ -75,14 +80,13 @@ __global__ __launch_bounds__(512) void k_conv_f32(const float* __restrict__ X, c
     mask[j] = m < Npix ? mk : 0u;
   }
 
-  const int nxu = (xrows * XQ + 511) / 512;           // slab units per thread (<= 4, host-checked)
-  f32x4 xreg[4], wreg[NWU];
+  f32x4 xreg[NXU], wreg[NWU];                         // (xrows * XQ <= NXU * NT: host-checked)
   auto load_chunk = [&](int chunk) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NXU; ++i) {
       xreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int u = tid + 512 * i;
-      if (i < nxu && u < xrows * XQ) {
+      const int u = tid + NT * i;
+      if (u < xrows * XQ) {
         const int row = u / XQ, q = u % XQ;
         const long pix = (long)m0 - HALO + row;
         if (pix >= 0 && pix < Npix) xreg[i] = ld4(X + pix * Cin + chunk * KC + q * 4);
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(512) void k_conv_f32(const float* __restrict__ X, c
 #pragma unroll
     for (int i = 0; i < NWU; ++i) {
       wreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int u = tid + 512 * i;
+      const int u = tid + NT * i;
       if (u < BN * UPRW) {
         const int co = n0 + u / UPRW, f4 = u % UPRW;
         if (co < Cout) {
@@ -110,11 +114,11 @@ __global__ __launch_bounds__(512) void k_conv_f32(const float* __restrict__ X, c
   };
   auto store_chunk = [&](int buf) {
     float* xs = Xs + buf * KC * XR;
-    float* ws = Ws + buf * TAPS * KC * BN;
+    float* ws = Ws + buf * TAPS * KC * BNP;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int u = tid + 512 * i;
-      if (i < nxu && u < xrows * XQ) {
+    for (int i = 0; i < NXU; ++i) {
+      const int u = tid + NT * i;
+      if (u < xrows * XQ) {
         const int row = u / XQ, q = u % XQ;
 #pragma unroll
         for (int e = 0; e < 4; ++e) xs[(q * 4 + e) * XR + row] = xreg[i][e];
@@ -122,13 +126,13 @@ __global__ __launch_bounds__(512) void k_conv_f32(const float* __restrict__ X, c
     }
 #pragma unroll
     for (int i = 0; i < NWU; ++i) {
-      const int u = tid + 512 * i;
+      const int u = tid + NT * i;
       if (u < BN * UPRW) {
         const int col = u / UPRW, f4 = u % UPRW;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int f = f4 * 4 + e;                   // flat (ci_local, tap) index of the master row
-          ws[((f % TAPS) * KC + f / TAPS) * BN + col] = wreg[i][e];
+          ws[((f % TAPS) * KC + f / TAPS) * BNP + col] = wreg[i][e];
         }
       }
     }
@@ -149,8 +153,8 @@ __global__ __launch_bounds__(512) void k_conv_f32(const float* __restrict__ X, c
   for (int c = 0; c < nchunks; ++c) {
     if (c + 1 < nchunks) load_chunk(c + 1);
     const float* xs = Xs + (c & 1) * KC * XR + wm * 64 + l31 + HALO;
-    const float* ws = Ws + (c & 1) * TAPS * KC * BN + wn * 64 + l31;
-#pragma unroll 1
+    const float* ws = Ws + (c & 1) * TAPS * KC * BNP + wn * 64 + l31;
+#pragma unroll 3
     for (int t = 0; t < TAPS; ++t) {
       const int shift = TAPS == 9 ? (t / 3 - 1) * W + (t % 3 - 1) : 0;
       const bool v0 = (mask[0] >> t) & 1, v1 = (mask[1] >> t) & 1;
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(512) void k_conv_f32(const float* __restrict__ X, c
         float a0 = xs[k * XR + shift], a1 = xs[k * XR + 32 + shift];
         a0 = v0 ? a0 : 0.f;
         a1 = v1 ? a1 : 0.f;
-        const float b0 = ws[(t * KC + k) * BN], b1 = ws[(t * KC + k) * BN + 32];
+        const float b0 = ws[(t * KC + k) * BNP], b1 = ws[(t * KC + k) * BNP + 32];
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -193,23 +197,24 @@ __global__ __launch_bounds__(512) void k_conv_f32(const float* __restrict__ X, c
     }
 }
 
-template <int TAPS, int KC>
+template <int TAPS, int KC, int WM>
 void launch_conv(const float* X, const float* Wh, float* Y, const float* R, float alpha, float beta, const float* lin,
                  long lin_stride, const float* gain, int B, int H, int W, int Cin, int I, int Cout, hipStream_t st) {
+  constexpr int BM = 64 * WM;
   const int Npix = B * H * W;
   const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + BN - 1) / BN;
   const int xrows = BM + (TAPS == 9 ? 2 * (W + 1) : 0);
   const int XR = (xrows + 31) / 32 * 32 + 4;
-  const size_t lds = ((size_t)2 * KC * XR + (size_t)2 * TAPS * KC * BN) * sizeof(float);
+  const size_t lds = ((size_t)2 * KC * XR + (size_t)2 * TAPS * KC * BNP) * sizeof(float);
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
-  auto kern = k_conv_f32<TAPS, KC>;
+  auto kern = k_conv_f32<TAPS, KC, WM>;
   static std::atomic<bool> attr_set{false};  // (idempotent call: a race only repeats it)
   if (!attr_set.load(std::memory_order_acquire)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set.store(true, std::memory_order_release);
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, X, Wh, Y, R, alpha, beta, lin, lin_stride, gain, H * W, Npix, H,
-                     W, Cin, I, Cout, tiles_m, tiles_n, XR);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WM), lds, st, X, Wh, Y, R, alpha, beta, lin, lin_stride, gain, H * W,
+                     Npix, H, W, Cin, I, Cout, tiles_m, tiles_n, XR);
 }
 
 // ------------------------------------------------------------------------------------------------ attention
@@ -490,12 +495,16 @@ extern "C" int edm_f32_conv(const float* X, const float* w_hat, float* Y, const 
   EDM_REQUIRE(Cout > 0 && I > 0 && I <= Cin, "f32_conv: bad channel counts");
   EDM_REQUIRE(!lin || (gain && lin_stride >= Cout), "f32_conv: modulation epilogue needs gain and lin_stride >= Cout");
   EDM_REQUIRE(taps == 1 || W <= 64, "f32_conv: W > 64 unsupported for 3x3");
+  // the 256-pixel tile when it gives (nearly) every CU a workgroup, else the 128-pixel tile
+  const long big = (((long)B * H * W + 255) / 256) * ((Cout + BN - 1) / BN);
   if (taps == 9) {
     EDM_REQUIRE(Cin % 8 == 0, "f32_conv: Cin %% 8 required (3x3)");
-    launch_conv<9, 8>(X, w_hat, Y, R, alpha, beta, lin, lin_stride, gain, B, H, W, Cin, I, Cout, st);
+    if (big >= 200) launch_conv<9, 8, 4>(X, w_hat, Y, R, alpha, beta, lin, lin_stride, gain, B, H, W, Cin, I, Cout, st);
+    else launch_conv<9, 8, 2>(X, w_hat, Y, R, alpha, beta, lin, lin_stride, gain, B, H, W, Cin, I, Cout, st);
   } else {
     EDM_REQUIRE(Cin % 32 == 0, "f32_conv: Cin %% 32 required (1x1)");
-    launch_conv<1, 32>(X, w_hat, Y, R, alpha, beta, lin, lin_stride, gain, B, H, W, Cin, I, Cout, st);
+    if (big >= 200) launch_conv<1, 32, 4>(X, w_hat, Y, R, alpha, beta, lin, lin_stride, gain, B, H, W, Cin, I, Cout, st);
+    else launch_conv<1, 32, 2>(X, w_hat, Y, R, alpha, beta, lin, lin_stride, gain, B, H, W, Cin, I, Cout, st);
   }
   EDM_CHECK_LAUNCH("f32_conv");
   return EDM_OK;
