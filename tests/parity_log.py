@@ -11,7 +11,9 @@ _records = {}
 def record(name: str, err: float, limit: float) -> None:
     prev = _records.get(name)
     if prev is None or err > prev["err"]:
-        _records[name] = {"err": float(err), "limit": float(limit), "margin": float(limit) / max(float(err), 1e-30)}
+        # margin = limit / err; an exact-equality check (limit 0) that measured 0 has no finite margin: recorded as null
+        margin = None if (limit == 0 and err == 0) else float(limit) / max(float(err), 1e-30)
+        _records[name] = {"err": float(err), "limit": float(limit), "margin": margin}
 
 
 def dump() -> None:

@@ -62,6 +62,9 @@ def imagenet_cfg(channels=4):
 
 
 def eval_parity(ecfg, dcfg, shape, seed, tol):
+    """tol: HIP bf16 path vs the oracle with bf16 rounding points.  profiles/r03_error_growth.json: one bf16 evaluation of
+    the CIFAR-10 net sits 7-9e-3 from fp32 after ~5 blocks and stays there, two independent bf16 evaluations therefore
+    ~1e-2 apart (1.2-1.5e-2 on the deeper / wider nets): limits are 2.3-2.5x the measured values."""
     g = torch.Generator().manual_seed(seed)
     P = O.init_params(ecfg, dcfg, g)
     emb, den = build(ecfg, dcfg, P)
@@ -80,6 +83,17 @@ def eval_parity(ecfg, dcfg, shape, seed, tol):
     r = rel(D.cpu() - base, D_or - base)
     record(f"configs/eval_forward_vs_bf16_oracle[{tuple(shape)} emb{ecfg.embedding_dim}]", r, tol)
     assert r <= tol, f"eval forward rel {r:.3e}"
+    # the reference-precision path against the FP32 oracle (head dims the fp32 attention kernel is built for)
+    if all(c // dcfg.num_heads in (32, 64, 128) for c, t in zip(list(dcfg.encoder_out_channels) + list(dcfg.decoder_out_channels),
+                                                               list(dcfg.encoder_block_types) + list(dcfg.decoder_block_types))
+           if t.endswith("A")):
+        den.set_eval_dtype("f32")
+        with torch.no_grad():
+            D32 = den(noisy.to(DEV), sigma.to(DEV), e)
+        den.set_eval_dtype("bf16")
+        r32 = rel(D32.cpu() - base, O.edm_forward(P, ecfg, dcfg, noisy, sigma, labels, bf16=False) - base)
+        record(f"configs/eval_forward_f32_path_vs_fp32_oracle[{tuple(shape)} emb{ecfg.embedding_dim}]", r32, 1e-4)
+        assert r32 <= 1e-4, f"fp32 eval forward rel {r32:.3e}"
     return P, emb, den, (noisy, sigma, labels)
 
 
@@ -112,7 +126,7 @@ def train_smoke(emb, den, batch, P=None, ecfg=None, dcfg=None, loss_tol=None):
 
 def test_mnist_config_forward_and_training_step():
     ecfg, dcfg = mnist_cfg()
-    P, emb, den, batch = eval_parity(ecfg, dcfg, (2, 1, 28, 28), seed=11, tol=1.5e-2)
+    P, emb, den, batch = eval_parity(ecfg, dcfg, (2, 1, 28, 28), seed=11, tol=3e-2)
     den.dropout_rate = 0.0
     for m in den.modules():
         if hasattr(m, "dropout_rate"):
@@ -122,12 +136,12 @@ def test_mnist_config_forward_and_training_step():
 
 def test_cifar10_conditional_config_forward():
     ecfg, dcfg = O.cifar10_cfg(num_classes=10)
-    eval_parity(ecfg, dcfg, (3, 3, 32, 32), seed=5, tol=1.5e-2)
+    eval_parity(ecfg, dcfg, (3, 3, 32, 32), seed=5, tol=3e-2)
 
 
 def test_imagenet64_default_denoiser_forward_and_training_step():
     ecfg, dcfg = imagenet_cfg()
-    P, emb, den, batch = eval_parity(ecfg, dcfg, (1, 4, 64, 64), seed=3, tol=2e-2)
+    P, emb, den, batch = eval_parity(ecfg, dcfg, (1, 4, 64, 64), seed=3, tol=3.5e-2)
     train_smoke(emb, den, batch)
 
 
@@ -136,7 +150,7 @@ def test_imagenet64_pixel_config_training_step_loss_vs_oracle():
     eval forward and the training-mode loss against the oracle with the same bf16 rounding points; every parameter
     receives a finite gradient."""
     ecfg, dcfg = imagenet_cfg(channels=3)
-    P, emb, den, batch = eval_parity(ecfg, dcfg, (1, 3, 64, 64), seed=4, tol=2e-2)
+    P, emb, den, batch = eval_parity(ecfg, dcfg, (1, 3, 64, 64), seed=4, tol=3.5e-2)
     train_smoke(emb, den, batch, P, ecfg, dcfg, loss_tol=3e-2)
 
 
@@ -177,7 +191,7 @@ def test_latent32_hipgraph_32_step_sampler_matches_eager_loop():
 def test_latent32_default_denoiser_forward():
     """ImageNet-256 latent diffusion: the same default net on 32x32x4 latents (attention at 8x8 and 4x4)."""
     ecfg, dcfg = imagenet_cfg()
-    eval_parity(ecfg, dcfg, (2, 4, 32, 32), seed=9, tol=2e-2)
+    eval_parity(ecfg, dcfg, (2, 4, 32, 32), seed=9, tol=3.5e-2)
 
 
 @pytest.mark.parametrize("name", ["mnist", "cifar10_cond", "default32"])

@@ -158,5 +158,15 @@ def test_cifar10_unconditional_forward_b128_vs_oracle():
     c_skip, _, _ = O.precond_scalars(sigma[IMGS], dcfg.sigma_data)
     base = c_skip * noisy[IMGS]
     err = rel(D[IMGS] - base, D_or - base)
-    record("fullsize/cifar10_uncond_B128_forward_vs_bf16_oracle", err, 1.5e-2)
-    assert err <= 1.5e-2, err
+    # (limit: profiles/r03_error_growth.json -- two independent bf16 evaluations of this net are ~1e-2 apart)
+    record("fullsize/cifar10_uncond_B128_forward_vs_bf16_oracle", err, 2.5e-2)
+    assert err <= 2.5e-2, err
+    # the same batch through the reference-precision path against the FP32 oracle
+    den.set_eval_dtype("f32")
+    with torch.no_grad():
+        D32 = den(noisy.to(DEV), sigma.to(DEV), e).cpu()
+        D_or32 = O.edm_forward(P, ecfg, dcfg, noisy[IMGS], sigma[IMGS], None, bf16=False)
+    den.set_eval_dtype("bf16")
+    err32 = rel(D32[IMGS] - base, D_or32 - base)
+    record("fullsize/cifar10_uncond_B128_forward_f32_path_vs_fp32_oracle", err32, 1e-4)
+    assert err32 <= 1e-4, err32

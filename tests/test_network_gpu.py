@@ -79,10 +79,21 @@ def test_eval_forward_matches_golden_and_oracle(tiny):
     # network part F*c_out (D - c_skip*x): compare on the residual so c_skip*x cannot hide errors
     c_skip, _, _ = O.precond_scalars(sigma, dcfg.sigma_data)
     base = c_skip * noisy
-    record("tiny_net/eval_D_vs_bf16_oracle", rel(D.cpu() - base, D_or - base), 1e-2)
-    record("tiny_net/eval_D_vs_reference_fp32", rel(D.cpu() - base, ref32 - base), max(2.0 * rel(refbf - base, ref32 - base), 5e-3))
-    assert rel(D.cpu() - base, D_or - base) <= 1e-2, rel(D.cpu() - base, D_or - base)
-    assert rel(D.cpu() - base, ref32 - base) <= max(2.0 * rel(refbf - base, ref32 - base), 5e-3)
+    # Limits from profiles/r03_error_growth.json: ONE bf16 evaluation of a network of this depth sits 7-9e-3 from the fp32
+    # result (4.4e-3 after the first block, saturating: the mp_add residual mix attenuates old error), so two independent
+    # bf16 evaluations (HIP vs the oracle with bf16 rounding points) differ by ~sqrt(2) x that ~ 1e-2: limit 2.5e-2.
+    record("tiny_net/eval_D_vs_bf16_oracle", rel(D.cpu() - base, D_or - base), 2.5e-2)
+    record("tiny_net/eval_D_vs_reference_fp32", rel(D.cpu() - base, ref32 - base), max(2.5 * rel(refbf - base, ref32 - base), 2e-2))
+    assert rel(D.cpu() - base, D_or - base) <= 2.5e-2, rel(D.cpu() - base, D_or - base)
+    assert rel(D.cpu() - base, ref32 - base) <= max(2.5 * rel(refbf - base, ref32 - base), 2e-2)
+    # the discriminating comparison: the reference-precision path against the REFERENCE's own fp32 output (golden)
+    den.set_eval_dtype("f32")
+    with torch.no_grad():
+        D32 = den(noisy.to(DEV), sigma.to(DEV), e)
+    den.set_eval_dtype("bf16")
+    e32 = rel(D32.cpu() - base, ref32 - base)
+    record("tiny_net/eval_D_f32_path_vs_reference_fp32", e32, 1e-4)
+    assert e32 <= 1e-4, e32
     # unconditional and scalar-sigma call patterns (solvers.py:48)
     with torch.no_grad():
         _, eu = emb(sigma.to(DEV), None)
