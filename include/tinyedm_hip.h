@@ -265,7 +265,7 @@ int edm_f32_conv(const float* X, const float* w_hat, float* Y, const float* R, f
                  long lin_stride, const float* gain, int B, int H, int W, int Cin, int I, int Cout, int taps,
                  edm_stream_t stream);
 /* cosine attention (networks.py:194-202) on the qkv conv's own output order: channel head*3d + 3*dd + {q,k,v};
- * y [B*N][C] with channel head*d + dd.  head_dim in {32, 64, 128}; 2*N*d*4 bytes of LDS. */
+ * y [B*N][C] with channel head*d + dd.  head_dim in {32, 64, 128, 144, 192}; any number of tokens (key tiles of 64). */
 int edm_f32_attention(const float* qkv, float* y, int B, int N, int C, int heads, edm_stream_t stream);
 int edm_f32_pixelnorm_silu(const float* x, float* xn, float* s, long P, int C, edm_stream_t stream);
 int edm_f32_silu(const float* x, float* s, long n, edm_stream_t stream);

@@ -84,9 +84,12 @@ def test_f32_conv_padded_input_channels_and_modulation_epilogue(ops):
     assert e <= 5e-6, e
 
 
-@pytest.mark.parametrize("B,H,W,heads,hd", [(2, 8, 8, 4, 64), (2, 16, 16, 4, 64), (3, 7, 7, 2, 32), (1, 4, 4, 2, 128)])
+@pytest.mark.parametrize("B,H,W,heads,hd", [(2, 8, 8, 4, 64), (2, 16, 16, 4, 64), (3, 7, 7, 2, 32), (1, 4, 4, 2, 128),
+                                            (1, 16, 16, 4, 144), (2, 8, 8, 4, 192), (1, 9, 9, 2, 144), (1, 20, 20, 2, 64),
+                                            (1, 32, 32, 1, 32)])
 def test_f32_attention_vs_fp64(ops, B, H, W, heads, hd):
-    """the reference's own arithmetic (networks.py:194-202) in fp64 on the reference channel interleaving"""
+    """the reference's own arithmetic (networks.py:194-202) in fp64 on the reference channel interleaving; head dims 144 /
+    192 (the default ImageNet net), ragged token counts and more than 256 tokens (key tiles of 64)"""
     g = torch.Generator().manual_seed(B + H + hd)
     C = heads * hd
     qkv = torch.randn(B, 3 * C, H, W, generator=g)

@@ -13,6 +13,7 @@
 //   edm_f32_*           the elementwise steps between them (networks.py:9-14, 72, 80, 83-84, 112-118, 311, 578-603)
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -218,74 +219,116 @@ void launch_conv(const float* X, const float* Wh, float* Y, const float* R, floa
 }
 
 // ------------------------------------------------------------------------------------------------ attention
-// One workgroup per (sample, head), one query per thread; K and V of the head live in LDS, pixel-normalised (fp32);
-// every thread walks the keys with an online softmax (m, l, acc[D] in registers) -- plain fp32 fma chains.  The qkv
-// tensor keeps the qkv conv's own channel order: channel head*3D + 3*dd + {0: q, 1: k, 2: v} (networks.py:194).
+// Any head_dim that is a multiple of 16, any token count.  FOUR threads share a query (each owns every fourth float4 of q
+// and of the output accumulator; a logit is two lane shuffles away), a workgroup owns 64 queries of one (sample, head),
+// and K / V stream through LDS in tiles of 64 keys, pixel-normalised as they are staged (four threads per key); online
+// softmax in registers, plain fp32 fma chains.  The qkv tensor keeps the qkv conv's own channel order: channel
+// head*3D + 3*dd + {0: q, 1: k, 2: v} (networks.py:194).  (A first form -- one query per thread, K and V of the whole
+// head resident in LDS -- ran at 17 TF/s on the 16x16 layers and could not hold head_dim 144 / 192; this one: 30.)
 template <int D>
-__global__ __launch_bounds__(256) void k_attn_f32(const float* __restrict__ qkv, float* __restrict__ y, int N, int C,
-                                                    int heads) {
-  extern __shared__ __attribute__((aligned(16))) float sma[];
-  float* Ks = sma;                // [N][D]
-  float* Vs = sma + (size_t)N * D;
+__global__ __launch_bounds__(256) void k_attn_f32_g(const float* __restrict__ qkv, float* __restrict__ y, int N, int C,
+                                                      int heads) {
+  constexpr int TK = 64, NV = D / 16;      // keys per tile; float4s of q / acc per thread
+  __shared__ __attribute__((aligned(16))) float Ks[TK * D];
+  __shared__ __attribute__((aligned(16))) float Vs[TK * D];
   const int b = blockIdx.x / heads, head = blockIdx.x % heads;
   const float* base = qkv + ((long)b * N) * 3 * C + (long)head * 3 * D;
   const float rsd = 1.0f / sqrtf((float)D);
-  // stage K, V: one token per thread per pass
-  for (int j = threadIdx.x; j < N; j += blockDim.x) {
-    const float* row = base + (long)j * 3 * C;
-    float ssk = 0.f, ssv = 0.f;
-    for (int d = 0; d < D; ++d) {
-      const float kx = row[3 * d + 1], vx = row[3 * d + 2];
-      ssk += kx * kx;
-      ssv += vx * vx;
-    }
-    const float ik = 1.0f / (NORM_EPS + sqrtf(ssk) * rsd), iv = 1.0f / (NORM_EPS + sqrtf(ssv) * rsd);
-    for (int d = 0; d < D; ++d) {
-      Ks[j * D + d] = row[3 * d + 1] * ik;
-      Vs[j * D + d] = row[3 * d + 2] * iv;
-    }
-  }
-  __syncthreads();
-  for (int qi = threadIdx.x; qi < N; qi += blockDim.x) {
-    const float* row = base + (long)qi * 3 * C;
-    float q[D], acc[D];
+  const int part = threadIdx.x & 3, ql = threadIdx.x >> 2;
+  const int qi = blockIdx.y * 64 + ql;
+  const bool qok = qi < N;
+  f32x4 q[NV], acc[NV];
+  {
+    const float* row = base + (long)(qok ? qi : 0) * 3 * C;
     float ss = 0.f;
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      q[d] = row[3 * d];
-      ss += q[d] * q[d];
-      acc[d] = 0.f;
-    }
-    const float iq = rsd / (NORM_EPS + sqrtf(ss) * rsd);   // pixel norm and the 1/sqrt(d) of the logits, folded
+    for (int i = 0; i < NV; ++i) {
+      const int d0 = (i * 4 + part) * 4;
 #pragma unroll
-    for (int d = 0; d < D; ++d) q[d] *= iq;
-    float m = -INFINITY, l = 0.f;
-    for (int j = 0; j < N; ++j) {
-      const float* kr = Ks + j * D;
+      for (int e = 0; e < 4; ++e) {
+        q[i][e] = row[3 * (d0 + e)];
+        ss += q[i][e] * q[i][e];
+        acc[i][e] = 0.f;
+      }
+    }
+    ss += __shfl_xor(ss, 1, 64);
+    ss += __shfl_xor(ss, 2, 64);
+    const float iq = rsd / (NORM_EPS + sqrtf(ss) * rsd);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) q[i][e] *= iq;
+  }
+  float m = -INFINITY, l = 0.f;
+  for (int k0 = 0; k0 < N; k0 += TK) {
+    __syncthreads();                       // the previous tile's readers are done
+    {
+      const int kj = k0 + ql;              // this thread stages its quarter of key kj (4 threads per key)
+      const float* row = base + (long)(kj < N ? kj : 0) * 3 * C;
+      f32x4 kv[NV], vv[NV];
+      float ssk = 0.f, ssv = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int d0 = (i * 4 + part) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          kv[i][e] = row[3 * (d0 + e) + 1];
+          vv[i][e] = row[3 * (d0 + e) + 2];
+          ssk += kv[i][e] * kv[i][e];
+          ssv += vv[i][e] * vv[i][e];
+        }
+      }
+      ssk += __shfl_xor(ssk, 1, 64);
+      ssk += __shfl_xor(ssk, 2, 64);
+      ssv += __shfl_xor(ssv, 1, 64);
+      ssv += __shfl_xor(ssv, 2, 64);
+      const float ik = 1.0f / (NORM_EPS + sqrtf(ssk) * rsd), iv = 1.0f / (NORM_EPS + sqrtf(ssv) * rsd);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int d0 = (i * 4 + part) * 4;
+        f32x4 a = kv[i], c = vv[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[e] *= ik;
+          c[e] *= iv;
+        }
+        st4(Ks + ql * D + d0, a);
+        st4(Vs + ql * D + d0, c);
+      }
+    }
+    __syncthreads();
+    const int nk = min(TK, N - k0);
+    for (int j = 0; j < nk; ++j) {
       float s = 0.f;
 #pragma unroll
-      for (int d = 0; d < D; d += 4) {
-        const f32x4 kv = ld4(kr + d);
-        s += q[d] * kv[0] + q[d + 1] * kv[1] + q[d + 2] * kv[2] + q[d + 3] * kv[3];
+      for (int i = 0; i < NV; ++i) {
+        const f32x4 kk = ld4(Ks + j * D + (i * 4 + part) * 4);
+        s += q[i][0] * kk[0] + q[i][1] * kk[1] + q[i][2] * kk[2] + q[i][3] * kk[3];
       }
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
       const float mn = fmaxf(m, s);
       const float corr = __expf(m - mn), p = __expf(s - mn);
       l = l * corr + p;
-      const float* vr = Vs + j * D;
 #pragma unroll
-      for (int d = 0; d < D; d += 4) {
-        const f32x4 vv = ld4(vr + d);
-        acc[d] = acc[d] * corr + p * vv[0];
-        acc[d + 1] = acc[d + 1] * corr + p * vv[1];
-        acc[d + 2] = acc[d + 2] * corr + p * vv[2];
-        acc[d + 3] = acc[d + 3] * corr + p * vv[3];
+      for (int i = 0; i < NV; ++i) {
+        const f32x4 vv = ld4(Vs + j * D + (i * 4 + part) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][e] = acc[i][e] * corr + p * vv[e];
       }
       m = mn;
     }
+  }
+  if (qok) {
     const float il = 1.0f / l;
     float* dst = y + ((long)b * N + qi) * C + head * D;
 #pragma unroll
-    for (int d = 0; d < D; d += 4) st4(dst + d, f32x4{acc[d] * il, acc[d + 1] * il, acc[d + 2] * il, acc[d + 3] * il});
+    for (int i = 0; i < NV; ++i) {
+      f32x4 o = acc[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] *= il;
+      st4(dst + (i * 4 + part) * 4, o);
+    }
   }
 }
 
@@ -510,31 +553,23 @@ extern "C" int edm_f32_conv(const float* X, const float* w_hat, float* Y, const 
   return EDM_OK;
 }
 
-// qkv [B*N][3C] fp32 in the qkv conv's own channel order (head*3d + 3*dd + {q,k,v}) -> y [B*N][C] fp32 (head*d + dd)
+// qkv [B*N][3C] fp32 in the qkv conv's own channel order (head*3d + 3*dd + {q,k,v}) -> y [B*N][C] fp32 (head*d + dd).
+// head_dim in {32, 64, 128, 144, 192} (every configuration of the reference); any number of tokens.
 extern "C" int edm_f32_attention(const float* qkv, float* y, int B, int N, int C, int heads, hipStream_t st) {
   EDM_REQUIRE(qkv && y && B > 0 && N > 0 && heads > 0 && C > 0 && C % heads == 0, "f32_attention: bad args");
   const int D = C / heads;
-  const size_t lds = (size_t)2 * N * D * sizeof(float);
-  EDM_REQUIRE(lds <= 160 * 1024, "f32_attention: %d tokens x head_dim %d does not fit LDS", N, D);
-#define ATT(DV)                                                                                                        \
-  {                                                                                                                    \
-    static std::atomic<bool> attr_set{false};                                                                          \
-    if (!attr_set.load(std::memory_order_acquire)) {                                                                   \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_f32<DV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                160 * 1024);                                                                           \
-      attr_set.store(true, std::memory_order_release);                                                                 \
-    }                                                                                                                  \
-    hipLaunchKernelGGL(k_attn_f32<DV>, dim3(B * heads), dim3(N >= 256 ? 256 : (N + 63) / 64 * 64), lds, st, qkv, y, N, C, \
-                       heads);                                                                                         \
-  }
-  if (D == 64) ATT(64)
-  else if (D == 32) ATT(32)
-  else if (D == 128) ATT(128)
+#define ATTG(DV) \
+  hipLaunchKernelGGL(k_attn_f32_g<DV>, dim3(B * heads, (N + 63) / 64), dim3(256), 0, st, qkv, y, N, C, heads)
+  if (D == 32) ATTG(32);
+  else if (D == 64) ATTG(64);
+  else if (D == 128) ATTG(128);
+  else if (D == 144) ATTG(144);
+  else if (D == 192) ATTG(192);
   else {
-    edm_set_error("f32_attention: head_dim %d is not built (32, 64, 128 are)", D);
+    edm_set_error("f32_attention: head_dim %d is not built (32, 64, 128, 144, 192 are)", D);
     return EDM_ERR_UNSUPPORTED;
   }
-#undef ATT
+#undef ATTG
   EDM_CHECK_LAUNCH("f32_attention");
   return EDM_OK;
 }

@@ -35,10 +35,10 @@ for (HW, Cin, Cout, taps) in [(32, 256, 256, 9), (32, 512, 256, 9), (16, 256, 25
     ms = timeit(lambda: ops.f32_conv(x, w, taps))
     fl = 2.0 * B * HW * HW * Cin * Cout * taps
     print(f"conv {HW:2d}x{HW:<2d} {Cin:3d}->{Cout:3d} k{taps}: {ms * 1e3:9.1f} us {fl / ms / 1e9:7.1f} TF/s ({fl / ms / 1e9 / 157.3:.2f} of peak)", flush=True)
-for HW in (16, 8):
-    qkv = torch.randn(B, HW, HW, 768, device=dev)
+for HW, C in ((16, 256), (8, 256), (16, 576), (8, 768)):
+    qkv = torch.randn(B, HW, HW, 3 * C, device=dev)
     ms = timeit(lambda: ops.f32_attention(qkv, 4))
-    fl = 4.0 * B * (HW * HW) ** 2 * 256
-    print(f"attention {HW}x{HW}: {ms * 1e3:9.1f} us {fl / ms / 1e9:7.1f} TF/s", flush=True)
+    fl = 4.0 * B * (HW * HW) ** 2 * C
+    print(f"attention {HW}x{HW} d{C // 4}: {ms * 1e3:9.1f} us {fl / ms / 1e9:7.1f} TF/s", flush=True)
 x = torch.randn(B, 32, 32, 256, device=dev)
 print(f"pixelnorm_silu 32x32: {timeit(lambda: ops.f32_pixelnorm_silu(x)) * 1e3:.1f} us; silu {timeit(lambda: ops.f32_silu(x)) * 1e3:.1f} us", flush=True)
