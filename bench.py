@@ -183,9 +183,22 @@ def train_bench(args, rank, world, device):
                        "entry_point_calls_per_step": round(e_calls, 1)}
     if can_graph and mode in ("auto", "graph"):
         from tinyedm_amd.graph import CapturedTrainStep
-        captured = CapturedTrainStep(model, opt, reducer=reducer)
-        for i in range(CapturedTrainStep.WARMUP + 1):        # warm-up on the capture stream, then the capture itself
-            captured(batch)
+        captured, ok = None, 1
+        try:
+            captured = CapturedTrainStep(model, opt, reducer=reducer)
+            for i in range(CapturedTrainStep.WARMUP + 1):    # warm-up on the capture stream, then the capture itself
+                captured(batch)
+        except Exception as e:      # noqa: BLE001  (a runtime that cannot capture the collectives must not sink the line)
+            note(f"capturing the step failed ({type(e).__name__}: {str(e)[:200]}); timing the eager step")
+            ok = 0
+        if world > 1:               # every rank replays, or none does
+            flag = torch.tensor([ok], device=device, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if not ok:
+            can_graph, mode = False, "eager"
+            launch_info["graph_capture"] = "failed on at least one rank"
+    if can_graph and mode in ("auto", "graph"):
         for i in range(3):                                   # the first replays upload the executable graph
             captured(batch)
         g_ms, g_host, _ = probe(lambda i: captured(batch), 10)

@@ -6,8 +6,9 @@ import tinyedm_amd as _impl
 from tinyedm_amd import *  # noqa: F401,F403
 from tinyedm_amd import config, edm, ema, metric, networks, solvers, utils  # noqa: F401
 
+# (`generate` is a real shim module, tinyedm/generate.py, so that `python -m tinyedm.generate` runs)
 for _name in ("config", "edm", "ema", "metric", "networks", "solvers", "utils", "trainer", "datamodules", "callbacks",
-              "generate", "graph"):
+              "graph"):
     try:
         _mod = __import__(f"tinyedm_amd.{_name}", fromlist=["_"])
     except ImportError:
