@@ -100,6 +100,17 @@ int edm_conv_wgrad_v2(const void* X, const void* dY, float* slabs, int B, int H,
 int edm_conv_wgrad_1x1_nsplit(long npix, int Cin, int Cout);
 int edm_conv_wgrad_1x1(const void* X, const void* dY, float* slabs, long npix, int Cin, int Cout, int nsplit,
                        edm_stream_t stream);
+/* up to 16 1x1 layers in ONE launch (their (tile, split) workgroups laid end to end in one grid); `items` is a HOST array
+ * read during the call */
+typedef struct {
+  const void* X;   /* bf16 [npix][Cin] */
+  const void* dY;  /* bf16 [npix][Cout] */
+  float* slabs;    /* fp32 [nsplit][Cout][Cin], nsplit = edm_conv_wgrad_1x1_nsplit_grouped(npix, Cin, Cout) */
+  long npix;
+  int Cin, Cout, nsplit, pad;
+} edm_wgrad1_item;
+int edm_conv_wgrad_1x1_nsplit_grouped(long npix, int Cin, int Cout);
+int edm_conv_wgrad_1x1_group(const edm_wgrad1_item* items, int n, edm_stream_t stream);
 /* third generation, 3x3 layers, a GROUP of layers per call (autograd wgrad of networks.py:35-37 + the projection of
  * networks.py:32-36's normalisation): the reduction dimension of all layers is laid end to end and cut into equal
  * ranges, one per workgroup (128x64x9 tile, one wave per SIMD); partial tiles go to `workspace`; a second launch sums

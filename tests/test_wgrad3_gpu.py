@@ -126,3 +126,24 @@ def test_wgrad3_full_size_layers(ops):
         worst = max(worst, e)
         assert e <= 2e-3, f"full-size wgrad rel {e:.3e}"
     record("wgrad3_group[full-size B=128]", worst, 2e-3)
+
+
+def test_wgrad1x1_grouped_launch_matches_per_layer_kernels():
+    """edm_conv_wgrad_1x1_group: 1x1 layers of different shapes (ragged tiles, pixel counts that are not a multiple of the
+    stage, 16 layers = the maximum) in ONE launch against an fp64 GEMM of the same bf16 operands per layer"""
+    from tinyedm_amd import ops
+    g = torch.Generator().manual_seed(3)
+    shapes = [(3, 5, 7, 160, 96), (2, 16, 16, 256, 768), (5, 8, 8, 512, 256), (1, 3, 3, 32, 32), (16, 16, 16, 128, 320),
+              (128, 16, 16, 256, 256), (128, 8, 8, 768, 256), (8, 32, 32, 512, 256)]
+    shapes = shapes + shapes                                   # 16 layers
+    pairs = []
+    for (B, H, W, Cin, Cout) in shapes:
+        x = torch.randn(B, H, W, Cin, generator=g).to(torch.bfloat16).to("cuda")
+        dy = torch.randn(B, H, W, Cout, generator=g).to(torch.bfloat16).to("cuda")
+        pairs.append((x, dy))
+    slabs = ops.conv_wgrad_1x1_group(pairs)
+    for (x, dy), sl in zip(pairs, slabs):
+        ref = dy.double().reshape(-1, dy.shape[-1]).t() @ x.double().reshape(-1, x.shape[-1])
+        got = sl.double().sum(0)[0]
+        e = ((got - ref).norm() / ref.norm()).item()
+        assert e <= 1e-5, (tuple(x.shape), tuple(dy.shape), e)

@@ -58,7 +58,9 @@ SIGNATURES = {
     "edm_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, P],
     "edm_conv_wgrad_v2": [P, P, P, I, I, I, I, I, I, I, P],
     "edm_conv_wgrad_1x1_nsplit": [L, I, I],
+    "edm_conv_wgrad_1x1_nsplit_grouped": [L, I, I],
     "edm_conv_wgrad_1x1": [P, P, P, L, I, I, I, P],
+    "edm_conv_wgrad_1x1_group": [P, I, P],
     # conv_wgrad3.hip (items = host array of WGrad3Item)
     "edm_wgrad3_workspace": [P, I],
     "edm_wgrad3_group": [P, I, P, L, P],
@@ -110,7 +112,7 @@ DIAG_SIGNATURES = {
     "edm_conv_igemm_v2_ablate": [P, P, P, I, I, I, I, I, I, P],
 }
 _RET = {"edm_last_error": ctypes.c_char_p, "edm_wgrad3_workspace": ctypes.c_long}
-_NO_STATUS = {"edm_version", "edm_graph_replay_safe", "edm_last_error", "edm_conv_wgrad_nsplit", "edm_conv_wgrad_1x1_nsplit", "edm_wgrad3_workspace"}
+_NO_STATUS = {"edm_version", "edm_graph_replay_safe", "edm_last_error", "edm_conv_wgrad_nsplit", "edm_conv_wgrad_1x1_nsplit", "edm_conv_wgrad_1x1_nsplit_grouped", "edm_wgrad3_workspace"}
 
 _lib = None
 
@@ -123,6 +125,11 @@ class FinishItem(ctypes.Structure):
     """edm_finish_item (include/tinyedm_hip.h)"""
     _fields_ = [("slabs", P), ("w", P), ("grad", P), ("perm", P), ("S", I), ("O", I), ("I", I), ("Ipad", I), ("taps", I),
                 ("scale", F), ("accumulate", I)]
+
+
+class WGrad1Item(ctypes.Structure):
+    """edm_wgrad1_item (include/tinyedm_hip.h): one 1x1 layer of a grouped weight-gradient launch."""
+    _fields_ = [("X", P), ("dY", P), ("slabs", P), ("npix", L), ("Cin", I), ("Cout", I), ("nsplit", I), ("pad", I)]
 
 
 class WGrad3Item(ctypes.Structure):

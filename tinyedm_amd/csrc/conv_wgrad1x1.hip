@@ -44,14 +44,13 @@ __device__ __forceinline__ bf16x8 frag_of(const u32x2_t& lo, const u32x2_t& hi) 
   return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(512, 1) void k_wgrad1x1(const bf16* __restrict__ X, const bf16* __restrict__ dY,
-                                                       float* __restrict__ slabs, const bf16* __restrict__ zeros,
-                                                       long Npix, int Cin, int Cout, int tiles_ci, long L) {
+__device__ __forceinline__ void wgrad1x1_body(const bf16* __restrict__ X, const bf16* __restrict__ dY,
+                                              float* __restrict__ slabs, const bf16* __restrict__ zeros, long Npix, int Cin,
+                                              int Cout, int tiles_ci, long L, int tile, int s) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tco = blockIdx.x / tiles_ci, tci = blockIdx.x % tiles_ci;
-  const int s = blockIdx.y;
+  const int tco = tile / tiles_ci, tci = tile % tiles_ci;
   const int co0 = tco * TCO, ci0 = tci * TCI;
   const int wr = wave >> 1, wc = wave & 1;  // this wave's 64(co) x 64(ci) block
   const long k0 = (long)s * L;
@@ -160,6 +159,37 @@ __global__ __launch_bounds__(512, 1) void k_wgrad1x1(const bf16* __restrict__ X,
     }
 }
 
+__global__ __launch_bounds__(512, 1) void k_wgrad1x1(const bf16* __restrict__ X, const bf16* __restrict__ dY,
+                                                       float* __restrict__ slabs, const bf16* __restrict__ zeros,
+                                                       long Npix, int Cin, int Cout, int tiles_ci, long L) {
+  wgrad1x1_body(X, dY, slabs, zeros, Npix, Cin, Cout, tiles_ci, L, blockIdx.x, blockIdx.y);
+}
+
+// A GROUP of 1x1 layers in one launch (round 3).  The ~31 1x1 weight gradients of a step were 31 launches of 9-70 us, the
+// 8x8 / 16x16 ones launch- and latency-bound (one short burst of workgroups each).  Their results are only needed by the
+// optimizer, so the layers of a stretch of the backward pass are queued and their (tile, split) workgroups laid end to
+// end in ONE grid: a workgroup finds its layer by its block index and runs the same body.
+constexpr int W1_MAX = 16;
+struct W1Group {
+  const bf16* X[W1_MAX];
+  const bf16* dY[W1_MAX];
+  float* slabs[W1_MAX];
+  long npix[W1_MAX], L[W1_MAX];
+  int Cin[W1_MAX], Cout[W1_MAX], tiles_ci[W1_MAX], tiles[W1_MAX];
+  int wg_end[W1_MAX];     // exclusive prefix of workgroups: layer i owns blocks [wg_end[i-1], wg_end[i])
+  int n;
+  const bf16* zeros;
+};
+__global__ __launch_bounds__(512, 1) void k_wgrad1x1_group(W1Group g) {
+  int i = 0;
+  const int b = blockIdx.x;
+  while (i + 1 < g.n && b >= g.wg_end[i]) ++i;
+  i = __builtin_amdgcn_readfirstlane(i);
+  const int lid = b - (i ? g.wg_end[i - 1] : 0);
+  wgrad1x1_body(g.X[i], g.dY[i], g.slabs[i], g.zeros, g.npix[i], g.Cin[i], g.Cout[i], g.tiles_ci[i], g.L[i],
+                lid % g.tiles[i], lid / g.tiles[i]);
+}
+
 }  // namespace
 
 // Number of split-K slabs edm_conv_wgrad_1x1 writes for this shape (sizes the workspace [S][Cout][Cin] fp32).
@@ -173,6 +203,17 @@ extern "C" int edm_conv_wgrad_1x1_nsplit(long npix, int Cin, int Cout) {
   if (S > max_split) S = max_split;  // more splits buy no kernel time (r01 sweep) but every slab is re-read by the finish pass
   if (S < 1) S = 1;
   return (int)S;
+}
+
+// Splits of a layer inside a GROUPED launch: the group as a whole fills the chip, so a layer needs only enough splits to
+// give each workgroup ~32 stages of 64 pixels -- every split is a slab written here and re-read by the finish pass
+// (16x16 layers: 16 instead of 43-64 splits, 8x8 layers: 4 instead of 32; sweep 8 / 16 / 32 / 64 stages: 13.91 / 13.81 / 13.79 / 13.78 ms per step).
+extern "C" int edm_conv_wgrad_1x1_nsplit_grouped(long npix, int Cin, int Cout) {
+  const int single = edm_conv_wgrad_1x1_nsplit(npix, Cin, Cout);
+  static const long stages = [] { const char* e = getenv("EDM_W1_STAGES"); return e ? atol(e) : 32L; }();   // tools only
+  long S = (npix + stages * KP - 1) / (stages * KP);
+  if (S > single) S = single;
+  return S < 1 ? 1 : (int)S;
 }
 
 // X [npix, Cin] bf16, dY [npix, Cout] bf16 (NHWC flattened) -> slabs fp32 [nsplit][Cout][Cin]; Cin, Cout % 32 == 0.
@@ -195,5 +236,63 @@ extern "C" int edm_conv_wgrad_1x1(const void* X, const void* dY, float* slabs, l
   hipLaunchKernelGGL(k_wgrad1x1, dim3(tiles_co * tiles_ci, nsplit), dim3(512), (size_t)RING * STAGE, st, (const bf16*)X,
                      (const bf16*)dY, slabs, (const bf16*)edm_zero_page(), npix, Cin, Cout, tiles_ci, L);
   EDM_CHECK_LAUNCH("conv_wgrad_1x1");
+  return EDM_OK;
+}
+
+// The same for up to 16 layers in ONE launch; `items` is a HOST array read during the call; every layer's slabs are
+// [nsplit][Cout][Cin] fp32 with nsplit = edm_conv_wgrad_1x1_nsplit_grouped(npix, Cin, Cout).
+struct edm_wgrad1_item_ {
+  const void* X;
+  const void* dY;
+  float* slabs;
+  long npix;
+  int Cin, Cout, nsplit, pad;
+};
+extern "C" int edm_conv_wgrad_1x1_group(const void* items_, int n, hipStream_t st) {
+  const edm_wgrad1_item_* items = (const edm_wgrad1_item_*)items_;
+  EDM_REQUIRE(items && n > 0 && n <= W1_MAX, "conv_wgrad_1x1_group: 1..%d layers per group", W1_MAX);
+  EDM_ZERO_PAGE(zero_page_, "conv_wgrad_1x1_group");
+  W1Group g;
+  g.n = n;
+  g.zeros = (const bf16*)zero_page_;
+  long total = 0;
+  for (int i = 0; i < n; ++i) {
+    const edm_wgrad1_item_& it = items[i];
+    EDM_REQUIRE(it.X && it.dY && it.slabs, "conv_wgrad_1x1_group: null pointer (layer %d)", i);
+    EDM_REQUIRE(it.npix > 0 && it.npix < (1L << 31), "conv_wgrad_1x1_group: bad pixel count (layer %d)", i);
+    EDM_REQUIRE(it.Cin > 0 && it.Cin % 32 == 0 && it.Cout > 0 && it.Cout % 32 == 0,
+                "conv_wgrad_1x1_group: Cin, Cout must be multiples of 32 (layer %d)", i);
+    EDM_REQUIRE(it.nsplit == edm_conv_wgrad_1x1_nsplit_grouped(it.npix, it.Cin, it.Cout),
+                "conv_wgrad_1x1_group: nsplit mismatch (layer %d)", i);
+    long L = (it.npix + it.nsplit - 1) / it.nsplit;
+    L = (L + KP - 1) / KP * KP;
+    const int tiles_co = (it.Cout + TCO - 1) / TCO, tiles_ci = (it.Cin + TCI - 1) / TCI;
+    g.X[i] = (const bf16*)it.X;
+    g.dY[i] = (const bf16*)it.dY;
+    g.slabs[i] = it.slabs;
+    g.npix[i] = it.npix;
+    g.L[i] = L;
+    g.Cin[i] = it.Cin;
+    g.Cout[i] = it.Cout;
+    g.tiles_ci[i] = tiles_ci;
+    g.tiles[i] = tiles_co * tiles_ci;
+    total += (long)g.tiles[i] * it.nsplit;
+    EDM_REQUIRE(total < (1L << 30), "conv_wgrad_1x1_group: grid too large");
+    g.wg_end[i] = (int)total;
+  }
+  for (int i = n; i < W1_MAX; ++i) {
+    g.X[i] = g.dY[i] = nullptr;
+    g.slabs[i] = nullptr;
+    g.npix[i] = g.L[i] = 0;
+    g.Cin[i] = g.Cout[i] = g.tiles_ci[i] = g.tiles[i] = 0;
+    g.wg_end[i] = (int)total;
+  }
+  static std::atomic<bool> attr_set{false};  // (idempotent call: a race only repeats it)
+  if (!attr_set.load(std::memory_order_acquire)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad1x1_group), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set.store(true, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(k_wgrad1x1_group, dim3((unsigned)total), dim3(512), (size_t)RING * STAGE, st, g);
+  EDM_CHECK_LAUNCH("conv_wgrad_1x1_group");
   return EDM_OK;
 }

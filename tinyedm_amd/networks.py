@@ -136,6 +136,9 @@ WGRAD_STREAM = os.environ.get("EDM_WGRAD_STREAM", "1") != "0"
 W3_GROUP = max(0, min(16, int(os.environ.get("EDM_W3_GROUP", "12"))))
 W3_MAXPIX = int(os.environ.get("EDM_W3_MAXPIX", str(1 << 18)))
 FIN_GROUP = 40              # small weight gradients per multi-tensor finish launch (csrc/weights.hip)
+# 1x1 weight gradients: layers per grouped launch (csrc/conv_wgrad1x1.hip k_wgrad1x1_group; 0 = one launch per layer)
+W1_GROUP = max(0, min(16, int(os.environ.get("EDM_W1_GROUP", "16"))))
+_w1_pending = {}            # device index -> [(mod, x, dy, scale)] 1x1 layers waiting for their grouped launch
 _bwd_end_queued = set()     # devices whose end-of-backward callback is queued for the running backward pass
 _w3_pending = {}            # device index -> [(mod, x, dy, scale)] 3x3 layers waiting for their grouped launch
 _fin_pending = {}           # device index -> [(slabs, w, perm, taps, I, scale)] small weight gradients to finish
@@ -171,9 +174,26 @@ def _flush_w3(key):
             hook(m.weight)
 
 
+def _flush_w1(key):
+    """The pending 1x1 weight gradients of device `key` as ONE grouped slab launch; their finish (reduction over the
+    splits + projection through the weight normalisation) joins the multi-tensor finish queue."""
+    items = _w1_pending.pop(key, None)
+    if not items:
+        return
+    dev = items[0][0].weight.device
+    box = []
+    _run_on_side(dev, lambda: box.extend(ops.conv_wgrad_1x1_group([(x, dy) for _, x, dy, _ in items])),
+                 [t for _, x, dy, _ in items for t in (x, dy)])
+    pend = _fin_pending.setdefault(key, [])
+    for (m, _, _, scale), slabs in zip(items, box):
+        w = m.weight
+        pend.append((slabs, w, m._perm, 1, w.shape[1], scale))
+
+
 def _flush_fin(key):
     """One multi-tensor launch for the pending small weight gradients of device `key` (on the auxiliary stream,
     ordered after both streams' producers of the slabs)."""
+    _flush_w1(key)              # queued 1x1 layers first: their slabs are finished by this very launch
     items = _fin_pending.pop(key, None)
     if not items:
         return
@@ -210,8 +230,12 @@ def _queue_backward_end(device):
 def reset_backward_state():
     """Forget deferred work of a backward pass that did not complete (an exception inside autograd leaves its
     end-of-backward callback unrun).  Called at the start of every Denoiser forward."""
-    if _bwd_end_queued or _w3_pending or _fin_pending:
+    if _bwd_end_queued or _w3_pending or _fin_pending or _w1_pending:
         _bwd_end_queued.clear()
+        for items in _w1_pending.values():
+            for m, _, _, _ in items:
+                m.weight._edm_deferred = False
+        _w1_pending.clear()
         for items in _fin_pending.values():
             for _, w, *_rest in items:
                 w._edm_deferred = False
@@ -248,6 +272,17 @@ def _wgrad(mod, x, dy, taps, scale=1.0):
         g = torch.empty_like(w.data)
         ops.wgrad3_group([(x, dy, w.data, g, mod._perm, scale, False)])
         return g
+    if direct and taps == 1 and W1_GROUP and w.dim() == 4 and ops.wgrad1x1_group_supported(x, dy):
+        # flat-arena mode: the layer joins a group of 1x1 layers whose slabs come from ONE launch (and whose finish rides in
+        # the multi-tensor finish launch that follows it)
+        key = w.device.index
+        pend = _w1_pending.setdefault(key, [])
+        pend.append((mod, x, dy, scale))
+        w._edm_deferred = True
+        if len(pend) >= W1_GROUP:
+            _flush_fin(key)
+        _queue_backward_end(w.device)
+        return None
     if direct:
         _run_on_side(w.device, lambda: mod.finish_grad(ops.conv_wgrad(x, dy, taps), scale=scale), (x, dy))
         _queue_backward_end(w.device)

@@ -642,6 +642,36 @@ def conv_wgrad(x, dy, taps):
     return slabs
 
 
+def wgrad1x1_group_supported(x, dy):
+    return WGRAD_1X1 and x.shape[-1] % 32 == 0 and dy.shape[-1] % 32 == 0
+
+
+def conv_wgrad_1x1_group(pairs):
+    """pairs: sequence (<= 16) of (x, dy) NHWC bf16 tensors of 1x1 layers -> list of their fp32 split-K slabs
+    (S, 1, Cout, Cin), all produced by ONE launch (csrc/conv_wgrad1x1.hip k_wgrad1x1_group)."""
+    n = len(pairs)
+    if not 0 < n <= 16:
+        raise ValueError("conv_wgrad_1x1_group: 1..16 layers per group")
+    arr = (_lib.WGrad1Item * n)()
+    out = []
+    flops = nbytes = 0.0
+    for k, (x, dy) in enumerate(pairs):
+        B, H, W, Cin = _nhwc(x, "x")
+        Bd, Hd, Wd, Cout = _nhwc(dy, "dy")
+        if (Bd, Hd, Wd) != (B, H, W) or Cin % 32 or Cout % 32:
+            raise ValueError("conv_wgrad_1x1_group: x/dy mismatch or channels not multiples of 32")
+        npix = B * H * W
+        S = _lib.call("edm_conv_wgrad_1x1_nsplit_grouped", npix, Cin, Cout)
+        slabs = torch.empty(S, 1, Cout, Cin, device=x.device, dtype=f32)
+        arr[k] = _lib.WGrad1Item(x.data_ptr(), dy.data_ptr(), slabs.data_ptr(), npix, Cin, Cout, S, 0)
+        out.append(slabs)
+        flops += 2.0 * npix * Cin * Cout
+        nbytes += 2.0 * npix * (Cin + Cout) + 4.0 * slabs.numel()
+    with _prof("conv1x1_wgrad", flops, nbytes):
+        _lib.call("edm_conv_wgrad_1x1_group", ctypes.byref(arr), n, _stream())
+    return out
+
+
 def wgrad3_supported(x, dy, I):
     """shapes the grouped 3x3 weight-gradient path (csrc/conv_wgrad3.hip) covers"""
     B, H, W, Cin = x.shape
