@@ -38,31 +38,47 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s2) {
 }
 __device__ __forceinline__ const bf16x8& ld128(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
-// load + pixel-normalise `nimg` [N][D] slices (stride between slices = D channels) into LDS images
-template <bool SAVE>
-__device__ __forceinline__ void stage_normalised(const bf16* __restrict__ src, long row_stride, char* img0, int NP,
-                                                 int N, int nimg, float* dsave) {
-  const int total = nimg * NP * 8;
-  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+// load + pixel-normalise NIMG [N][D] slices (stride between slices = D channels) into LDS images.  The trip count is a
+// compile-time constant (NIMG * NP * 8 / THREADS 16-byte pieces per thread: 12 for three 256-token images) and ALL of a
+// thread's loads are issued before the first is consumed: with one workgroup per CU nothing else hides the HBM latency,
+// and the rolled loop paid it once per piece (round 3: fwd 35 -> see DESIGN 3.3).
+template <bool SAVE, int NIMG, int NP, int THREADS>
+__device__ __forceinline__ void stage_normalised(const bf16* __restrict__ src, long row_stride, char* img0, int N,
+                                                 float* dsave) {
+  constexpr int TOTAL = NIMG * NP * 8;
+  constexpr int IT = (TOTAL + THREADS - 1) / THREADS;
+  u32x4 raw[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int idx = threadIdx.x + it * THREADS;
     const int which = idx / (NP * 8), rem = idx % (NP * 8);
     const int row = rem >> 3, c8 = rem & 7;
+    raw[it] = u32x4{0u, 0u, 0u, 0u};
+    if (idx < TOTAL && row < N)
+      raw[it] = *reinterpret_cast<const u32x4*>(src + (long)row * row_stride + which * D + c8 * 8);
+  }
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int idx = threadIdx.x + it * THREADS;
+    const int which = idx / (NP * 8), rem = idx % (NP * 8);
+    const int row = rem >> 3, c8 = rem & 7;
+    const bf16x8 bv = __builtin_bit_cast(bf16x8, raw[it]);
     float v[8];
     float ss = 0.f;
-    if (row < N) {
-      load8(src + (long)row * row_stride + which * D + c8 * 8, v);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) ss += v[i] * v[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    for (int i = 0; i < 8; ++i) {
+      v[i] = (float)bv[i];
+      ss += v[i] * v[i];
     }
     ss = group_sum<8>(ss);
     const float dn = NORM_EPS + sqrtf(ss) * 0.125f;  // 1/sqrt(64)
     const float inv = 1.0f / dn;
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] *= inv;
-    store8(reinterpret_cast<bf16*>(img0 + (long)which * NP * RS + row * RS + c8 * 16), v);
-    if (SAVE && c8 == 0) dsave[which * NP + row] = dn;
+    if (idx < TOTAL) {
+      store8(reinterpret_cast<bf16*>(img0 + (long)which * NP * RS + row * RS + c8 * 16), v);
+      if (SAVE && c8 == 0) dsave[which * NP + row] = dn;
+    }
   }
 }
 
@@ -94,7 +110,7 @@ __global__ __launch_bounds__(attn_threads<NT>()) void k_attn_fwd(const bf16* __r
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   const bf16* src = qkv + ((long)b * N) * 3 * C + head * 3 * D;
-  stage_normalised<false>(src, 3L * C, Qn, NP, N, 3, nullptr);
+  stage_normalised<false, 3, NP, attn_threads<NT>()>(src, 3L * C, Qn, N, nullptr);
   __syncthreads();
 
   const float scale = 0.125f;  // 1/sqrt(64)
@@ -218,24 +234,34 @@ __global__ __launch_bounds__(attn_threads<NT>()) void k_attn_bwd(const bf16* __r
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   const bf16* src = qkv + ((long)b * N) * 3 * C + head * 3 * D;
-  stage_normalised<true>(src, 3L * C, Qn, NP, N, 3, dsave);
-  // dO image + delta
-  for (int idx = threadIdx.x; idx < NP * 8; idx += blockDim.x) {
+  // dO image + delta: its loads are issued FIRST (before the q/k/v staging consumes anything), all at once
+  constexpr int THR = attn_threads<NT>();
+  constexpr int ITD = (NP * 8 + THR - 1) / THR;
+  u32x4 graw[ITD], oraw[ITD];
+#pragma unroll
+  for (int it = 0; it < ITD; ++it) {
+    const int idx = threadIdx.x + it * THR;
     const int row = idx >> 3, c8 = idx & 7;
-    float g[8], o[8];
-    float dl = 0.f;
-    if (row < N) {
-      load8(gy + ((long)b * N + row) * C + head * D + c8 * 8, g);
-      load8(y + ((long)b * N + row) * C + head * D + c8 * 8, o);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) dl += g[i] * o[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) g[i] = 0.f;
+    graw[it] = oraw[it] = u32x4{0u, 0u, 0u, 0u};
+    if (idx < NP * 8 && row < N) {
+      graw[it] = *reinterpret_cast<const u32x4*>(gy + ((long)b * N + row) * C + head * D + c8 * 8);
+      oraw[it] = *reinterpret_cast<const u32x4*>(y + ((long)b * N + row) * C + head * D + c8 * 8);
     }
+  }
+  stage_normalised<true, 3, NP, THR>(src, 3L * C, Qn, N, dsave);
+#pragma unroll
+  for (int it = 0; it < ITD; ++it) {
+    const int idx = threadIdx.x + it * THR;
+    const int row = idx >> 3, c8 = idx & 7;
+    const bf16x8 gv = __builtin_bit_cast(bf16x8, graw[it]), ov = __builtin_bit_cast(bf16x8, oraw[it]);
+    float dl = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dl += (float)gv[i] * (float)ov[i];
     dl = group_sum<8>(dl);
-    store8(reinterpret_cast<bf16*>(dO + row * RS + c8 * 16), g);
-    if (c8 == 0) st_d[row] = dl;
+    if (idx < NP * 8) {
+      *reinterpret_cast<u32x4*>(dO + row * RS + c8 * 16) = graw[it];
+      if (c8 == 0) st_d[row] = dl;
+    }
   }
   __syncthreads();
 
