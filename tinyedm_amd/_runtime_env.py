@@ -1,6 +1,6 @@
 """Process-level HIP runtime settings this package depends on.  Imported first by tinyedm_amd/__init__.py.
 
-hipGraph replay on ROCm 7.2 (measured round 2, tools/nan_hunt.py): with the runtime's default "AQL packet capture"
+hipGraph replay on ROCm 7.2 (measured round 2): with the runtime's default "AQL packet capture"
 fast path, the first replay of an instantiated graph that follows a hipStreamSynchronize / hipDeviceSynchronize
 runs some of its nodes with clobbered kernel arguments -- a captured training step then turns its weights into
 garbage / NaN (and, drawing less power, runs faster: the bug first showed up as a "too good" bench number).  Event

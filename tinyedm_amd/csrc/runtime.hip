@@ -21,7 +21,7 @@ std::mutex g_mu;
 
 // hipGraph replay on ROCm 7.2: with the runtime's default AQL-packet-capture path the first replay after a
 // hipStreamSynchronize / hipDeviceSynchronize runs graph nodes with clobbered kernel arguments (measured round 2,
-// tools/nan_hunt.py; see tinyedm_amd/_runtime_env.py).  The runtime reads DEBUG_CLR_GRAPH_PACKET_CAPTURE at its
+// see tinyedm_amd/_runtime_env.py).  The runtime reads DEBUG_CLR_GRAPH_PACKET_CAPTURE at its
 // initialisation, so the library's load-time constructor sets it to 0 when the host has not chosen a value -- and
 // records whether that can still have taken effect: FAIL CLOSED, the answer is yes only when the variable was already
 // "0" when the library was loaded, or the process had not initialised the HIP runtime yet (it did not hold /dev/kfd
