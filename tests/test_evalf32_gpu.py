@@ -208,3 +208,12 @@ def test_heun_32_step_trajectory_f32_vs_fp32_oracle():
         with torch.no_grad():
             x_g = solver.solve(model, x0.to(DEV), None, graph=True).cpu()
         assert torch.equal(x_g, x_hip)              # bit-reproducible: eager == hipGraph replay
+        # switching the evaluation precision on the SAME solver / model must not replay the other path's graph
+        model.denoiser.set_eval_dtype("bf16")
+        with torch.no_grad():
+            x_b = solver.solve(model, x0.to(DEV), None, graph=True).cpu()
+            x_be = solver.solve(model, x0.to(DEV), None).cpu()
+        assert torch.equal(x_b, x_be) and not torch.equal(x_b, x_g)
+        model.denoiser.set_eval_dtype("f32")
+        with torch.no_grad():
+            assert torch.equal(solver.solve(model, x0.to(DEV), None, graph=True).cpu(), x_g)

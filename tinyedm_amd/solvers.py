@@ -66,7 +66,12 @@ class DeterministicSolver:
         per_model = self._graphs.get(owner)
         if per_model is None:
             per_model = self._graphs[owner] = {}
-        key = (tuple(x0.shape), None if class_labels is None else tuple(class_labels.shape), x0.device.index)
+        # the evaluation precision of the denoiser(s) is part of the key: set_eval_dtype() between two solves must not
+        # replay a graph captured with the other path's kernels
+        dtypes = ()
+        if isinstance(owner, torch.nn.Module):
+            dtypes = tuple(getattr(m, "eval_dtype", None) for m in owner.modules() if hasattr(m, "eval_dtype"))
+        key = (tuple(x0.shape), None if class_labels is None else tuple(class_labels.shape), x0.device.index, dtypes)
         ent = per_model.get(key)
         if ent is None:
             _runtime_env.require_graph_replay_safe("DeterministicSolver.solve(graph=True)")
