@@ -175,19 +175,27 @@ struct W1Group {
   const bf16* dY[W1_MAX];
   float* slabs[W1_MAX];
   long npix[W1_MAX], L[W1_MAX];
-  int Cin[W1_MAX], Cout[W1_MAX], tiles_ci[W1_MAX], tiles[W1_MAX];
+  int Cin[W1_MAX], Cout[W1_MAX], tiles_ci[W1_MAX], tiles[W1_MAX], nsplit[W1_MAX];
   int wg_end[W1_MAX];     // exclusive prefix of workgroups: layer i owns blocks [wg_end[i-1], wg_end[i])
   int n;
   const bf16* zeros;
 };
+// Block -> (tile, split) inside a layer: the `tiles` workgroups of ONE split read the same pixel rows at the same time
+// (a dY row is shared by the ci-tiles, an X row by the co-tiles), so they are put on ONE XCD (blockIdx % 8 under round-robin
+// placement; layer ranges start at multiples of 8) and the second..last read of a row hits that XCD's L2 instead of HBM:
+// within a chunk of 8 * tiles consecutive blocks, block j is split (chunk * 8 + j % 8), tile j / 8.  Splits past the
+// layer's count (its block range is padded to whole chunks) exit at once.
 __global__ __launch_bounds__(512, 1) void k_wgrad1x1_group(W1Group g) {
   int i = 0;
   const int b = blockIdx.x;
   while (i + 1 < g.n && b >= g.wg_end[i]) ++i;
   i = __builtin_amdgcn_readfirstlane(i);
   const int lid = b - (i ? g.wg_end[i - 1] : 0);
-  wgrad1x1_body(g.X[i], g.dY[i], g.slabs[i], g.zeros, g.npix[i], g.Cin[i], g.Cout[i], g.tiles_ci[i], g.L[i],
-                lid % g.tiles[i], lid / g.tiles[i]);
+  const int tiles = g.tiles[i], per = 8 * tiles;
+  const int chunk = lid / per, j = lid - chunk * per;
+  const int s = chunk * 8 + (j & 7), tile = j >> 3;
+  if (s >= g.nsplit[i]) return;
+  wgrad1x1_body(g.X[i], g.dY[i], g.slabs[i], g.zeros, g.npix[i], g.Cin[i], g.Cout[i], g.tiles_ci[i], g.L[i], tile, s);
 }
 
 }  // namespace
@@ -276,7 +284,8 @@ extern "C" int edm_conv_wgrad_1x1_group(const void* items_, int n, hipStream_t s
     g.Cout[i] = it.Cout;
     g.tiles_ci[i] = tiles_ci;
     g.tiles[i] = tiles_co * tiles_ci;
-    total += (long)g.tiles[i] * it.nsplit;
+    g.nsplit[i] = it.nsplit;
+    total += (long)g.tiles[i] * ((it.nsplit + 7) / 8 * 8);     // whole chunks of 8 splits: every layer starts on XCD 0
     EDM_REQUIRE(total < (1L << 30), "conv_wgrad_1x1_group: grid too large");
     g.wg_end[i] = (int)total;
   }
@@ -284,7 +293,7 @@ extern "C" int edm_conv_wgrad_1x1_group(const void* items_, int n, hipStream_t s
     g.X[i] = g.dY[i] = nullptr;
     g.slabs[i] = nullptr;
     g.npix[i] = g.L[i] = 0;
-    g.Cin[i] = g.Cout[i] = g.tiles_ci[i] = g.tiles[i] = 0;
+    g.Cin[i] = g.Cout[i] = g.tiles_ci[i] = g.tiles[i] = g.nsplit[i] = 0;
     g.wg_end[i] = (int)total;
   }
   static std::atomic<bool> attr_set{false};  // (idempotent call: a race only repeats it)
