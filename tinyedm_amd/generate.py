@@ -56,7 +56,7 @@ def generate(ckpt_path, load_ema, output_dir, num_samples, image_size, num_class
     writer = PreditionWriter(output_dir=output_dir, write_interval="batch", mean=mean, std=std, first_index=first)
     trainer = Trainer(accelerator="gpu", strategy="auto", callbacks=[writer])
     if n_local > 0:
-        trainer.predict(model, datamodule=datamodule, distributed=False)
+        trainer.predict(model, datamodule=datamodule, return_predictions=False, ckpt_path=None, distributed=False)   # generate.py:45-47
     print(f"[rank {rank}] wrote images {first}..{first + n_local - 1} to {output_dir}", flush=True)
 
 
