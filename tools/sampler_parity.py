@@ -1,12 +1,13 @@
-"""How far is the bf16-network sampler from the reference's fp32 sampler?  
+"""How far are the two sampler precisions of this build from the reference's fp32 sampler?  
 
-The reference samples in fp32 (generate.py:39-44, solvers.py:43-59); this build evaluates the network in bf16 (fp32
-accumulation, fp32 Heun state).  This tool integrates the SAME 32-step Heun trajectory (63 evaluations) of the
-CIFAR-10 U-Net (35.6 M parameters, seeded weights with non-zero gains) from the same x0
-  (a) on the HIP path (bf16 network, hipGraph), and
-  (b) on the CPU oracle in fp32 (the reference's arithmetic: oracle pinned to the reference's golden vectors),
-and writes the relative L2 distance of the final images and of every intermediate state to
-gpurun_out/r02_sampler_parity.json (copied to profiles/).   python tools/sampler_parity.py [--images 2]
+The reference samples in fp32 (generate.py:39-44, solvers.py:43-59).  This tool integrates the SAME 32-step Heun trajectory
+(63 evaluations) of the CIFAR-10 U-Net (35.6 M parameters, seeded weights with non-zero gains) from the same x0
+  (a) on the HIP path with the bf16 network (the training path's kernels; hipGraph),
+  (a') on the HIP path with the fp32 network (the reference-precision evaluation, csrc/eval_f32.hip; hipGraph), and
+  (b) on the CPU oracle in fp32 (the reference's arithmetic: oracle pinned to the reference's golden vectors), plus the
+      same oracle with every convolution operand rounded to TF32,
+and writes the relative L2 distances of the final images to gpurun_out/r03_sampler_parity.json (copied to profiles/).
+    python tools/sampler_parity.py [--images 2]
 """
 import argparse
 import json
@@ -55,6 +56,9 @@ def main():
     x0 = torch.randn(a.images, 3, 32, 32, generator=torch.Generator().manual_seed(7))
     sol = T.DeterministicSolver(num_steps=a.steps)
     x_hip = sol.solve(Model().eval(), x0.to(dev), None, graph=True).cpu()
+    den.set_eval_dtype("f32")
+    x_hip32 = sol.solve(Model().eval(), x0.to(dev), None, graph=True).cpu()
+    den.set_eval_dtype("bf16")
 
     import bench
     torch.set_num_threads(bench.host_cores())
@@ -93,6 +97,8 @@ def main():
     out = {"config": "CIFAR-10 unconditional U-Net (35.6M params, seeded weights, gains non-zero)", "heun_steps": a.steps,
            "nfe": 2 * a.steps - 1, "images": a.images,
            "hip_bf16net_vs_fp32_oracle_rel_l2": rel(x_hip, x_f32),
+           "hip_fp32net_vs_fp32_oracle_rel_l2": rel(x_hip32, x_f32),
+           "hip_fp32net_max_abs_diff_vs_fp32": (x_hip32 - x_f32).abs().max().item(),
            "hip_bf16net_vs_bf16_oracle_rel_l2": rel(x_hip, x_bf) if a.bf16_oracle else None,
            "bf16_oracle_vs_fp32_oracle_rel_l2": rel(x_bf, x_f32) if a.bf16_oracle else None,
            "tf32conv_oracle_vs_fp32_oracle_rel_l2": rel(x_tf, x_f32) if x_tf is not None else None,
@@ -103,7 +109,7 @@ def main():
                    "accumulation on the HIP path). 1/255 of the [-1,1] image range is 7.8e-3.",
            "oracle_cpu_seconds": round(cpu_s, 1)}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r02_sampler_parity.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r03_sampler_parity.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
 
