@@ -67,16 +67,18 @@ int edm_conv_igemm_s(const void* X, const void* Wp, void* Y, const void* R, floa
  * Y = conv3x3(X) (bf16, may be NULL in eval), Y2 = dropout(mp_silu(Y * (lin[b,:]*gain + 1))) -- bit-identical to
  * edm_mod_silu_drop_fwd applied to Y (same Philox counters), so edm_mod_silu_drop_bwd serves as its backward. */
 int edm_conv3x3_mod(const void* X, const void* Wp, void* Y, void* Y2, const float* lin, long lin_stride,
-                    const float* gain, float pdrop, unsigned long long seed, unsigned sub, unsigned step, int B, int H,
-                    int W, int Cin, int Cout, const void* dyn, edm_stream_t stream);
+                    const float* gain, float pdrop, unsigned long long seed, unsigned sub, unsigned step, int mark_dropped,
+                    int B, int H, int W, int Cin, int Cout, const void* dyn, edm_stream_t stream);
 /* backward counterpart: dgrad of the block's second 3x3 conv (ga = alpha*conv3x3(dY, Wd), never written) with the
  * modulation backward in the epilogue: GR = ga*keep*mp_silu'(u*m)*m, gm[b,c] += sum_px ga*keep*mp_silu'(u*m)*u (gm
  * zero-filled fp32, rows of gm_stride floats, 0 = Cout); finish with edm_mod_finish, or -- when gm is a column slice of a
  * buffer shared by all blocks -- with ONE edm_mod_finish_multi at the end of the backward pass.  -3 when H*W % 32 != 0
- * (use the separate kernels). */
+ * (use the separate kernels).  mark_dropped (forward) writes NaN into the elements of Y (= U) the dropout removed; with
+ * u_marked (backward) the mask is read back from those NaNs instead of regenerating the Philox stream (a third of the
+ * backward epilogue's vector-ALU work). */
 int edm_conv3x3_modbwd(const void* dY, const void* Wd, float alpha, const void* U, const float* lin, long lin_stride,
                        const float* gain, void* GR, float* gm, long gm_stride, float pdrop, unsigned long long seed,
-                       unsigned sub, unsigned step, int B, int H, int W, int Cin, int Cout, const void* dyn,
+                       unsigned sub, unsigned step, int u_marked, int B, int H, int W, int Cin, int Cout, const void* dyn,
                        edm_stream_t stream);
 /* dgrad of a block's first 3x3 conv with the mp_silu backward of the block input in its epilogue
  * (g = conv3x3(dY, Wd) never written): GX = mp_silu'(Xpre)*g + add_scale*ADD (ADD may be NULL). */

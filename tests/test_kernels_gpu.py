@@ -288,6 +288,43 @@ def test_conv3x3_modbwd_epilogue_matches_separate_kernels(ops, B, H, W, C1, C2, 
     assert rel(glin, glin_ref) <= 1e-5 and abs(gg.item() - gg_ref.item()) <= 1e-4 * (abs(gg_ref.item()) + 1e-3)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pdrop", [(3, 16, 16, 128, 64, 0.25), (2, 4, 8, 64, 72, 0.1), (128, 32, 32, 256, 256, 0.13),
+                                                   (128, 16, 16, 256, 256, 0.13), (128, 8, 8, 256, 256, 0.13),
+                                                   (512, 8, 8, 64, 256, 0.1), (2, 8, 8, 64, 128, 0.0)])
+def test_dropout_marks_in_saved_preactivation(ops, B, H, W, Cin, Cout, pdrop):
+    """conv3x3_mod(mark_dropped=True) returns u with NaN exactly where the Philox mask (ops.dropout_mask, the stream the
+    oracle's gradient-parity test injects) dropped the element and the plain u everywhere else; a2 is unchanged.  With
+    that u, conv3x3_modbwd(u_marked=True) -- which regenerates no random stream -- and the separate mod_silu_drop_bwd kernel
+    give the results of the unmarked path: gr bit for bit, glin / ggain up to fp32 summation order."""
+    g = torch.Generator().manual_seed(B + Cin + Cout)
+    x = nhwc(q(torch.randn(B, Cin, H, W, generator=g)))
+    wp = pack_fwd(q(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)))
+    lin_all = torch.randn(B, Cout + 40, generator=g).to(DEV)
+    lin = lin_all[:, 8:8 + Cout]
+    gain = torch.tensor(0.7, device=DEV)
+    u, a2 = ops.conv3x3_mod(x, wp, lin, gain, pdrop, 1234, 5, 6)
+    um, a2m = ops.conv3x3_mod(x, wp, lin, gain, pdrop, 1234, 5, 6, mark_dropped=True)
+    assert torch.equal(a2, a2m)
+    keep = ops.dropout_mask(u.numel(), pdrop, 1234, 5, 6, DEV).view_as(u).bool() if pdrop > 0 else torch.ones_like(u, dtype=torch.bool)
+    assert torch.equal(torch.isnan(um), ~keep)
+    assert torch.equal(torch.where(keep, um, u), u)
+    if pdrop > 0:
+        assert abs((~keep).float().mean().item() - pdrop) < 0.02
+    if (H * W) % 32:
+        return
+    gout = nhwc(q(torch.randn(B, Cin, H, W, generator=g)))
+    wd = pack_fwd(q(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)))
+    gr_ref, glin_ref, gg_ref = ops.conv3x3_modbwd(gout, wd, 0.8, u, lin, gain, pdrop, 1234, 5, 6)
+    gr, glin, gg = ops.conv3x3_modbwd(gout, wd, 0.8, um, lin, gain, pdrop, 999, 1, 2, u_marked=True)   # (seed / stream unused)
+    assert torch.equal(gr, gr_ref)
+    assert torch.isfinite(glin).all() and rel(glin, glin_ref) <= 1e-5
+    assert abs(gg.item() - gg_ref.item()) <= 1e-4 * (abs(gg_ref.item()) + 1e-3)
+    # the separate backward kernel (layers whose H*W is not a multiple of 32 take it) accepts the marked tensor too
+    ga = ops.conv_igemm(gout, wd, 9, alpha=0.8)
+    gr2, glin2, gg2 = ops.mod_silu_drop_bwd(um, lin, gain, ga, pdrop, 1234, 5, 6)
+    assert torch.equal(gr2, gr_ref) and torch.isfinite(glin2).all() and rel(glin2, glin_ref) <= 1e-5
+
+
 @pytest.mark.parametrize("B,H,W,C1,C2", [(2, 8, 8, 64, 128), (3, 5, 7, 128, 72), (128, 32, 32, 256, 256)])
 @pytest.mark.parametrize("with_extra", [False, True])
 def test_conv3x3_silubwd_epilogue_is_bit_identical(ops, B, H, W, C1, C2, with_extra):
@@ -311,7 +348,8 @@ def test_v4_32x32x16_fallback_is_covered():
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, EDM_V4_MFMA16="0", EDM_PARITY_LOG="0")
     sel = ("(test_conv_igemm_forward and igemm-v4) or (test_conv_igemm_residual_epilogue and igemm-v4) or "
-           "test_conv3x3_mod_epilogue or test_conv3x3_modbwd_epilogue or test_conv3x3_silubwd_epilogue")
+           "test_conv3x3_mod_epilogue or test_conv3x3_modbwd_epilogue or test_conv3x3_silubwd_epilogue or "
+           "test_dropout_marks")
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_kernels_gpu.py"), "-x", "-q", "-m", "gpu",
                           "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]

@@ -54,6 +54,16 @@ __device__ __forceinline__ float mp_silu_grad_f(float x) {
   return s * (1.0f + x * (1.0f - s)) * (1.0f / SILU_DIV);
 }
 
+// The same two functions for results that are rounded to bf16 right away (the conv epilogues and the bf16 elementwise
+// kernels): v_rcp_f32 (1 ulp) instead of the ten-instruction IEEE division -- the epilogues run with no MFMA work to hide
+// behind and are bound by the vector ALU.  The fp32 evaluation path, the Linears and the gate MLPs keep the exact forms.
+__device__ __forceinline__ float sigmoid_b(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float mp_silu_b(float x) { return x * sigmoid_b(x) * (1.0f / SILU_DIV); }
+__device__ __forceinline__ float mp_silu_grad_b(float x) {
+  float s = sigmoid_b(x);
+  return s * (1.0f + x * (1.0f - s)) * (1.0f / SILU_DIV);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -152,7 +162,10 @@ struct ModEpilogue {
   int mode;           // 0: none / forward modulation (Y2 set), 1: modulation backward, 2: mp_silu backward
   const StepParams* dyn;  // non-null: step / seed of the Philox stream come from device memory (captured steps)
   long gm_stride;         // row stride of gm in floats; 0 = Cout (a private contiguous [B][Cout] buffer)
+  int u_marks;            // forward: write a NaN into Y (= U) where the element was dropped; backward: U carries those
+                          // marks (dropped <=> NaN), no Philox stream is regenerated
 };
+constexpr uint32_t U_DROPPED = 0x7FFFu;   // the bf16 pattern of a dropped element in a marked U
 __device__ __forceinline__ void apply_dyn(ModEpilogue& m) {
   if (m.dyn) {
     m.step = m.dyn->step;
@@ -161,44 +174,60 @@ __device__ __forceinline__ void apply_dyn(ModEpilogue& m) {
   }
 }
 // mode 2 on 8 channels: gx = mp_silu'(x)*g + s*ge  (k_silu_bwd's arithmetic; g = the conv result rounded to bf16)
-__device__ __forceinline__ u32x4 silu_bwd8(const u32x4& graw, const u32x4& xraw, const bf16* __restrict__ add, float s) {
+__device__ __forceinline__ u32x4 silu_bwd8(const u32x4& graw, const u32x4& xraw, const u32x4& eraw, bool add, float s) {
   const bf16x8 gv = __builtin_bit_cast(bf16x8, graw), xv = __builtin_bit_cast(bf16x8, xraw);
-  bf16x8 ev;
-  if (add) ev = *reinterpret_cast<const bf16x8*>(add);
+  const bf16x8 ev = __builtin_bit_cast(bf16x8, eraw);
   bf16x8 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = (bf16)(mp_silu_grad_f((float)xv[j]) * (float)gv[j] + (add ? s * (float)ev[j] : 0.f));
+  for (int j = 0; j < 8; ++j) o[j] = (bf16)(mp_silu_grad_b((float)xv[j]) * (float)gv[j] + (add ? s * (float)ev[j] : 0.f));
   return __builtin_bit_cast(u32x4, o);
 }
 // backward form on 8 channels: returns gr, accumulates ga*keep*silu'(u*m)*u into part[]
 __device__ __forceinline__ u32x4 mod_silu_drop_bwd8(const u32x4& garaw, const u32x4& uraw, long i8,
-                                                    const float* __restrict__ lp, float g, const ModEpilogue& m,
-                                                    float (&part)[8]) {
+                                                    const float (&mv)[8], const ModEpilogue& m, float (&part)[8]) {
   const bf16x8 gv = __builtin_bit_cast(bf16x8, garaw), uv = __builtin_bit_cast(bf16x8, uraw);
-  const Keep8 keep = dropout_keep8(i8, m.pdrop, m.sub, m.step, m.seed_lo, m.seed_hi);
+  Keep8 keep{0xFFu, 1.0f};
+  if (m.u_marks) {
+    if (m.pdrop > 0.f) {
+      const uint32_t thr = (uint32_t)(m.pdrop * 65536.0f + 0.5f);
+      keep.scale = 65536.0f / (float)(65536u - thr);
+    }
+  } else {
+    keep = dropout_keep8(i8, m.pdrop, m.sub, m.step, m.seed_lo, m.seed_hi);
+  }
   const float keep_scale = keep.scale;
   bf16x8 o;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float mm = lp[j] * g + 1.0f;
-    const float u = (float)uv[j];
-    float gu = (float)gv[j] * mp_silu_grad_f(u * mm);
-    if (m.pdrop > 0.f) gu = keep[j] ? gu * keep_scale : 0.f;
+    const float mm = mv[j];
+    float u = (float)uv[j];
+    const bool kept = m.u_marks ? u == u : keep[j];
+    u = kept ? u : 0.f;
+    float gu = (float)gv[j] * mp_silu_grad_b(u * mm);
+    if (m.pdrop > 0.f) gu = kept ? gu * keep_scale : 0.f;
     part[j] += gu * u;
     o[j] = (bf16)(gu * mm);
   }
   return __builtin_bit_cast(u32x4, o);
 }
-__device__ __forceinline__ u32x4 mod_silu_drop8(const u32x4& uraw, long i8, const float* __restrict__ lp, float g,
-                                                const ModEpilogue& m) {
+// (U with the dropped elements of `bits` marked)
+__device__ __forceinline__ uint32_t mark2(uint32_t bits2) {   // two keep bits -> the OR mask of a bf16 pair
+  return ((bits2 & 1u) ? 0u : U_DROPPED) | ((bits2 & 2u) ? 0u : U_DROPPED << 16);
+}
+__device__ __forceinline__ u32x4 mark_dropped8(const u32x4& uraw, uint32_t bits) {
+  return u32x4{uraw[0] | mark2(bits), uraw[1] | mark2(bits >> 2), uraw[2] | mark2(bits >> 4), uraw[3] | mark2(bits >> 6)};
+}
+__device__ __forceinline__ u32x4 mod_silu_drop8(const u32x4& uraw, long i8, const float (&mv)[8], const ModEpilogue& m,
+                                                uint32_t& keepbits) {
   const bf16x8 uv = __builtin_bit_cast(bf16x8, uraw);
   const Keep8 keep = dropout_keep8(i8, m.pdrop, m.sub, m.step, m.seed_lo, m.seed_hi);
+  keepbits = keep.bits;
   const float keep_scale = keep.scale;
   bf16x8 o;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float mm = lp[j] * g + 1.0f;
-    float v = mp_silu_f((float)uv[j] * mm);
+    const float mm = mv[j];
+    float v = mp_silu_b((float)uv[j] * mm);
     if (m.pdrop > 0.f) v = keep[j] ? v * keep_scale : 0.f;
     o[j] = (bf16)v;
   }
@@ -215,61 +244,122 @@ __device__ __forceinline__ u32x4 mod_silu_drop8(const u32x4& uraw, long i8, cons
 // barrier after its last read of the LDS bytes that `stage` overlays.
 // `put(j, stage)` writes alpha * acc (+ beta * the residual already staged) of the 32-pixel block j into `stage` as
 // bf16 [32 px][NI*32 co] rows of EROW bytes: the part that depends on the MFMA shape (see the two wrappers below).
+// Epilogue forms that read a second tensor (EPI 1 / 2: the saved pre-activation U) issue its loads one 32-pixel block
+// AHEAD of their use -- block 0's before anything else, block j+1's right after the accumulators of block j have gone
+// to LDS and freed their registers (EPI 2's optional extra gradient ADD: before put()) -- and the modulation factors of a block
+// (one sample per block: HW % 32 == 0) are formed once: the epilogue runs with no other workgroup on the CU, so a
+// load -> use -> store chain per 4-8 pixel rows (the first form of this code) was 16 exposed memory latencies per wave.
 template <int NI, int NJ, int EPI, class Put>
 __device__ __forceinline__ void store_tile_core(Put&& put, char* stage, bf16* __restrict__ Y, const bf16* __restrict__ R,
-                                                long mb0, long Npix, int cw0, int Cout, const ModEpilogue& mod) {
+                                                long mb0, long Npix, int cw0, int Cout, const ModEpilogue& mod,
+                                                float* gmred = nullptr) {
   constexpr int EROW = NI * 64 + 16, CPR = NI * 4, RPI = 64 / CPR;  // 16-byte chunks per row, rows per instruction
+  constexpr int IT = 32 / RPI;
   const int lane = threadIdx.x & 63;
   const int c16 = lane % CPR, prow = lane / CPR;
   const int co_c = cw0 + c16 * 8;
+  u32x4 ub[EPI ? NJ : 1][EPI ? IT : 1], ab[EPI == 2 ? IT : 1];
+  const bool has_add = EPI == 2 && mod.ADD != nullptr;
+  auto prefetch = [&](int j) {
+    const long mb = mb0 + j * 32;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int px = it * RPI + prow;
+      const bool ok = mb + px < Npix && co_c < Cout;
+      const long e = (mb + px) * Cout + co_c;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      ub[j][it] = ok ? *reinterpret_cast<const u32x4*>(mod.U + e) : z;
+    }
+  };
+  if constexpr (EPI != 0) prefetch(0);
+  // forward modulation / modulation backward with one sample per 32-pixel block: the factors m = lin*gain + 1 once per block
+  const bool block_mod = (EPI == 1) || (EPI == 0 && mod.Y2 && mod.HW % 32 == 0);
+  float gain = 0.f;
+  if (EPI != 2 && mod.Y2) gain = *mod.gain;
+  float part[8];  // backward form: per-lane sums over a block's (gmred: the wave's) pixels
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const long mb = mb0 + j * 32;
+    float mm[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    if (EPI != 2 && block_mod && mb < Npix && co_c < Cout) {
+      const float* lp = mod.lin + ((int)mb / mod.HW) * mod.lin_stride + co_c;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) mm[k] = lp[k] * gain + 1.0f;
+    }
     if (R) {
 #pragma unroll
-      for (int it = 0; it < 32 / RPI; ++it) {
+      for (int it = 0; it < IT; ++it) {
         const int px = it * RPI + prow;
         u32x4 rv = {0u, 0u, 0u, 0u};
         if (mb + px < Npix && co_c < Cout) rv = *reinterpret_cast<const u32x4*>(R + (mb + px) * Cout + co_c);
         *reinterpret_cast<u32x4*>(stage + px * EROW + c16 * 16) = rv;
       }
     }
+    if constexpr (EPI == 2) {  // (U runs a block ahead; U and ADD both would not fit beside the accumulators)
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int px = it * RPI + prow;
+        ab[it] = u32x4{0u, 0u, 0u, 0u};
+        if (has_add && mb + px < Npix && co_c < Cout) ab[it] = *reinterpret_cast<const u32x4*>(mod.ADD + (mb + px) * Cout + co_c);
+      }
+    }
     put(j, stage);
-    float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // backward form: per-lane sums over this block's pixels
-#pragma unroll(EPI ? 1 : 32 / RPI)
-    for (int it = 0; it < 32 / RPI; ++it) {
+    if constexpr (EPI != 0) {
+      __builtin_amdgcn_sched_barrier(0);  // (hoisted above put(), the next block's loads would not find free registers)
+      if (j + 1 < NJ) prefetch(j + 1);
+    }
+    if (!gmred || j == 0) {
+#pragma unroll
+      for (int j8 = 0; j8 < 8; ++j8) part[j8] = 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
       const int px = it * RPI + prow;
       const u32x4 ov = *reinterpret_cast<const u32x4*>(stage + px * EROW + c16 * 16);
       if (mb + px < Npix && co_c < Cout) {
         const long e = (mb + px) * Cout + co_c;
-        if (Y) *reinterpret_cast<u32x4*>(Y + e) = ov;
+        if (Y && !(EPI == 0 && mod.Y2 && mod.u_marks)) *reinterpret_cast<u32x4*>(Y + e) = ov;
         if (mod.Y2) {
-          const float* lp = nullptr;
-          if (EPI != 2) lp = mod.lin + ((mb + px) / mod.HW) * mod.lin_stride + co_c;
-          if (EPI == 1) {
-            const u32x4 uraw = *reinterpret_cast<const u32x4*>(mod.U + e);
-            *reinterpret_cast<u32x4*>(mod.Y2 + e) = mod_silu_drop_bwd8(ov, uraw, e >> 3, lp, *mod.gain, mod, part);
-          } else if (EPI == 2) {
-            const u32x4 xraw = *reinterpret_cast<const u32x4*>(mod.U + e);
-            *reinterpret_cast<u32x4*>(mod.Y2 + e) = silu_bwd8(ov, xraw, mod.ADD ? mod.ADD + e : nullptr, mod.add_scale);
+          if constexpr (EPI == 1) {
+            *reinterpret_cast<u32x4*>(mod.Y2 + e) = mod_silu_drop_bwd8(ov, ub[j][it], e >> 3, mm, mod, part);
+          } else if constexpr (EPI == 2) {
+            *reinterpret_cast<u32x4*>(mod.Y2 + e) = silu_bwd8(ov, ub[j][it], ab[it], has_add, mod.add_scale);
           } else {
-            *reinterpret_cast<u32x4*>(mod.Y2 + e) = mod_silu_drop8(ov, e >> 3, lp, *mod.gain, mod);
+            float mv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mv[k] = mm[k];
+            if (!block_mod) {   // a 32-pixel block may straddle samples: the factors of this pixel's own sample
+              const float* lp = mod.lin + ((int)(mb + px) / mod.HW) * mod.lin_stride + co_c;
+#pragma unroll
+              for (int k = 0; k < 8; ++k) mv[k] = lp[k] * gain + 1.0f;
+            }
+            uint32_t kb;
+            *reinterpret_cast<u32x4*>(mod.Y2 + e) = mod_silu_drop8(ov, e >> 3, mv, mod, kb);
+            if (Y && mod.u_marks) *reinterpret_cast<u32x4*>(Y + e) = mark_dropped8(ov, kb);
           }
         }
       }
     }
-    if (EPI == 1) {  // lanes with equal c16 hold partial sums of the same 8 channels: fold the RPI pixel rows
+    if (EPI == 1 && (!gmred || j == NJ - 1)) {  // lanes with equal c16 hold partial sums of the same 8 channels: fold the RPI pixel rows
 #pragma unroll
       for (int j8 = 0; j8 < 8; ++j8) {
 #pragma unroll
         for (int off = CPR; off < 64; off <<= 1) part[j8] += __shfl_xor(part[j8], off, 64);
       }
-      if (prow == 0 && mb < Npix && co_c < Cout) {
-        float* gp = mod.gm + (mb / mod.HW) * (mod.gm_stride ? mod.gm_stride : (long)Cout) + co_c;
+      if (gmred) {
+        // all NJ blocks of this wave lie in one sample: their sums go to the wave's row of the workgroup's LDS table
+        // (plain stores; the kernel adds the rows of a tile up and issues ONE global atomic per sample and channel)
+        if (prow == 0) {
+          *reinterpret_cast<f32x4*>(gmred + c16 * 8) = f32x4{part[0], part[1], part[2], part[3]};
+          *reinterpret_cast<f32x4*>(gmred + c16 * 8 + 4) = f32x4{part[4], part[5], part[6], part[7]};
+        }
+      } else if (prow == 0 && mb < Npix && co_c < Cout) {
+        float* gp = mod.gm + ((int)mb / mod.HW) * (mod.gm_stride ? mod.gm_stride : (long)Cout) + co_c;
 #pragma unroll
         for (int j8 = 0; j8 < 8; ++j8) atomicAdd(gp + j8, part[j8]);
       }
     }
+    if constexpr (EPI != 0) __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -312,7 +402,7 @@ template <int NI, int NJ, int EPI = 0>
 __device__ __forceinline__ void store_tile_transposed16(const f32x4 (&acc)[2 * NI][2 * NJ], char* stage,
                                                         bf16* __restrict__ Y, const bf16* __restrict__ R, float alpha,
                                                         float beta, long mb0, long Npix, int cw0, int Cout,
-                                                        const ModEpilogue& mod = ModEpilogue{}) {
+                                                        const ModEpilogue& mod = ModEpilogue{}, float* gmred = nullptr) {
   constexpr int EROW = NI * 64 + 16;
   const int lane = threadIdx.x & 63, l15 = lane & 15, lq = lane >> 4;
   store_tile_core<NI, NJ, EPI>(
@@ -324,5 +414,5 @@ __device__ __forceinline__ void store_tile_transposed16(const f32x4 (&acc)[2 * N
             stage4(st + (h * 16 + l15) * EROW + (i * 16 + 4 * lq) * 2, acc[i][2 * j + h][0], acc[i][2 * j + h][1],
                    acc[i][2 * j + h][2], acc[i][2 * j + h][3], alpha, beta, R != nullptr);
       },
-      stage, Y, R, mb0, Npix, cw0, Cout, mod);
+      stage, Y, R, mb0, Npix, cw0, Cout, mod, gmred);
 }

@@ -375,15 +375,17 @@ int edm_conv_igemm_s_ex(const void* X, const void* Wp, void* Y, const void* R, f
 // 3x3 conv with the fused embedding modulation epilogue (networks.py:253-260 / 317-324):
 //   u  = conv3x3(X, Wp)                               -> Y  (bf16; may be null when the caller does not need it: eval)
 //   a2 = dropout(mp_silu(u * (lin[b,:]*gain + 1)))     -> Y2 (bf16)   [same values as edm_mod_silu_drop_fwd on u]
+// mark_dropped != 0: the elements of Y the dropout removed are written as NaN (bf16 | 0x7FFF) instead of u -- their value is
+// never needed again, and edm_conv3x3_modbwd(u_marked = 1) / edm_mod_silu_drop_bwd then read the mask from U.
 // Picks the static-schedule kernel for layers with >= 512 tall tiles and the 128x128-tile kernel otherwise.
 extern "C" int edm_conv3x3_mod(const void* X, const void* Wp, void* Y, void* Y2, const float* lin, long lin_stride,
                                const float* gain, float pdrop, unsigned long long seed, unsigned sub, unsigned step,
-                               int B, int H, int W, int Cin, int Cout, const void* dyn, hipStream_t st) {
+                               int mark_dropped, int B, int H, int W, int Cin, int Cout, const void* dyn, hipStream_t st) {
   EDM_REQUIRE(X && Wp && Y2 && lin && gain, "conv3x3_mod: null pointer");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0 && lin_stride >= Cout && pdrop >= 0.f && pdrop < 1.f,
               "conv3x3_mod: bad args");
   ModEpilogue mod{lin, gain, (bf16*)Y2, lin_stride, H * W, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), sub, step,
-                  nullptr, nullptr, nullptr, 0.f, 0, (const StepParams*)dyn};
+                  nullptr, nullptr, nullptr, 0.f, 0, (const StepParams*)dyn, 0, (mark_dropped && pdrop > 0.f) ? 1 : 0};
   if (edm_conv_v4_worthwhile((long)B * H * W, Cout)) {
     const int rc = edm_conv_igemm_v4_ex(X, Wp, Y, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
     if (rc != EDM_ERR_UNSUPPORTED) return rc;
@@ -403,17 +405,19 @@ extern "C" int edm_conv3x3_mod(const void* X, const void* Wp, void* Y, void* Y2,
 // Returns EDM_ERR_UNSUPPORTED (-3) when H*W is not a multiple of 32 (a 32-pixel block would straddle images).
 // gm_stride: row stride of gm in floats (>= Cout; 0 = Cout): gm may be a column slice of a buffer shared by all blocks of
 // a network, finished by ONE edm_mod_finish_multi launch at the end of the backward pass.
+// u_marked != 0: U comes from edm_conv3x3_mod(mark_dropped = 1) with the same pdrop -- an element is dropped iff U holds a
+// NaN there, and no Philox stream is regenerated (seed / sub / step are ignored).
 extern "C" int edm_conv3x3_modbwd(const void* dY, const void* Wd, float alpha, const void* U, const float* lin,
                                   long lin_stride, const float* gain, void* GR, float* gm, long gm_stride, float pdrop,
-                                  unsigned long long seed, unsigned sub, unsigned step, int B, int H, int W, int Cin,
-                                  int Cout, const void* dyn, hipStream_t st) {
+                                  unsigned long long seed, unsigned sub, unsigned step, int u_marked, int B, int H, int W,
+                                  int Cin, int Cout, const void* dyn, hipStream_t st) {
   EDM_REQUIRE(dY && Wd && U && lin && gain && GR && gm, "conv3x3_modbwd: null pointer");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0 && lin_stride >= Cout && pdrop >= 0.f && pdrop < 1.f &&
                   (gm_stride == 0 || gm_stride >= Cout),
               "conv3x3_modbwd: bad args");
   if ((H * W) % 32 != 0) return EDM_ERR_UNSUPPORTED;
   ModEpilogue mod{lin, gain, (bf16*)GR, lin_stride, H * W, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), sub, step,
-                  (const bf16*)U, gm, nullptr, 0.f, 1, (const StepParams*)dyn, gm_stride};
+                  (const bf16*)U, gm, nullptr, 0.f, 1, (const StepParams*)dyn, gm_stride, (u_marked && pdrop > 0.f) ? 1 : 0};
   if (edm_conv_v4_worthwhile((long)B * H * W, Cout)) {
     const int rc = edm_conv_igemm_v4_ex(dY, Wd, nullptr, nullptr, alpha, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
     if (rc != EDM_ERR_UNSUPPORTED) return rc;

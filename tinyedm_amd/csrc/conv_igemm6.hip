@@ -78,6 +78,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Xb = smem;
   char* const Wb = smem + 2 * XBYTES;
+  // modulation backward: the per-(sample, channel) sums of the eight waves meet in LDS (one row of BNW floats per wave,
+  // behind the slab and ring buffers) and leave as one global atomic per sample and channel of the tile
+  float* const gmred = reinterpret_cast<float*>(smem + 2 * XBYTES + WRING * WTILE);
 
   const int id = blockIdx.x;
   const int xcd = id & 7, k = id >> 3;
@@ -340,15 +343,43 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
   lgkm_wait<0>();                // the last step's (unused) prefetch
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // asm MFMA results -> first read by ordinary code
   __builtin_amdgcn_s_barrier();  // every wave is done with the slab / weight ring
-  store_tile_transposed16<NI, NJ, EPI>(acc, smem + wave * (32 * (NI * 64 + 16)), Y, R, alpha, beta,
-                                       (long)m0 + wave * (32 * NJ), Npix, n0, Cout, mod);
+  if constexpr (EPI == 1) {
+    const bool wave_rows = mod.HW % (32 * NJ) == 0;   // a wave's 64 pixels lie in one sample
+    store_tile_transposed16<NI, NJ, EPI>(acc, smem + wave * (32 * (NI * 64 + 16)), Y, R, alpha, beta,
+                                         (long)m0 + wave * (32 * NJ), Npix, n0, Cout, mod,
+                                         wave_rows ? gmred + wave * BNW : nullptr);
+    if (wave_rows) {
+      __syncthreads();
+      if (tid < BNW && n0 + tid < Cout) {
+        const long gstride = mod.gm_stride ? mod.gm_stride : (long)Cout;
+        int cur = m0 / mod.HW;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {                   // fixed order within the tile
+          const int pw = m0 + w * (32 * NJ);
+          if (pw >= Npix) break;
+          const int sm = pw / mod.HW;
+          if (sm != cur) {
+            atomicAdd(mod.gm + cur * gstride + n0 + tid, sum);
+            sum = 0.f;
+            cur = sm;
+          }
+          sum += gmred[w * BNW + tid];
+        }
+        atomicAdd(mod.gm + cur * gstride + n0 + tid, sum);
+      }
+    }
+  } else {
+    store_tile_transposed16<NI, NJ, EPI>(acc, smem + wave * (32 * (NI * 64 + 16)), Y, R, alpha, beta,
+                                         (long)m0 + wave * (32 * NJ), Npix, n0, Cout, mod);
+  }
 }
 
 template <int NX, int EPI, int NI, int WB = 0>
 void launch6(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int Npix, int H, int W,
              int Cin, int Cout, const ModEpilogue& mod, hipStream_t st) {
   const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + 32 * NI - 1) / (32 * NI);
-  const size_t lds = (size_t)2 * NX * 8 * 16 * ROWB + WRING * (32 * NI * ROWB);
+  const size_t lds = (size_t)2 * NX * 8 * 16 * ROWB + WRING * (32 * NI * ROWB) + (EPI == 1 ? 8 * 32 * NI * 4 : 0);
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
   auto kern = k_conv3x3_v6<NX, EPI, NI, true, WB>;
   static std::atomic<bool> attr_set{false};  // (idempotent call: a race only repeats it)

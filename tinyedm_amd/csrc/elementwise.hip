@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_pnorm_silu_fwd(const bf16* __restrict__
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           o[i] = (float)(bf16)(v[it][i] * inv);
-          s[i] = mp_silu_f(o[i]);
+          s[i] = mp_silu_b(o[i]);
         }
         store8(xn + p * C + c8 * 8, o);
         store8(a + p * C + c8 * 8, s);
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_pnorm_silu_bwd(const bf16* __restrict__
         if (ga) {
           load8(ga + p * C + c8 * 8, t);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) g[it][i] += mp_silu_grad_f(y[it][i]) * t[i];
+          for (int i = 0; i < 8; ++i) g[it][i] += mp_silu_grad_b(y[it][i]) * t[i];
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) dot += g[it][i] * y[it][i];
@@ -174,7 +174,7 @@ __global__ void k_silu_fwd(const bf16* __restrict__ x, bf16* __restrict__ a, lon
     float v[8];
     load8(x + i * 8, v);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = mp_silu_f(v[j]);
+    for (int j = 0; j < 8; ++j) v[j] = mp_silu_b(v[j]);
     store8(a + i * 8, v);
   }
 }
@@ -187,7 +187,7 @@ __global__ void k_silu_bwd(const bf16* __restrict__ x, const bf16* __restrict__ 
     load8(ga + i * 8, g);
     if (ge) load8(ge + i * 8, e);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] = mp_silu_grad_f(v[j]) * g[j] + (ge ? s * e[j] : 0.f);
+    for (int j = 0; j < 8; ++j) g[j] = mp_silu_grad_b(v[j]) * g[j] + (ge ? s * e[j] : 0.f);
     store8(gx + i * 8, g);
   }
 }
@@ -249,7 +249,7 @@ __global__ void k_mod_silu_drop_fwd(const bf16* __restrict__ r, const float* __r
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float m = lp[j] * g + 1.0f;
-      float o = mp_silu_f(v[j] * m);
+      float o = mp_silu_b(v[j] * m);
       if (pdrop > 0.f) o = keep[j] ? o * keep_scale : 0.f;
       v[j] = o;
     }
@@ -288,9 +288,10 @@ __global__ void k_mod_silu_drop_bwd(const bf16* __restrict__ r, const float* __r
     const float keep_scale = keep.scale;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float gu = gg[j] * mp_silu_grad_f(v[j] * m[j]);
+      const float u = (pdrop > 0.f && !keep[j]) ? 0.f : v[j];   // (a dropped element may hold the NaN mark of conv3x3_mod)
+      float gu = gg[j] * mp_silu_grad_b(u * m[j]);
       if (pdrop > 0.f) gu = keep[j] ? gu * keep_scale : 0.f;
-      acc[j] += gu * v[j];
+      acc[j] += gu * u;
       gg[j] = gu * m[j];
     }
     store8(gr + i * 8, gg);
@@ -812,7 +813,7 @@ __global__ void k_concat_gate_fwd(const bf16* __restrict__ inp, const bf16* __re
     store8(cat + i * 8, v);
     if (sil) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = mp_silu_f(v[j]);
+      for (int j = 0; j < 8; ++j) v[j] = mp_silu_b(v[j]);
       store8(sil + i * 8, v);
     }
   }

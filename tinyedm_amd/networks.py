@@ -518,6 +518,9 @@ class ScaleLong(nn.Module):
 # ScaleLong gate: mean over H*W + MLP (and their backward) in one launch per direction (csrc/elementwise.hip
 # k_skip_gate_*); EDM_SKIP_GATE_FUSED=0 keeps the two-launch form (A/B runs)
 SKIP_GATE_FUSED = os.environ.get("EDM_SKIP_GATE_FUSED", "1") != "0"
+# The saved pre-activation of a block carries its dropout mask (dropped <=> NaN; ops.conv3x3_mod(mark_dropped=True)), so
+# the backward epilogue regenerates no Philox stream; EDM_U_MARKS=0: the mask is recomputed (A/B runs)
+U_MARKS = os.environ.get("EDM_U_MARKS", "1") != "0"
 
 
 class _ConcatGateFn(torch.autograd.Function):
@@ -751,7 +754,7 @@ class _ResBlockFn(torch.autograd.Function):
             # modulation + mp_silu + dropout ride in the conv epilogue; the pre-activation r1 is only written when
             # a backward pass will need it
             r1, a2 = ops.conv3x3_mod(s, wf1, lin, gain, pdrop, seed, sub, step, want_u=any(ctx.needs_input_grad),
-                                     dyn=rng.dyn)
+                                     dyn=rng.dyn, mark_dropped=U_MARKS)
         else:
             r1 = ops.conv_igemm(s, wf1, taps)
             a2 = ops.mod_silu_drop_fwd(r1, lin, gain, pdrop, seed, sub, step, dyn=rng.dyn)
@@ -759,6 +762,7 @@ class _ResBlockFn(torch.autograd.Function):
         out = ops.conv_igemm(a2, wf2, taps, residual=xres, alpha=b, beta=a)
         ctx.blk, ctx.enc, ctx.has1 = blk, enc, has1
         ctx.drop = (pdrop, seed, sub, step, rng.dyn)
+        ctx.u_marked = U_MARKS and ops.FUSE_MOD and ops.IGEMM_VERSION == 0
         ctx.batched, ctx.glin_view, ctx.gm_view = batched, glin_view, gm_view
         ctx.has_token = token is not None
         ctx.save_for_backward(u, xres if enc else None, dsave, s, r1, lin, a2, None if batched else emb, gain, wd1, wd2,
@@ -789,7 +793,8 @@ class _ResBlockFn(torch.autograd.Function):
             # final (`_edm_deferred`: the data-parallel reducer must not count it yet)
             deferred = ctx.gm_view is not None and gdirect
             gr1, glin, ggain = ops.conv3x3_modbwd(gout, wd2, b, r1, lin, gain, pdrop, seed, sub, step, glin_out=glin_out,
-                                                     ggain_out=ggain_out, dyn=dyn, gm_out=ctx.gm_view if deferred else None)
+                                                     ggain_out=ggain_out, dyn=dyn, gm_out=ctx.gm_view if deferred else None,
+                                                     u_marked=ctx.u_marked)
             if deferred:
                 gp._edm_deferred = True
         else:

@@ -519,9 +519,11 @@ def conv_igemm(x, wp, taps, residual=None, alpha=1.0, beta=0.0):
 FUSE_MOD = os.environ.get("EDM_FUSE_MOD", "1") != "0"
 
 
-def conv3x3_mod(x, wp, lin, gain, pdrop, seed, sub, step, want_u=True, dyn=None):
+def conv3x3_mod(x, wp, lin, gain, pdrop, seed, sub, step, want_u=True, dyn=None, mark_dropped=False):
     """First 3x3 conv of a block with the modulation epilogue fused: returns (u, a2) with u = conv(x) (None when
-    want_u is False) and a2 = dropout(mp_silu(u*(lin*gain+1))) -- same values as conv_igemm + mod_silu_drop_fwd."""
+    want_u is False) and a2 = dropout(mp_silu(u*(lin*gain+1))) -- same values as conv_igemm + mod_silu_drop_fwd.
+    mark_dropped: the elements of u that the dropout removed come back as NaN (their value is never needed again);
+    conv3x3_modbwd(u_marked=True) and mod_silu_drop_bwd read the mask from there."""
     B, H, W, Cin = _nhwc(x, "x")
     _chk(wp, bf16, "wp")
     if wp.dim() != 3 or wp.shape[0] != 9 or wp.shape[2] != Cin:
@@ -536,17 +538,19 @@ def conv3x3_mod(x, wp, lin, gain, pdrop, seed, sub, step, want_u=True, dyn=None)
     pname = "conv3x3_igemm" + (_v4_suffix(entry, npix, Cout) if entry in ("edm_conv_igemm_v4", "edm_conv_igemm_s") else "")
     with _prof(pname, 2.0 * npix * Cin * Cout * 9, 2.0 * (npix * (Cin + Cout * (2 if want_u else 1)) + wp.numel())):
         _lib.call("edm_conv3x3_mod", _p(x), _p(wp), _p(u), _p(a2), _p(lin), ls, _p(gain), float(pdrop), int(seed),
-                  int(sub), int(step), B, H, W, Cin, Cout, _dyn(dyn), _stream())
+                  int(sub), int(step), int(bool(mark_dropped)), B, H, W, Cin, Cout, _dyn(dyn), _stream())
     return u, a2
 
 
 def conv3x3_modbwd(gout, wd, alpha, r1, lin, gain, pdrop, seed, sub, step, glin_out=None, ggain_out=None, dyn=None,
-                   gm_out=None):
+                   gm_out=None, u_marked=False):
     """dgrad of a block's second 3x3 conv with the modulation backward in its epilogue: returns (gr1, glin, ggain),
     the values conv_igemm(gout, wd, 9, alpha=alpha) followed by mod_silu_drop_bwd would give (H*W % 32 == 0).
     gm_out: a zero-filled (B, Cout) fp32 view with unit column stride (a column slice of a buffer shared by all blocks):
     the raw modulation gradient is accumulated there and NOT finished -- returns (gr1, None, None); one
-    mod_finish_multi over the shared buffer turns it into glin / ggain for every block."""
+    mod_finish_multi over the shared buffer turns it into glin / ggain for every block.
+    u_marked: r1 comes from conv3x3_mod(mark_dropped=True) with the same pdrop: dropped <=> NaN, no Philox stream is
+    regenerated."""
     B, H, W, Cin = _nhwc(gout, "gout")
     _chk(wd, bf16, "wd")
     if wd.dim() != 3 or wd.shape[0] != 9 or wd.shape[2] != Cin:
@@ -572,7 +576,7 @@ def conv3x3_modbwd(gout, wd, alpha, r1, lin, gain, pdrop, seed, sub, step, glin_
     pname = "conv3x3_igemm" + (_v4_suffix(entry, npix, Cout) if entry in ("edm_conv_igemm_v4", "edm_conv_igemm_s") else "") + "_modbwd"
     with _prof(pname, 2.0 * npix * Cin * Cout * 9, 2.0 * (npix * (Cin + 2 * Cout) + wd.numel())):
         _lib.call("edm_conv3x3_modbwd", _p(gout), _p(wd), float(alpha), _p(r1), _p(lin), ls, _p(gain), _p(gr), _p(gm), gms,
-                  float(pdrop), int(seed), int(sub), int(step), B, H, W, Cin, Cout, _dyn(dyn), _stream())
+                  float(pdrop), int(seed), int(sub), int(step), int(bool(u_marked)), B, H, W, Cin, Cout, _dyn(dyn), _stream())
     if gm_out is not None:
         return gr, None, None
     _lib.call("edm_mod_finish", _p(gm), _p(lin), ls, _p(gain), _p(glin), gs, _p(ggain), B, Cout, _stream())
