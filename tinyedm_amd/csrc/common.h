@@ -272,6 +272,20 @@ __device__ __forceinline__ void store_tile_core(Put&& put, char* stage, bf16* __
     }
   };
   if constexpr (EPI != 0) prefetch(0);
+  // plain epilogue with a residual: R runs a block ahead in the same way
+  u32x4 rb[EPI == 0 ? NJ : 1][EPI == 0 ? IT : 1];
+  auto prefetch_r = [&](int j) {
+    const long mb = mb0 + j * 32;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int px = it * RPI + prow;
+      rb[j][it] = u32x4{0u, 0u, 0u, 0u};
+      if (mb + px < Npix && co_c < Cout) rb[j][it] = *reinterpret_cast<const u32x4*>(R + (mb + px) * Cout + co_c);
+    }
+  };
+  if constexpr (EPI == 0) {
+    if (R) prefetch_r(0);
+  }
   // forward modulation / modulation backward with one sample per 32-pixel block: the factors m = lin*gain + 1 once per block
   const bool block_mod = (EPI == 1) || (EPI == 0 && mod.Y2 && mod.HW % 32 == 0);
   float gain = 0.f;
@@ -291,7 +305,8 @@ __device__ __forceinline__ void store_tile_core(Put&& put, char* stage, bf16* __
       for (int it = 0; it < IT; ++it) {
         const int px = it * RPI + prow;
         u32x4 rv = {0u, 0u, 0u, 0u};
-        if (mb + px < Npix && co_c < Cout) rv = *reinterpret_cast<const u32x4*>(R + (mb + px) * Cout + co_c);
+        if constexpr (EPI == 0) rv = rb[j][it];
+        else if (mb + px < Npix && co_c < Cout) rv = *reinterpret_cast<const u32x4*>(R + (mb + px) * Cout + co_c);
         *reinterpret_cast<u32x4*>(stage + px * EROW + c16 * 16) = rv;
       }
     }
@@ -304,6 +319,12 @@ __device__ __forceinline__ void store_tile_core(Put&& put, char* stage, bf16* __
       }
     }
     put(j, stage);
+    if constexpr (EPI == 0) {
+      if (R && j + 1 < NJ) {
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch_r(j + 1);
+      }
+    }
     if constexpr (EPI != 0) {
       __builtin_amdgcn_sched_barrier(0);  // (hoisted above put(), the next block's loads would not find free registers)
       if (j + 1 < NJ) prefetch(j + 1);
