@@ -205,12 +205,13 @@ int edm_scalelong_bwd(const float* mean, const float* W1h, const float* W2h, con
 /* The two steps above in ONE launch per direction (one workgroup per sample: mean over H*W in a fixed order, then the
  * sample's gate MLP from LDS).  fwd: skip [B*HW][C] bf16 -> mean, gate [B][C], z1save [B][R].  bwd: channels
  * [c_off, c_off+C) of gcat (rows of gcat_stride elements) are d loss / d (skip*gate); ggate = sum_hw gcat*skip is formed
- * and consumed in place; gW1h / gW2h are accumulated (caller zero-fills), gmean written. */
+ * and consumed in place; gmean, gW1h [R][C+1] and gW2h [C][R] are written (the weight gradients by a second small launch
+ * that sums the per-sample outer products over the batch in a fixed order); ws: [B][C + 2R] floats of scratch. */
 int edm_skip_gate_fwd(const void* skip, const float* W1h, const float* W2h, float* mean, float* gate, float* z1save,
                       int B, int HW, int C, int R, edm_stream_t stream);
 int edm_skip_gate_bwd(const void* gcat, long gcat_stride, int c_off, const void* skip, const float* mean,
                       const float* W1h, const float* W2h, const float* gate, const float* z1save, float* gmean,
-                      float* gW1h, float* gW2h, int B, int HW, int C, int R, edm_stream_t stream);
+                      float* gW1h, float* gW2h, float* ws, int B, int HW, int C, int R, edm_stream_t stream);
 /* cat = [inp, skip*gate] (networks.py:311) and backward */
 int edm_concat_gate_fwd(const void* inp, const void* skip, const float* gate, void* cat, void* silu_out, int B, int HW,
                         int Ci, int Cs, edm_stream_t stream);

@@ -34,7 +34,7 @@ SIGNATURES = {
     "edm_scalelong_fwd": [P, P, P, P, P, I, I, I, P],
     "edm_scalelong_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, P],
     "edm_skip_gate_fwd": [P, P, P, P, P, P, I, I, I, I, P],
-    "edm_skip_gate_bwd": [P, L, I, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "edm_skip_gate_bwd": [P, L, I, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     "edm_concat_gate_fwd": [P, P, P, P, P, I, I, I, I, P],
     "edm_concat_gate_bwd": [P, P, P, P, P, I, I, I, I, P],
     "edm_precond_in": [P, P, I, F, P, I, I, I, I, P],

@@ -552,6 +552,21 @@ extern "C" int edm_reduce_hw(const void* x, long x_stride, const void* y, long y
   return EDM_OK;
 }
 
+// s = sum_r w[r * stride] * v[r], the loads issued 16 at a time (the plain loop waits for one L2 round trip per term)
+__device__ __forceinline__ float strided_dot(const float* __restrict__ w, long stride, const float* v, int n) {
+  float s = 0.f;
+  int r = 0;
+  for (; r + 16 <= n; r += 16) {
+    float t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = w[(long)(r + k) * stride];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += t[k] * v[r + k];
+  }
+  for (; r < n; ++r) s += w[(long)r * stride] * v[r];
+  return s;
+}
+
 // per-sample gate MLP, fp32:  m=[mean;1] -> z1=W1 m -> h=mp_silu(z1) -> z2=W2 h -> gate=sigmoid(z2)
 // W1h [R][C+1], W2h [C][R] are effective (normalised, /sqrt(fan_in)) fp32 weights.
 __global__ void k_scalelong_fwd(const float* __restrict__ mean, const float* __restrict__ W1, const float* __restrict__ W2,
@@ -574,11 +589,7 @@ __global__ void k_scalelong_fwd(const float* __restrict__ mean, const float* __r
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float s = 0.f;
-    for (int r = 0; r < R; ++r) s += W2[(long)c * R + r] * h[r];
-    gate[(long)b * C + c] = sigmoidf_(s);
-  }
+  for (int c = threadIdx.x; c < C; c += blockDim.x) gate[(long)b * C + c] = sigmoidf_(strided_dot(W2 + (long)c * R, 1, h, R));
 }
 // backward: ggate[b,C] -> gmean[b,C], gW1 += , gW2 += (fp32 atomics; tiny)
 __global__ void k_scalelong_bwd(const float* __restrict__ mean, const float* __restrict__ W1, const float* __restrict__ W2,
@@ -710,50 +721,75 @@ __global__ __launch_bounds__(1024) void k_skip_gate_fwd(const bf16* __restrict__
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float s = 0.f;
-    for (int r = 0; r < R; ++r) s += W2[(long)c * R + r] * h[r];
-    gate[(long)b * C + c] = sigmoidf_(s);
-  }
+  for (int c = threadIdx.x; c < C; c += blockDim.x) gate[(long)b * C + c] = sigmoidf_(strided_dot(W2 + (long)c * R, 1, h, R));
 }
-// backward: ggate[b,c] = sum_hw gcat[b,hw,Ci+c] * skip[b,hw,c], then the MLP backward of k_scalelong_bwd
+// backward: ggate[b,c] = sum_hw gcat[b,hw,Ci+c] * skip[b,hw,c], then the MLP backward of k_scalelong_bwd per sample.
+// The weight gradients are sums over the batch of per-sample outer products; adding them with atomics from every
+// workgroup (the first form of this kernel) meant B-way contention on each of the 2 C R addresses -- 20 us per launch
+// whatever the image size.  Each workgroup now leaves its vectors (d z2, d z1, h) in ws[b][C + 2R] and
+// k_skip_gate_wgrad sums the outer products over b in a fixed order.
 __global__ __launch_bounds__(1024) void k_skip_gate_bwd(const bf16* __restrict__ gcat, long gs, const bf16* __restrict__ skip,
-                                                          const float* __restrict__ mean, const float* __restrict__ W1,
-                                                          const float* __restrict__ W2, const float* __restrict__ gate,
-                                                          const float* __restrict__ z1save, float* __restrict__ gmean,
-                                                          float* __restrict__ gW1, float* __restrict__ gW2, int HW, int C,
+                                                          const float* __restrict__ W1, const float* __restrict__ W2,
+                                                          const float* __restrict__ gate, const float* __restrict__ z1save,
+                                                          float* __restrict__ gmean, float* __restrict__ ws, int HW, int C,
                                                           int R) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // red[rpp*C] | gz2[C] | m[C+1] | h[R] | gz1[R]
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // red[rpp*C] | gz2[C] | gz1[R]
   const int rpp = blockDim.x / (C >> 3);
   float* red = sm;
   float* gz2 = sm + rpp * C;
-  float* m = gz2 + C;
-  float* h = m + C + 1;
-  float* gz1 = h + R;
+  float* gz1 = gz2 + C;
   const int b = blockIdx.x;
+  float* wsb = ws + (long)b * (C + 2 * R);
   sample_reduce<true>(gcat + (long)b * HW * gs, gs, skip + (long)b * HW * C, C, HW, C, red, gz2, 1.0f);   // gz2 <- ggate
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    m[c] = mean[(long)b * C + c];
     const float g = gate[(long)b * C + c];
     gz2[c] *= g * (1.0f - g);
+    wsb[c] = gz2[c];
   }
-  if (threadIdx.x == 0) m[C] = 1.0f;
-  for (int r = threadIdx.x; r < R; r += blockDim.x) h[r] = mp_silu_f(z1save[(long)b * R + r]);
+  for (int r = threadIdx.x; r < R; r += blockDim.x) wsb[C + R + r] = mp_silu_f(z1save[(long)b * R + r]);
   __syncthreads();
-  for (int i = threadIdx.x; i < C * R; i += blockDim.x) atomicAdd(gW2 + i, gz2[i / R] * h[i % R]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (int r = wave; r < R; r += nw) {
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += W2[(long)c * R + r] * gz2[c];
     s = wave_sum(s);
-    if (lane == 0) gz1[r] = s * mp_silu_grad_f(z1save[(long)b * R + r]);
+    if (lane == 0) {
+      gz1[r] = s * mp_silu_grad_f(z1save[(long)b * R + r]);
+      wsb[C + r] = gz1[r];
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < R * (C + 1); i += blockDim.x) atomicAdd(gW1 + i, gz1[i / (C + 1)] * m[i % (C + 1)]);
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) gmean[(long)b * C + c] = strided_dot(W1 + c, C + 1, gz1, R);
+}
+// gW2[c][r] = sum_b dz2[b][c] h[b][r];  gW1[r][c'] = sum_b dz1[b][r] [mean[b]; 1][c']   (b ascending: reproducible).
+// A workgroup owns four columns of the C (resp. C+1) dimension and all R rows: it stages A[b][4] and Bm[b][R] in LDS with
+// every load in flight at once, then each thread sums its (column, row) pair over b.  blockIdx < CT: gW2, else gW1.
+__global__ __launch_bounds__(256) void k_skip_gate_wgrad(const float* __restrict__ ws, const float* __restrict__ mean,
+                                                           float* __restrict__ gW1, float* __restrict__ gW2, int B, int C,
+                                                           int R, int CT) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // A[B][4] | Bm[B][R]
+  float* A = sm;
+  float* Bm = sm + 4 * B;
+  const int W = C + 2 * R;
+  const bool second = blockIdx.x >= CT;
+  const int c0 = (second ? blockIdx.x - CT : blockIdx.x) * 4;
+  const int ncol = second ? C + 1 : C;
+  for (int i = threadIdx.x; i < 4 * B; i += blockDim.x) {
+    const int b = i >> 2, c = c0 + (i & 3);
+    float v = 0.f;
+    if (c < ncol) v = second ? (c < C ? mean[(long)b * C + c] : 1.0f) : ws[(long)b * W + c];
+    A[i] = v;
+  }
+  const int boff = second ? C : C + R;     // Bm = dz1 (gW1) or h (gW2)
+  for (int i = threadIdx.x; i < B * R; i += blockDim.x) Bm[i] = ws[(long)(i / R) * W + boff + i % R];
+  __syncthreads();
+  for (int o = threadIdx.x; o < 4 * R; o += blockDim.x) {
+    const int cc = o / R, r = o % R;
+    if (c0 + cc >= ncol) continue;
     float s = 0.f;
-    for (int r = 0; r < R; ++r) s += W1[(long)r * (C + 1) + c] * gz1[r];
-    gmean[(long)b * C + c] = s;
+    for (int b = 0; b < B; ++b) s += A[b * 4 + cc] * Bm[b * R + r];
+    if (second) gW1[(long)r * (C + 1) + c0 + cc] = s;
+    else gW2[(long)(c0 + cc) * R + r] = s;
   }
 }
 static inline int skip_gate_threads(int C) {   // a multiple of the C/8 lanes of a pixel row, <= 1024
@@ -774,19 +810,24 @@ extern "C" int edm_skip_gate_fwd(const void* skip, const float* W1h, const float
   EDM_CHECK_LAUNCH("skip_gate_fwd");
   return EDM_OK;
 }
-// gcat rows of gcat_stride elements whose channels [c_off, c_off + C) are the gradient of skip * gate; gW1h / gW2h are
-// ACCUMULATED (zero-filled by the caller), gmean [B][C] written
+// gcat rows of gcat_stride elements whose channels [c_off, c_off + C) are the gradient of skip * gate; gmean [B][C],
+// gW1h [R][C+1] and gW2h [C][R] are WRITTEN; ws: [B][C + 2R] floats of scratch (two launches: per-sample pass, then the
+// batch sums of the weight gradients)
 extern "C" int edm_skip_gate_bwd(const void* gcat, long gcat_stride, int c_off, const void* skip, const float* mean,
                                  const float* W1h, const float* W2h, const float* gate, const float* z1save, float* gmean,
-                                 float* gW1h, float* gW2h, int B, int HW, int C, int R, hipStream_t st) {
-  EDM_REQUIRE(gcat && skip && mean && W1h && W2h && gate && z1save && gmean && gW1h && gW2h, "skip_gate_bwd: null pointer");
+                                 float* gW1h, float* gW2h, float* ws, int B, int HW, int C, int R, hipStream_t st) {
+  EDM_REQUIRE(gcat && skip && mean && W1h && W2h && gate && z1save && gmean && gW1h && gW2h && ws, "skip_gate_bwd: null pointer");
   EDM_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 8 == 0 && C <= 4096 && R > 0 && R <= 1024 && c_off >= 0 && c_off % 8 == 0 &&
                   gcat_stride >= c_off + C && gcat_stride % 8 == 0, "skip_gate_bwd: bad args");
   const int threads = skip_gate_threads(C);
   EDM_REQUIRE(threads > 0, "skip_gate_bwd: C too large");
-  const size_t lds = ((size_t)(threads / (C / 8)) * C + 2 * C + 1 + 2 * R) * sizeof(float);
+  const size_t lds = ((size_t)(threads / (C / 8)) * C + C + R) * sizeof(float);
   hipLaunchKernelGGL(k_skip_gate_bwd, dim3(B), dim3(threads), lds, st, (const bf16*)gcat + c_off, gcat_stride,
-                     (const bf16*)skip, mean, W1h, W2h, gate, z1save, gmean, gW1h, gW2h, HW, C, R);
+                     (const bf16*)skip, W1h, W2h, gate, z1save, gmean, ws, HW, C, R);
+  const int CT = (C + 3) / 4, CT1 = (C + 4) / 4;
+  const size_t lds2 = ((size_t)4 * B + (size_t)B * R) * sizeof(float);
+  EDM_REQUIRE(lds2 <= 64 * 1024, "skip_gate_bwd: B * R too large for the weight-gradient pass");
+  hipLaunchKernelGGL(k_skip_gate_wgrad, dim3(CT + CT1), dim3(256), lds2, st, ws, mean, gW1h, gW2h, B, C, R, CT);
   EDM_CHECK_LAUNCH("skip_gate_bwd");
   return EDM_OK;
 }

@@ -350,10 +350,11 @@ def skip_gate_bwd(gcat, Ci, skip, mean, w1h, w2h, gate, z1):
     _chk(w1h, f32, "w1h", (R, C + 1))
     _chk(w2h, f32, "w2h", (C, R))
     gmean = torch.empty(B, C, device=skip.device, dtype=f32)
-    gw1 = zeros_f32(w1h.shape, w1h.device)
-    gw2 = zeros_f32(w2h.shape, w2h.device)
+    gw1 = torch.empty(w1h.shape, device=w1h.device, dtype=f32)
+    gw2 = torch.empty(w2h.shape, device=w2h.device, dtype=f32)
+    ws = torch.empty(B, C + 2 * R, device=skip.device, dtype=f32)
     _lib.call("edm_skip_gate_bwd", _p(gcat), Ct, Ci, _p(skip), _p(mean), _p(w1h), _p(w2h), _p(gate), _p(z1), _p(gmean),
-              _p(gw1), _p(gw2), B, H * W, C, R, _stream())
+              _p(gw1), _p(gw2), _p(ws), B, H * W, C, R, _stream())
     return gmean, gw1, gw2
 
 
