@@ -59,6 +59,14 @@ __device__ __forceinline__ void lgkm_wait() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+#ifdef EDM_V6_TIMELINE   // diagnostic build only (tools/v6_timeline.py): per-workgroup timestamps of the kernel's phases
+__device__ unsigned long long* g_v6_timeline = nullptr;
+#define V6_STAMP(slot)                                                                                          \
+  if (g_v6_timeline && threadIdx.x == 0) g_v6_timeline[(long)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define V6_STAMP(slot)
+#endif
+
 template <int NX, int EPI = 0, int NI = 4, bool WPTR64 = true, int WB = 0, bool LATE_DMA = false>
 __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ X, const bf16* __restrict__ Wp,
                                                          bf16* __restrict__ Y, const bf16* __restrict__ R,
@@ -66,6 +74,16 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
                                                          int Npix, int H, int W, int Cin, int Cout, int tiles_m,
                                                          int tiles_n, ModEpilogue mod) {
   apply_dyn(mod);
+  V6_STAMP(0);
+#ifdef EDM_V6_TIMELINE
+  if (g_v6_timeline && threadIdx.x == 0) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_v6_timeline[(long)blockIdx.x * 8 + 5] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
   constexpr int NJ = 2;               // 32-pixel blocks per wave (epilogue units)
   constexpr int NA = 2 * NI, NAH = NI;  // 16-channel weight fragments per step / per half
   constexpr int NB = 4;               // 16-pixel fragments per wave
@@ -265,6 +283,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
         }
       }
       __builtin_amdgcn_s_barrier();
+#ifdef EDM_V6_TIMELINE
+      if (u == 0 && chunk2 == 0) { V6_STAMP(1); }
+#endif
       // ---- this step's DMAs: weight tile t+D into the ring slot read at step t-1, and (tap 0) the next slab.  An LDS-DMA
       // instruction holds the issuing wave for 60-180 cycles and the two waves of a SIMD leave the barrier together.
       // LATE_DMA (waves 4-7 issue in the middle of the step instead, so that one partner multiplies while the other
@@ -343,6 +364,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
   lgkm_wait<0>();                // the last step's (unused) prefetch
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // asm MFMA results -> first read by ordinary code
   __builtin_amdgcn_s_barrier();  // every wave is done with the slab / weight ring
+  V6_STAMP(2);
   if constexpr (EPI == 1) {
     const bool wave_rows = mod.HW % (32 * NJ) == 0;   // a wave's 64 pixels lie in one sample
     store_tile_transposed16<NI, NJ, EPI>(acc, smem + wave * (32 * (NI * 64 + 16)), Y, R, alpha, beta,
@@ -373,6 +395,11 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
     store_tile_transposed16<NI, NJ, EPI>(acc, smem + wave * (32 * (NI * 64 + 16)), Y, R, alpha, beta,
                                          (long)m0 + wave * (32 * NJ), Npix, n0, Cout, mod);
   }
+  V6_STAMP(3);
+#ifdef EDM_V6_TIMELINE
+  __builtin_amdgcn_s_waitcnt(0);   // stores retired
+  V6_STAMP(4);
+#endif
 }
 
 template <int NX, int EPI, int NI, int WB = 0>
@@ -431,6 +458,12 @@ int edm_conv_igemm_v6_ex(const void* X, const void* Wp, void* Y, const void* R, 
   EDM_CHECK_LAUNCH("conv_igemm_v6");
   return EDM_OK;
 }
+
+#ifdef EDM_V6_TIMELINE
+extern "C" int edm_v6_set_timeline(unsigned long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_v6_timeline), &buf, sizeof(buf)) == hipSuccess ? EDM_OK : EDM_ERR_LAUNCH;
+}
+#endif
 
 extern "C" int edm_conv_igemm_v6(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B,
                                  int H, int W, int Cin, int Cout, int taps, hipStream_t st) {
