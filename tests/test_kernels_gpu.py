@@ -288,7 +288,7 @@ def test_conv3x3_modbwd_epilogue_matches_separate_kernels(ops, B, H, W, C1, C2, 
     assert rel(glin, glin_ref) <= 1e-5 and abs(gg.item() - gg_ref.item()) <= 1e-4 * (abs(gg_ref.item()) + 1e-3)
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout,pdrop", [(3, 16, 16, 128, 64, 0.25), (2, 4, 8, 64, 72, 0.1), (128, 32, 32, 256, 256, 0.13),
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pdrop", [(3, 16, 16, 128, 64, 0.25), (2, 4, 8, 64, 72, 0.1), (1, 5, 7, 64, 72, 0.2), (128, 32, 32, 256, 256, 0.13),
                                                    (128, 16, 16, 256, 256, 0.13), (128, 8, 8, 256, 256, 0.13),
                                                    (512, 8, 8, 64, 256, 0.1), (2, 8, 8, 64, 128, 0.0)])
 def test_dropout_marks_in_saved_preactivation(ops, B, H, W, Cin, Cout, pdrop):
@@ -310,19 +310,20 @@ def test_dropout_marks_in_saved_preactivation(ops, B, H, W, Cin, Cout, pdrop):
     assert torch.equal(torch.where(keep, um, u), u)
     if pdrop > 0:
         assert abs((~keep).float().mean().item() - pdrop) < 0.02
-    if (H * W) % 32:
-        return
     gout = nhwc(q(torch.randn(B, Cin, H, W, generator=g)))
     wd = pack_fwd(q(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)))
-    gr_ref, glin_ref, gg_ref = ops.conv3x3_modbwd(gout, wd, 0.8, u, lin, gain, pdrop, 1234, 5, 6)
+    ga = ops.conv_igemm(gout, wd, 9, alpha=0.8)
+    gr_ref, glin_ref, gg_ref = ops.mod_silu_drop_bwd(u, lin, gain, ga, pdrop, 1234, 5, 6)
+    # the separate backward kernel (layers whose H*W is not a multiple of 32 take it) accepts the marked tensor
+    gr2, glin2, gg2 = ops.mod_silu_drop_bwd(um, lin, gain, ga, pdrop, 1234, 5, 6)
+    assert torch.equal(gr2, gr_ref) and torch.isfinite(glin2).all() and rel(glin2, glin_ref) <= 1e-5
+    assert abs(gg2.item() - gg_ref.item()) <= 1e-4 * (abs(gg_ref.item()) + 1e-3)
+    if (H * W) % 32:
+        return
     gr, glin, gg = ops.conv3x3_modbwd(gout, wd, 0.8, um, lin, gain, pdrop, 999, 1, 2, u_marked=True)   # (seed / stream unused)
     assert torch.equal(gr, gr_ref)
     assert torch.isfinite(glin).all() and rel(glin, glin_ref) <= 1e-5
     assert abs(gg.item() - gg_ref.item()) <= 1e-4 * (abs(gg_ref.item()) + 1e-3)
-    # the separate backward kernel (layers whose H*W is not a multiple of 32 take it) accepts the marked tensor too
-    ga = ops.conv_igemm(gout, wd, 9, alpha=0.8)
-    gr2, glin2, gg2 = ops.mod_silu_drop_bwd(um, lin, gain, ga, pdrop, 1234, 5, 6)
-    assert torch.equal(gr2, gr_ref) and torch.isfinite(glin2).all() and rel(glin2, glin_ref) <= 1e-5
 
 
 @pytest.mark.parametrize("B,H,W,C1,C2", [(2, 8, 8, 64, 128), (3, 5, 7, 128, 72), (128, 32, 32, 256, 256)])
