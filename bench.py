@@ -110,6 +110,33 @@ def build_model(device, conditional=False):
     return model, cfg
 
 
+def timed_region(args, step, world, device, marks=None, last=None):
+    """The contract's timed region: EXACTLY args.steps steps between barrier + synchronize on both sides, MAX over ranks.
+    marks (optional) receives the host timestamps t0, t1 .. tK; last the final step's loss."""
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if marks is not None:
+        marks.append(t0)
+    loss = None
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+        if marks is not None:
+            marks.append(time.perf_counter())
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    if last is not None:
+        last.append(loss)
+    return dt
+
+
 def train_bench(args, rank, world, device):
     import tinyedm
     from tinyedm_amd import ops
@@ -181,6 +208,32 @@ def train_bench(args, rank, world, device):
         e_ms, e_host, e_calls = probe(eager_step, 10)
         launch_info = {"eager_probe_ms": round(e_ms, 3), "host_enqueue_ms_per_step": round(e_host, 3),
                        "entry_point_calls_per_step": round(e_calls, 1)}
+    watchdog = None
+    if can_graph and mode in ("auto", "graph") and (world > 1 or os.environ.get("EDM_BENCH_WATCHDOG") == "1"):   # (test hook)
+        # Insurance for the one configuration this code cannot rehearse on a one-GPU box: capturing a step whose RCCL
+        # all-reduces span several ranks.  A capture that RAISES falls back to the eager step below; one that HANGS would
+        # leave the job without its line -- so the eager step is timed first (the contract's K steps, barriers and all), and
+        # a timer prints that line and ends every rank if capture + first replays have not finished after 180 s.
+        import threading
+        e_dt = timed_region(args, eager_step, world, device)
+
+        def bail():
+            if rank == 0:
+                line = {"metric": "train imgs/sec CIFAR-10 32x32 bf16", "value": round(args.batch * world * args.steps / e_dt, 2),
+                        "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                        "ms_per_step": round(e_dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                        "config": {"workload": "CIFAR-10 32x32 unconditional EDM2 U-Net (conf/cifar10.yaml, 35.6M params) "
+                                               "full training step: diffuse+embed+denoiser fwd/bwd+loss+grad all-reduce+Adam+EMA",
+                                   "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                                   "step_launch": "eager (capturing the collective-bearing step did not finish in 180 s)",
+                                   "collective": "rccl bucketed all-reduce", **launch_info}}
+                print(json.dumps(line), flush=True)
+            note("graph capture watchdog fired: eager figures reported, leaving")
+            os._exit(0)
+        watchdog = threading.Timer(float(os.environ.get("EDM_BENCH_CAPTURE_TIMEOUT", "180")), bail)
+        watchdog.daemon = True
+        watchdog.start()
     if can_graph and mode in ("auto", "graph"):
         from tinyedm_amd.graph import CapturedTrainStep
         captured, ok = None, 1
@@ -210,31 +263,20 @@ def train_bench(args, rank, world, device):
             mode = "graph" if float(pair[0]) < float(pair[1]) else "eager"
         note(f"step launch probe: eager {launch_info['eager_probe_ms']:.2f} ms (host enqueue {e_host:.2f} ms), "
              f"hipGraph replay {g_ms:.2f} ms -> timing the {mode} step")
+    if watchdog is not None:
+        watchdog.cancel()
     if mode == "graph":
         def step(i):                            # noqa: F811
             return captured(batch)
     use_graph = mode == "graph"
     launch_info["step_launch"] = "hipGraph replay" if use_graph else "eager"
     note(f"warmup done, timing {args.steps} steps ({launch_info['step_launch']})")
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    marks = []
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
-        marks.append(time.perf_counter())
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    host = [(b - a) * 1e3 for a, b in zip([t0] + marks[:-1], marks)]
+    marks, last = [], []
+    dt = timed_region(args, step, world, device, marks, last)
+    host = [(b - a) * 1e3 for a, b in zip(marks[:-1], marks[1:])]
     launch_info["host_step_ms_max"] = round(max(host), 2)
     launch_info["host_step_ms_median"] = round(sorted(host)[len(host) // 2], 2)
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    loss = last[0]
     final_loss = float(loss.detach())
     wnorm = float(base.arena.theta.norm())
     if not (final_loss == final_loss and abs(final_loss) < 1e4 and wnorm == wnorm and wnorm < 1e6):

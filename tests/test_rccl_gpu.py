@@ -195,3 +195,19 @@ def test_bench_and_fit_through_the_nccl_backend_on_one_gpu(tmp_path):
     # the collective-bearing step is host-cheap: the all-reduces are nodes of the replayed graph
     assert line["config"]["graph_host_ms_per_step"] <= 5.0, line["config"]
     assert line["config"]["step_launch"] in ("hipGraph replay", "eager")
+
+
+def test_bench_capture_watchdog_reports_the_eager_line(tmp_path):
+    """bench.py times the eager step first when the captured step would contain multi-rank collectives, and a timer prints
+    that line and ends the process if capture + first replays do not finish (a hang there cannot be rehearsed on one GPU).
+    EDM_BENCH_WATCHDOG=1 arms the timer with one rank, EDM_BENCH_CAPTURE_TIMEOUT makes it fire at once."""
+    env = dict(os.environ, EDM_FORCE_REDUCE="1", EDM_BENCH_WATCHDOG="1", EDM_BENCH_CAPTURE_TIMEOUT="0.001", WORLD_SIZE="1",
+               RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--batch", "16",
+                        "--no-sampler", "--no-cpu-baseline", "--step-launch", "graph"], capture_output=True, text=True, env=env,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["steps"] == 3 and line["value"] > 0 and line["ms_per_step"] > 0
+    assert line["config"]["step_launch"].startswith("eager (capturing"), line["config"]
+
