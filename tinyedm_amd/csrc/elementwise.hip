@@ -956,25 +956,31 @@ __global__ __launch_bounds__(256) void k_conv_out_fwd(const bf16* __restrict__ x
       for (int c8 = lig; c8 < CL; c8 += LPP) {
         float v[8];
         load8(x + p * C + c8 * 8, v);
-        for (int o = 0; o < Co; ++o) {
-          const float* wp = wh + (long)o * C + c8 * 8;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[o] += v[j] * wp[j];
+        for (int o = 0; o < 8; ++o) {
+          if (o < Co) {
+            const float* wp = wh + (long)o * C + c8 * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[o] += v[j] * wp[j];
+          }
         }
       }
     }
 #pragma unroll
-    for (int o = 0; o < 8; ++o) acc[o] = group_sum<LPP>(acc[o]);
+    for (int o = 0; o < 8; ++o)
+      if (o < Co) acc[o] = group_sum<LPP>(acc[o]);   // (Co is 3 or 4: the unconditional form spent 25 of its 40 shuffles on zeros)
     if (pv && lig == 0) {
-      long b = p / HW;
-      int hw = (int)(p % HW);
+      const int b = (int)p / HW, hw = (int)p - b * HW;     // (npix < 2^31: host-checked; the 64-bit division cost 100+ instructions)
       float s = sigma[b * sstride];
       float den = s * s + sd * sd;
       float cskip = sd * sd / den, cout = s * sd * rsqrtf(den);
-      for (int o = 0; o < Co; ++o) {
-        long idx = (b * Co + o) * HW + hw;
-        if (Fraw) Fraw[idx] = acc[o];
-        D[idx] = acc[o] * go * cout + noisy[idx] * cskip;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        if (o < Co) {
+          long idx = ((long)b * Co + o) * HW + hw;
+          if (Fraw) Fraw[idx] = acc[o];
+          D[idx] = acc[o] * go * cout + noisy[idx] * cskip;
+        }
       }
     }
   }
@@ -985,6 +991,7 @@ extern "C" int edm_conv_out_fwd(const void* x, const float* w_hat, const float* 
   EDM_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && Co >= 1 && Co <= 8 && (sigma_stride == 0 || sigma_stride == 1),
               "conv_out_fwd: bad args (Co<=8 required)");
   long npix = (long)B * HW;
+  EDM_REQUIRE(npix < (1L << 31), "conv_out_fwd: too many pixels");
   hipLaunchKernelGGL(k_conv_out_fwd<32>, dim3(grid_for(npix, 8)), dim3(256), 0, st, (const bf16*)x, w_hat, gain_out,
                      noisy, sigma, sigma_stride, sigma_data, D, Fraw, HW, C, Co, npix);
   EDM_CHECK_LAUNCH("conv_out_fwd");
