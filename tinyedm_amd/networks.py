@@ -133,7 +133,7 @@ WGRAD_STREAM = os.environ.get("EDM_WGRAD_STREAM", "1") != "0"
 # largest layer (pixels) that joins a group.  A layer with more pixels fills the chip alone and its per-layer launch
 # overlaps the backward pass at a finer grain (ImageNet-64 config, 64x64 layers at batch 176: 144 vs 147 ms).  Only with
 # the side stream: on one chain (captured step) everything is grouped (154.6 vs 161 ms).
-W3_GROUP = max(0, min(16, int(os.environ.get("EDM_W3_GROUP", "12"))))
+W3_GROUP = max(0, min(16, int(os.environ.get("EDM_W3_GROUP", "16"))))
 W3_MAXPIX = int(os.environ.get("EDM_W3_MAXPIX", str(1 << 18)))
 FIN_GROUP = 40              # small weight gradients per multi-tensor finish launch (csrc/weights.hip)
 # 1x1 weight gradients: layers per grouped launch (csrc/conv_wgrad1x1.hip k_wgrad1x1_group; 0 = one launch per layer)
