@@ -515,7 +515,7 @@ def main():
                 # training image) over 8 TB/s; 70 % of it would need 7 PFLOP/s of bf16 MFMA (not reachable)
                 "northstar_hbm3x3_frac": round(ips / world * 59.7e6 / 1e9 / HBM_PEAK_GBS, 4),
                 # the other chip-filling MFMA kernel of the step: the grouped stream-K weight gradient (conv_wgrad3.hip)
-                "wgrad3": (lambda w: {"kernel": "k_wgrad3<1> (3x3 weight gradients, 4 grouped launches per step)",
+                "wgrad3": (lambda w: {"kernel": f"k_wgrad3<1> (3x3 weight gradients, {w['launches']} grouped launches per step)",
                                       "achieved": round(w["gflop"] / w["ms"], 2) if w["ms"] else 0.0,
                                       "frac": round(w["gflop"] / w["ms"] / MFMA_PEAK_TFLOPS, 4) if w["ms"] else 0.0,
                                       "avg_launch_ms": round(w["ms"] / max(1, w["launches"]), 4),
