@@ -20,6 +20,35 @@ import time
 # exports this already, keep it for hand launches.  Must be set before the HIP runtime initialises.
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+
+def _self_launch():
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start the N ranks as CHILD
+    processes -- `python -m torch.distributed.run --nproc-per-node N bench.py <same flags>`, the reference's
+    `trainer.devices: N` / `strategy: ddp` (/root/reference/experiments/conf/cifar10.yaml:4-8) -- relay their output
+    (stdout is inherited: rank 0's ONE JSON line) and exit with their return code.  This runs before torch is imported:
+    the parent never touches the GPU and nothing that has is ever re-exec'ed."""
+    if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    pre = argparse.ArgumentParser(add_help=False)
+    pre.add_argument("--gpus", type=int, default=1)
+    n = pre.parse_known_args()[0].gpus
+    if n <= 1:
+        return
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    sys.exit(subprocess.run(cmd).returncode)
+
+
+if __name__ == "__main__":
+    _self_launch()
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -80,6 +109,13 @@ def pmc_traffic(kernel):
         return None if rec is None else round(rec["hbm_gb_per_launch"], 4)
     except (OSError, ValueError, KeyError, IndexError):
         return None
+
+
+def pmc_source():
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
+    return ("offline: " + os.path.relpath(paths[-1], ROOT) + " (committed rocprofv3 --pmc passes of this command on the replayed "
+            "graph; counters cannot be read from inside the timed process)") if paths else None
 
 
 def vendor_gemm_tflops(device, M=131072, N=256, K=2304, iters=10):
@@ -177,6 +213,13 @@ def train_bench(args, rank, world, device):
     eager_step = step
     from tinyedm_amd import _lib as _L, _runtime_env as _RE
     can_graph = _RE.GRAPH_REPLAY_SAFE and (not reducer.active or reducer.capturable())
+    if args.step_launch == "graph" and not can_graph:
+        # an explicit request that cannot be honoured is an error, not a silent eager run (a profile labelled "graph replay"
+        # must be one): e.g. under `rocprofv3 --pmc` the profiler initialises the GPU before python starts, so the runtime
+        # flag must be inherited (export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0)
+        raise SystemExit("bench.py: --step-launch graph, but hipGraph replay is not available here ("
+                         + ("the HIP runtime was initialised before DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 could be set: export it"
+                            if not _RE.GRAPH_REPLAY_SAFE else "the reducer's collectives are not capturable") + ")")
     mode = args.step_launch if can_graph else "eager"
     launch_info = {}
     opt.zero_grad()
@@ -216,21 +259,35 @@ def train_bench(args, rank, world, device):
         # a timer prints that line and ends every rank if capture + first replays have not finished after 180 s.
         import threading
         e_dt = timed_region(args, eager_step, world, device)
+        wd_lock = threading.Lock()              # bail() and the main thread agree on who prints the ONE line
+        wd_state = {"done": False, "phase": "capture: warm-up steps on the capture stream"}
 
         def bail():
-            if rank == 0:
-                line = {"metric": "train imgs/sec CIFAR-10 32x32 bf16", "value": round(args.batch * world * args.steps / e_dt, 2),
-                        "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                        "ms_per_step": round(e_dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-                        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                        "config": {"workload": "CIFAR-10 32x32 unconditional EDM2 U-Net (conf/cifar10.yaml, 35.6M params) "
-                                               "full training step: diffuse+embed+denoiser fwd/bwd+loss+grad all-reduce+Adam+EMA",
-                                   "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                                   "step_launch": "eager (capturing the collective-bearing step did not finish in 180 s)",
-                                   "collective": "rccl bucketed all-reduce", **launch_info}}
-                print(json.dumps(line), flush=True)
-            note("graph capture watchdog fired: eager figures reported, leaving")
-            os._exit(0)
+            with wd_lock:
+                if wd_state["done"]:            # the main thread got past capture + probe while the timer was firing
+                    return
+                wd_state["done"] = True
+                # what was stuck: the phase the main thread announced last, and how far the reducer got in this pass
+                fired = [i for i, b in enumerate(reducer.buckets) if b["work"] is not None]
+                where = (f"rank {rank}: {wd_state['phase']}; buckets issued this pass: {len(fired)} of {len(reducer.buckets)}"
+                         + (f" (last: #{fired[-1]}, arena [{reducer.buckets[fired[-1]]['lo']}, {reducer.buckets[fired[-1]]['hi']}))"
+                            if fired else ""))
+                note(f"graph capture watchdog fired -- {where}")
+                if rank == 0:
+                    line = {"metric": "train imgs/sec CIFAR-10 32x32 bf16", "value": round(args.batch * world * args.steps / e_dt, 2),
+                            "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                            "ms_per_step": round(e_dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                            "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "capture_hang": True,
+                            "config": {"workload": "CIFAR-10 32x32 unconditional EDM2 U-Net (conf/cifar10.yaml, 35.6M params) "
+                                                   "full training step: diffuse+embed+denoiser fwd/bwd+loss+grad all-reduce+Adam+EMA",
+                                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                                       "step_launch": "eager (capturing the collective-bearing step did not finish in time)",
+                                       "capture_hang_where": where,
+                                       "collective": "rccl bucketed all-reduce", **launch_info}}
+                    print(json.dumps(line), flush=True)
+                # the eager figures above are valid, but a hung capture / collective is a FAILURE of this run: say so to the
+                # launcher (never re-exec or retry from here: the process has touched the GPU)
+                os._exit(3)
         watchdog = threading.Timer(float(os.environ.get("EDM_BENCH_CAPTURE_TIMEOUT", "180")), bail)
         watchdog.daemon = True
         watchdog.start()
@@ -240,7 +297,14 @@ def train_bench(args, rank, world, device):
         try:
             captured = CapturedTrainStep(model, opt, reducer=reducer)
             for i in range(CapturedTrainStep.WARMUP + 1):    # warm-up on the capture stream, then the capture itself
+                if watchdog is not None:
+                    wd_state["phase"] = (f"capture: warm-up step {i}" if i < CapturedTrainStep.WARMUP else
+                                         "capture: stream capture of the step (training_step, backward, bucket all-reduces, Adam+EMA)")
                 captured(batch)
+            if captured.fallback:            # the step's own cross-rank agreement: some rank could not capture
+                ok = 0
+            if watchdog is not None:
+                wd_state["phase"] = "cross-rank agreement on the capture (all_reduce MIN)"
         except Exception as e:      # noqa: BLE001  (a runtime that cannot capture the collectives must not sink the line)
             note(f"capturing the step failed ({type(e).__name__}: {str(e)[:200]}); timing the eager step")
             ok = 0
@@ -252,8 +316,13 @@ def train_bench(args, rank, world, device):
             can_graph, mode = False, "eager"
             launch_info["graph_capture"] = "failed on at least one rank"
     if can_graph and mode in ("auto", "graph"):
+        if watchdog is not None:
+            wd_state["phase"] = "first replays of the captured step (graph upload + RCCL nodes)"
         for i in range(3):                                   # the first replays upload the executable graph
             captured(batch)
+        if watchdog is not None:
+            torch.cuda.synchronize()
+            wd_state["phase"] = "10-step replay probe"
         g_ms, g_host, _ = probe(lambda i: captured(batch), 10)
         launch_info.update({"graph_probe_ms": round(g_ms, 3), "graph_host_ms_per_step": round(g_host, 3)})
         if mode == "auto":
@@ -265,6 +334,8 @@ def train_bench(args, rank, world, device):
              f"hipGraph replay {g_ms:.2f} ms -> timing the {mode} step")
     if watchdog is not None:
         watchdog.cancel()
+        with wd_lock:                           # a timer that already started printing finishes (and exits) first
+            wd_state["done"] = True
     if mode == "graph":
         def step(i):                            # noqa: F811
             return captured(batch)
@@ -397,7 +468,7 @@ def cpu_baseline(args):
         return sum(times) / len(times), len(times)
 
     sec, n = leg(False, 12.0)
-    out = {"value": B / sec, "unit": "img/s", "cores": cores, "kind": "port",
+    out = {"value": B / sec, "unit": "img/s", "cores": cores, "cores_visible": os.cpu_count(), "kind": "port",
            "sample": f"{n} fp32 training steps of the CPU oracle (oracle/edm_oracle.py), batch {B}, same CIFAR-10 model, "
                      f"dropout 0.13, {sec:.2f} s/step"}
     try:
@@ -412,8 +483,8 @@ def cpu_baseline(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (100 x ~13 ms: the third digit of a 20-step run is noise)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (BASELINE.json configs[1]: 128)")
     ap.add_argument("--conditional", action="store_true")
     ap.add_argument("--sampler-batch", type=int, default=512)
@@ -466,7 +537,7 @@ def main():
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     model, ips, ms, final_loss, roof, launch_info = train_bench(args, rank, world, device)
     out = None
@@ -499,6 +570,7 @@ def main():
                                                    + ("v_mfma_f32_16x16x32_bf16" if mfma16 else "v_mfma_f32_32x32x16_bf16") + ")",
                 "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_source": pmc_source(),
                 "traffic_unit": "GB of HBM traffic per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc "
                                 "passes, newest profiles/r*_pmc_hbm.json)",
                 "algorithmic_gbytes_per_launch": round(conv["gbytes"] / max(1, conv["launches"]), 4),

@@ -211,3 +211,30 @@ def test_sampler_sentinel_trips_on_nonfinite_state():
     x0b[1, 0, 2, 2] = float("inf")
     with pytest.raises(ops.GraphCorruptionError, match="non-finite sampler state"):
         solver.solve(model, x0b, lab, graph=True)
+
+
+def test_fused_clear_is_not_trusted_after_an_eval_mode_backward():
+    """FusedAdam(fuse_zero_grad): step() clears the arena and the next zero_grad() is free ONLY if no gradient was written
+    since.  An eval-mode forward with autograd on (fine-tuning, parity runs with dropout off) writes gradients too: the
+    sequence step(); eval fwd/bwd; zero_grad() must leave the arena all-zero."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    model, _ = _build(pdrop=0.0)
+    opt, base, _ = _opt(model)
+    base.fuse_zero_grad = True
+    g = torch.Generator().manual_seed(6)
+    bt = ((0.5 * torch.randn(8, 3, 16, 16, generator=g)).to(DEV), torch.randint(0, 10, (8,), generator=g).to(DEV))
+    opt.zero_grad()
+    model.training_step(bt, 0).backward()
+    opt.step()                                  # clears the arena in the Adam pass
+    torch.cuda.synchronize()
+    assert float(base.arena.grad.abs().max()) == 0.0
+    model.eval()
+    with torch.enable_grad():
+        model.training_step(bt, 1).backward()   # eval-mode forward, gradients are written all the same
+    torch.cuda.synchronize()
+    assert float(base.arena.grad.abs().max()) > 0.0
+    opt.zero_grad()
+    torch.cuda.synchronize()
+    assert float(base.arena.grad.abs().max()) == 0.0
+    model.train()

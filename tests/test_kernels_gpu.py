@@ -476,7 +476,9 @@ def test_scalelong_concat(ops):
 
 
 @pytest.mark.parametrize("B,Ci,Cs,H,W", [(2, 64, 128, 8, 8), (3, 192, 192, 5, 7), (128, 256, 256, 32, 32), (4, 64, 768, 16, 16),
-                                          (2, 32, 1024, 4, 4)])
+                                          (2, 32, 1024, 4, 4),
+                                          # batches past one 64-KiB LDS chunk of the weight-gradient pass (B * (R + 4) > 16384):
+                                          (1024, 64, 256, 4, 4), (400, 64, 768, 2, 2)])
 def test_skip_gate_fused(ops, B, Ci, Cs, H, W):
     """edm_skip_gate_fwd / _bwd (mean over H*W + gate MLP and their backward in ONE launch each, one workgroup per sample)
     against the two-launch path (k_reduce_hw_det + k_scalelong_*) it replaces -- bit for bit in the forward (same fixed

@@ -304,21 +304,22 @@ def test_the_training_step_learns_a_small_dataset():
 
 
 def test_generate_cli_reference_precision(tmp_path):
-    """`python -m tinyedm.generate ... --network_dtype f32`: the sampler evaluates the denoiser through the exact-fp32
-    kernels (the reference samples in fp32, generate.py:39-44); images differ from the bf16 run by at most one grey
-    level on a handful of pixels, and both runs write every index"""
+    """`python -m tinyedm.generate ...` (default, = `--network_dtype f32`): the sampler evaluates the denoiser through the
+    exact-fp32 kernels (the reference samples in fp32, generate.py:39-44); the images of the opt-in bf16 fast mode differ
+    by at most a few grey levels on a handful of pixels, and every run writes every index"""
     import numpy as np
     from PIL import Image
     outs = {}
-    for dt in ("bf16", "f32"):
+    for dt in ("bf16", "f32", "default"):
         out = tmp_path / dt
         r = subprocess.run([sys.executable, "-m", "tinyedm.generate", "--config_name", "cifar10", "--output_dir", str(out),
                             "--num_samples", "6", "--image_size", "32", "--num_classes", "10", "--batch_size", "4",
-                            "--num_steps", "4", "--network_dtype", dt], capture_output=True, text=True, cwd=ROOT, timeout=600,
-                           env=dict(os.environ, PYTHONPATH=ROOT))
+                            "--num_steps", "4"] + ([] if dt == "default" else ["--network_dtype", dt]),
+                           capture_output=True, text=True, cwd=ROOT, timeout=600, env=dict(os.environ, PYTHONPATH=ROOT))
         assert r.returncode == 0, r.stderr[-2000:]
         files = sorted(glob.glob(str(out / "*.png")), key=lambda f: int(os.path.basename(f)[:-4]))
         assert [os.path.basename(f) for f in files] == [f"{i}.png" for i in range(6)]
         outs[dt] = np.stack([np.asarray(Image.open(f)).astype(int) for f in files])
+    assert np.array_equal(outs["default"], outs["f32"])      # no flag = the reference's precision (round 4)
     d = np.abs(outs["bf16"] - outs["f32"])
     assert d.max() <= 3 and (d > 0).mean() < 0.2, (d.max(), (d > 0).mean())

@@ -38,14 +38,36 @@ def _save_image(arr_hwc: np.ndarray, path: Path):
     Image.fromarray(a).save(path)
 
 
+class _eval_dtype:
+    """`with _eval_dtype(pl_module, "f32"):` -- the denoiser's evaluation precision for the duration of a sampling call"""
+
+    def __init__(self, pl_module, dtype):
+        self.den, self.dtype = getattr(pl_module, "denoiser", None), dtype
+        self.prev = None
+
+    def __enter__(self):
+        if self.den is not None and hasattr(self.den, "set_eval_dtype"):
+            self.prev = self.den.eval_dtype
+            self.den.set_eval_dtype(self.dtype)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            self.den.set_eval_dtype(self.prev)
+        return False
+
+
 class GenerateCallback:
     """Every ``every_n_epochs`` epochs: Heun-sample ``num_samples`` images from fixed noise with the EMA weights
     swapped in, denormalise to uint8 on the GPU and write a PNG mosaic (the reference logs it to wandb)."""
 
     def __init__(self, solver, img_shape: tuple[int, int, int], num_samples: int = 8, every_n_epochs=5,
-                 output_dir: str = "generated"):
+                 output_dir: str = "generated", network_dtype: str = "f32"):
         self.solver, self.num_samples, self.img_shape = solver, num_samples, tuple(img_shape)
         self.every_n_epochs, self.output_dir = every_n_epochs, Path(output_dir)
+        # the reference's callback samples outside Lightning's autocast context, i.e. in fp32 (callbacks.py:41-49): the
+        # default here too; "bf16" = the training path's kernels (fast mode)
+        self.network_dtype = network_dtype
         self.class_labels, self.x0, self.last_grid = None, None, None
 
     def on_train_start(self, trainer, pl_module):
@@ -64,7 +86,7 @@ class GenerateCallback:
             return
         was_training = pl_module.training
         pl_module.eval()
-        with torch.no_grad():
+        with torch.no_grad(), _eval_dtype(pl_module, self.network_dtype):
             if pl_module.use_ema:
                 with pl_module.swap_ema_weights(trainer):
                     xT = self.solver.solve(pl_module, self.x0, self.class_labels)
@@ -115,7 +137,8 @@ class LatentsGenerateCallback:
 
     def __init__(self, solver, img_shape: tuple[int, int, int], mean: tuple, std: tuple,
                  value_range: tuple[float, float] = (0, 1), num_samples_per_class: int = 8, num_classes=10,
-                 every_n_epochs=100, output_dir: str = "generated"):
+                 every_n_epochs=100, output_dir: str = "generated", network_dtype: str = "f32"):
+        self.network_dtype = network_dtype          # fp32 like the reference's callback (callbacks.py:95-104); "bf16" = fast mode
         self.solver, self.img_shape = solver, tuple(img_shape)
         self.num_samples_per_class, self.num_classes, self.every_n_epochs = num_samples_per_class, num_classes, every_n_epochs
         self.value_range, self.mean, self.std = tuple(value_range), mean, std
@@ -143,7 +166,7 @@ class LatentsGenerateCallback:
             return
         if trainer.current_epoch % self.every_n_epochs != 0:
             return
-        with torch.no_grad():
+        with torch.no_grad(), _eval_dtype(pl_module, self.network_dtype):
             labels = self.class_labels if pl_module.conditional else None
             if pl_module.use_ema:
                 with pl_module.swap_ema_weights(trainer):

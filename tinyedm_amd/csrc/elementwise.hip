@@ -763,33 +763,55 @@ __global__ __launch_bounds__(1024) void k_skip_gate_bwd(const bf16* __restrict__
 }
 // gW2[c][r] = sum_b dz2[b][c] h[b][r];  gW1[r][c'] = sum_b dz1[b][r] [mean[b]; 1][c']   (b ascending: reproducible).
 // A workgroup owns four columns of the C (resp. C+1) dimension and all R rows: it stages A[b][4] and Bm[b][R] in LDS with
-// every load in flight at once, then each thread sums its (column, row) pair over b.  blockIdx < CT: gW2, else gW1.
+// every load in flight at once, then each thread sums its (column, row) pairs over b.  blockIdx < CT: gW2, else gW1.
+// The batch is walked in chunks of BC samples (what 64 KiB of LDS holds; one chunk up to B * (R + 4) = 16384), the
+// partial sums stay in registers across chunks, so any batch size works and the order of the sum (b ascending) does not
+// depend on the chunking.
 __global__ __launch_bounds__(256) void k_skip_gate_wgrad(const float* __restrict__ ws, const float* __restrict__ mean,
                                                            float* __restrict__ gW1, float* __restrict__ gW2, int B, int C,
-                                                           int R, int CT) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // A[B][4] | Bm[B][R]
+                                                           int R, int CT, int BC) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // A[BC][4] | Bm[BC][R]
   float* A = sm;
-  float* Bm = sm + 4 * B;
+  float* Bm = sm + 4 * BC;
   const int W = C + 2 * R;
   const bool second = blockIdx.x >= CT;
   const int c0 = (second ? blockIdx.x - CT : blockIdx.x) * 4;
   const int ncol = second ? C + 1 : C;
-  for (int i = threadIdx.x; i < 4 * B; i += blockDim.x) {
-    const int b = i >> 2, c = c0 + (i & 3);
-    float v = 0.f;
-    if (c < ncol) v = second ? (c < C ? mean[(long)b * C + c] : 1.0f) : ws[(long)b * W + c];
-    A[i] = v;
-  }
   const int boff = second ? C : C + R;     // Bm = dz1 (gW1) or h (gW2)
-  for (int i = threadIdx.x; i < B * R; i += blockDim.x) Bm[i] = ws[(long)(i / R) * W + boff + i % R];
-  __syncthreads();
-  for (int o = threadIdx.x; o < 4 * R; o += blockDim.x) {
+  constexpr int MAXO = 16;                 // 4 * R / 256 outputs per thread, R <= 1024
+  float acc[MAXO];
+#pragma unroll
+  for (int k = 0; k < MAXO; ++k) acc[k] = 0.f;
+  for (int b0 = 0; b0 < B; b0 += BC) {
+    const int nb = min(BC, B - b0);
+    if (b0) __syncthreads();
+    for (int i = threadIdx.x; i < 4 * nb; i += blockDim.x) {
+      const int b = b0 + (i >> 2), c = c0 + (i & 3);
+      float v = 0.f;
+      if (c < ncol) v = second ? (c < C ? mean[(long)b * C + c] : 1.0f) : ws[(long)b * W + c];
+      A[i] = v;
+    }
+    for (int i = threadIdx.x; i < nb * R; i += blockDim.x) Bm[i] = ws[(long)(b0 + i / R) * W + boff + i % R];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXO; ++k) {
+      const int o = threadIdx.x + k * 256;
+      if (o < 4 * R) {
+        const int cc = o / R, r = o % R;
+        float s = acc[k];
+        for (int b = 0; b < nb; ++b) s += A[b * 4 + cc] * Bm[b * R + r];
+        acc[k] = s;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < MAXO; ++k) {
+    const int o = threadIdx.x + k * 256;
+    if (o >= 4 * R) continue;
     const int cc = o / R, r = o % R;
     if (c0 + cc >= ncol) continue;
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += A[b * 4 + cc] * Bm[b * R + r];
-    if (second) gW1[(long)r * (C + 1) + c0 + cc] = s;
-    else gW2[(long)(c0 + cc) * R + r] = s;
+    if (second) gW1[(long)r * (C + 1) + c0 + cc] = acc[k];
+    else gW2[(long)(c0 + cc) * R + r] = acc[k];
   }
 }
 static inline int skip_gate_threads(int C) {   // a multiple of the C/8 lanes of a pixel row, <= 1024
@@ -825,9 +847,9 @@ extern "C" int edm_skip_gate_bwd(const void* gcat, long gcat_stride, int c_off, 
   hipLaunchKernelGGL(k_skip_gate_bwd, dim3(B), dim3(threads), lds, st, (const bf16*)gcat + c_off, gcat_stride,
                      (const bf16*)skip, W1h, W2h, gate, z1save, gmean, ws, HW, C, R);
   const int CT = (C + 3) / 4, CT1 = (C + 4) / 4;
-  const size_t lds2 = ((size_t)4 * B + (size_t)B * R) * sizeof(float);
-  EDM_REQUIRE(lds2 <= 64 * 1024, "skip_gate_bwd: B * R too large for the weight-gradient pass");
-  hipLaunchKernelGGL(k_skip_gate_wgrad, dim3(CT + CT1), dim3(256), lds2, st, ws, mean, gW1h, gW2h, B, C, R, CT);
+  const int BC = B < 16384 / (R + 4) ? B : 16384 / (R + 4);      // samples per LDS chunk (64 KiB); R <= 1024 -> BC >= 15
+  const size_t lds2 = ((size_t)4 * BC + (size_t)BC * R) * sizeof(float);
+  hipLaunchKernelGGL(k_skip_gate_wgrad, dim3(CT + CT1), dim3(256), lds2, st, ws, mean, gW1h, gW2h, B, C, R, CT, BC);
   EDM_CHECK_LAUNCH("skip_gate_bwd");
   return EDM_OK;
 }

@@ -5,8 +5,10 @@ signature and the same command-line flags (`--ckpt_path --load_ema --output_dir 
     python -m tinyedm.generate --ckpt_path last.ckpt --load_ema --output_dir samples --num_samples 50000 \\
         --image_size 32 --num_classes 10 --batch_size 512
 
-Extensions (all optional): `--network_dtype f32` evaluates the denoiser at the reference's precision (the reference samples
-in fp32, generate.py:39-44; default bf16: the training path's kernels, ~10x faster, 1.3e-3 from the fp32 trajectory),
+Precision: the denoiser is evaluated in fp32 BY DEFAULT, as the reference does (generate.py:39-44: `L.Trainer(accelerator="gpu")`,
+i.e. 32-bit precision; exact-fp32 kernels, csrc/eval_f32.hip).  `--network_dtype bf16` is the opt-in fast mode: the training
+path's kernels, ~9x faster, 1.3e-3 from the fp32 trajectory.
+Extensions (all optional): `--network_dtype`,
 `--in_channels` (the reference's noise dataset hard-codes 3; default = the checkpoint's
 denoiser.in_channels), `--mean/--std` (default: the reference's CIFAR-10 constants), `--seed`, `--no_graph`, and
 `--config_name` to sample from random-init weights of a config instead of a checkpoint (plumbing runs).
@@ -26,7 +28,7 @@ CIFAR_STD = (0.24703223, 0.24348513, 0.26158784)
 
 def generate(ckpt_path, load_ema, output_dir, num_samples, image_size, num_classes, batch_size, num_workers=16,
              num_steps=32, *, in_channels=None, mean=None, std=None, seed=0, graph=True, model=None,
-             network_dtype="bf16") -> None:
+             network_dtype="f32") -> None:
     from .callbacks import PreditionWriter
     from .datamodules import RandomNoiseDataModule
     from .edm import EDM
@@ -77,8 +79,8 @@ def main(argv=None):
     parser.add_argument("--std", type=float, nargs="+", default=None)
     parser.add_argument("--seed", type=int, default=0)
     parser.add_argument("--no_graph", action="store_true", help="eager Heun loop instead of the captured hipGraph")
-    parser.add_argument("--network_dtype", choices=["bf16", "f32"], default="bf16",
-                        help="denoiser evaluation precision: f32 = the reference's (exact-fp32 kernels), bf16 = fast")
+    parser.add_argument("--network_dtype", choices=["bf16", "f32"], default="f32",
+                        help="denoiser evaluation precision: f32 (default) = the reference's (exact-fp32 kernels), bf16 = fast mode")
     parser.add_argument("--config_name", type=str, default=None,
                         help="sample from random-init weights of experiments/conf/<name>.yaml (no checkpoint)")
     parser.add_argument("--config_path", type=str, default=None)

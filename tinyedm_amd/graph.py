@@ -92,6 +92,9 @@ class CapturedTrainStep:
         self.stream = torch.cuda.Stream(self.base.arena.theta.device)
         self._graphs = {}
         self._calls = 0
+        # True once a capture failed on ANY rank of a multi-rank job: every rank then runs the eager step from here on
+        # (ranks replaying captured collectives beside a rank that issues none would hang)
+        self.fallback = False
 
     # ---- host-side bookkeeping identical to the eager path
     def _upload(self):
@@ -133,11 +136,40 @@ class CapturedTrainStep:
                     self.reducer.finish()   # joins the comm stream; 1/world rides in the device record (grad_scale)
                 self.base.step_dyn(self.params.dev, ema=self.ema.ema_arena if self.ema is not None else None)
                 loss = loss.detach()        # drop the autograd graph (and with it the AccumulateGrad nodes) now
+        except BaseException:
+            if self.reducer is not None:
+                self.reducer.reset()        # a half-consumed pass must not leak pending counts into the next step
+            raise
         finally:
             networks.WGRAD_STREAM = side
         cur.wait_stream(self.stream)
         self._restore(snap)
         return loss
+
+    def _capture_agreed(self, batch):
+        """Capture, then -- with more than one rank -- agree on the outcome: a rank-local failure (out of memory, a runtime
+        that refuses a node) must not leave the other ranks replaying collectives nobody answers.  Returns the graph entry,
+        or None when the job falls back to the eager step (single rank: the exception propagates)."""
+        ent, err = None, None
+        try:
+            ent = self._capture(batch)
+        except Exception as e:      # noqa: BLE001
+            err = e
+        multi = self.reducer is not None and self.reducer.world > 1
+        if multi:
+            import torch.distributed as dist
+            flag = torch.tensor([0 if err is not None else 1], device=self.base.arena.theta.device, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.reducer.group)
+            if int(flag.item()) == 0:
+                import warnings
+                warnings.warn("tinyedm_amd: capturing the data-parallel step failed on at least one rank"
+                              + (f" (here: {type(err).__name__}: {str(err)[:200]})" if err is not None else "")
+                              + "; every rank runs the eager step")
+                self.fallback = True
+                return None
+        elif err is not None:
+            raise err
+        return ent
 
     def __call__(self, batch):
         x, y = batch
@@ -146,11 +178,13 @@ class CapturedTrainStep:
         networks.rng.dyn = self.params.dev
         try:
             ent = self._graphs.get(key)
-            if ent is None and self._calls < self.WARMUP:
-                loss = self._eager(batch)          # allocator / plan / stream warm-up before capturing
+            if ent is None and not self.fallback and self._calls >= self.WARMUP:
+                ent = self._capture_agreed(batch)
+                if ent is not None:
+                    self._graphs[key] = ent
+            if ent is None:
+                loss = self._eager(batch)          # allocator / plan / stream warm-up before capturing; the fallback
             else:
-                if ent is None:
-                    ent = self._graphs[key] = self._capture(batch)
                 graph, sx, sy, loss = ent
                 sx.copy_(x, non_blocking=True)
                 if sy is not None:
@@ -190,6 +224,10 @@ class CapturedTrainStep:
                     self.reducer.finish()       # ... and this joins it: the all-reduces are nodes of the graph
                 self.base.step_dyn(self.params.dev, ema=self.ema.ema_arena if self.ema is not None else None)
                 loss = loss.detach()
+        except BaseException:
+            if self.reducer is not None:
+                self.reducer.reset()        # pending counts / fired set of the aborted pass
+            raise
         finally:
             networks.WGRAD_STREAM = side
             ops.capture_end()

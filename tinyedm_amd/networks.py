@@ -52,7 +52,7 @@ def manual_seed(seed: int) -> None:
 _WEIGHT_EPOCH = 0
 
 
-FORWARD_EPOCH = 0       # training-mode Denoiser forwards so far (FusedAdam.zero_grad: "was a gradient written since step()?")
+FORWARD_EPOCH = 0       # grad-enabled Denoiser forwards so far (FusedAdam.zero_grad: "was a gradient written since step()?")
 
 
 def bump_weight_epoch() -> None:
@@ -1286,7 +1286,7 @@ class Denoiser(nn.Module):
                                       _emb32(embedding.detach(), noisy.shape[0]))
             return D.to(noisy_image.dtype)
         reset_backward_state()
-        if self.training and torch.is_grad_enabled():
+        if torch.is_grad_enabled():      # eval-mode forwards with autograd on (fine-tuning, parity runs) write gradients too
             global FORWARD_EPOCH
             FORWARD_EPOCH += 1
         with torch.no_grad():
