@@ -51,11 +51,10 @@ int edm_conv_igemm_v2(const void* X, const void* Wp, void* Y, const void* R, flo
 /* third-generation kernel, same contract (512x128 "tall" tile, 128x64 per wave); -3 for shapes it does not cover */
 int edm_conv_igemm_v3(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
                       int W, int Cin, int Cout, int taps, edm_stream_t stream);
-/* fourth generation, 3x3 only: v3 geometry with a fully static schedule (18x unrolled, precomputed fragment addresses,
- * masks folded into addresses, incremental DMA pointers); -3 for shapes it does not cover (taps != 9, Cin % 64 != 0) */
-int edm_conv_igemm_v4(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
-                      int W, int Cin, int Cout, int taps, edm_stream_t stream);
-/* the fourth generation on v_mfma_f32_16x16x32_bf16 (the device holds a higher clock on this MFMA shape); same shapes */
+/* the 3x3 kernel of the 32x32 / 16x16 layers ("static schedule": 512 pixels x 128 or 64 channels per workgroup, the
+ * (tap, 2 channel-chunk) loop unrolled 18x, per-lane fragment addresses computed once, counted waits) on
+ * v_mfma_f32_16x16x32_bf16; -3 for shapes it does not cover (taps != 9, Cin % 64 != 0, W > 64).  (Its 32x32x16
+ * predecessor edm_conv_igemm_v4 was retired in round 4: no dispatch reached it.) */
 int edm_conv_igemm_v6(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
                       int W, int Cin, int Cout, int taps, edm_stream_t stream);
 /* small feature maps (8x8 layers; W <= 16, Cin % 256 == 0), 3x3 only: 128x64 tile whose reduction dimension is split
@@ -63,6 +62,16 @@ int edm_conv_igemm_v6(const void* X, const void* Wp, void* Y, const void* R, flo
  * -3 for shapes it does not cover */
 int edm_conv_igemm_s(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
                      int W, int Cin, int Cout, int taps, edm_stream_t stream);
+/* Same operation with an OUTPUT DESCRIPTOR -- how torch.cat((input, skip * gate)) (networks.py:311) and its backward stop
+ * being copies: Y rows have stride ldY elements (0 = Cout: Y may be the left column block of the next block's
+ * concatenated operand); Ysilu (optional) receives mp_silu(Y) at the same offsets of a second buffer with the same stride
+ * (the operand of that block's first 3x3 conv, networks.py:315); Yb (optional): output channels >= split go to
+ * Yb[pixel * ldYb + channel - split] (the 1x1 dgrad that produces d loss / d cat writes d loss / d input and the raw
+ * gradient of the gated skip to the two tensors their consumers read).  kernel: which generation runs (1 edm_conv_igemm,
+ * 2 _v2, 5 _s, 6 _v6; -3 = shape not covered by it).  R stays contiguous [pixels][Cout]. */
+int edm_conv_igemm_o(const void* X, const void* Wp, void* Y, long ldY, void* Ysilu, void* Yb, long ldYb, int split,
+                     const void* R, float alpha, float beta, int B, int H, int W, int Cin, int Cout, int taps, int kernel,
+                     edm_stream_t stream);
 /* first 3x3 conv of a block with the embedding modulation fused into its epilogue (networks.py:253-260 / 317-324):
  * Y = conv3x3(X) (bf16, may be NULL in eval), Y2 = dropout(mp_silu(Y * (lin[b,:]*gain + 1))) -- bit-identical to
  * edm_mod_silu_drop_fwd applied to Y (same Philox counters), so edm_mod_silu_drop_bwd serves as its backward. */
@@ -217,6 +226,13 @@ int edm_concat_gate_fwd(const void* inp, const void* skip, const float* gate, vo
                         int Ci, int Cs, edm_stream_t stream);
 int edm_concat_gate_bwd(const void* gcat, const float* gate, const float* gmean, void* ginp, void* gskip, int B,
                         int HW, int Ci, int Cs, edm_stream_t stream);
+/* The skip half alone (the input half is written by the producer of `input` through edm_conv_igemm_o):
+ * cat[b,p,Ci:] = skip*gate, silu_out[b,p,Ci:] = mp_silu(of it) (rows of Ci + Cs elements; silu_out may be NULL); and
+ * gskip = gcs*gate + gmean/HW from the skip half gcs [B*HW][Cs] of d loss / d cat. */
+int edm_skip_half_fwd(const void* skip, const float* gate, void* cat, void* silu_out, int B, int HW, int Ci, int Cs,
+                      edm_stream_t stream);
+int edm_skip_half_bwd(const void* gcs, const float* gate, const float* gmean, void* gskip, int B, int HW, int Cs,
+                      edm_stream_t stream);
 
 /* ---------------------------------------------------------------- EDM preconditioning (networks.py:578-587, 602-603) */
 /* out[b,h,w,:] = [c_in(b)*noisy[b,:,h,w], 1, 0...] (bf16, CP channels); sigma_stride 0 = one scalar sigma */

@@ -210,10 +210,13 @@ def test_latent_pipeline_datamodule_fit_and_generate_callback(ops, tmp_path, siz
     # Reference semantics, kept: the EMA callback has ALREADY swapped the EMA weights in for validation (ema.py:83-100) and
     # the callback's own `swap_ema_weights` (callbacks.py:110-113) swaps back, so this sample runs on the training weights
     model.eval()
+    assert cb.network_dtype == "f32" and model.denoiser.eval_dtype == "bf16"   # the callback samples in fp32 (the reference's
+    model.denoiser.set_eval_dtype("f32")                                        # precision) and restores the module's setting
     with torch.no_grad():
         xT = T.DeterministicSolver(num_steps=3).solve(model, cb.x0, cb.class_labels)
         with model.swap_ema_weights(tr):
             xT_ema = T.DeterministicSolver(num_steps=3).solve(model, cb.x0, cb.class_labels)
+    model.denoiser.set_eval_dtype("bf16")
     assert torch.allclose(out, E.denormalize_latents(xT.float()), rtol=1e-5, atol=1e-5)
     assert not torch.allclose(out, E.denormalize_latents(xT_ema.float()), rtol=1e-5, atol=1e-5)
     assert "val_loss" in tr.callback_metrics and np.isfinite(tr.callback_metrics["val_loss"])

@@ -1,5 +1,5 @@
 """Oracle checks of the kernel instantiations the benchmark actually dispatches: the full-size
-layers -- B = 128, 32x32 (512x128-tile v4 kernel), 16x16 (512x64 tile) and 8x8 -- with their fused epilogues, each
+layers -- B = 128, 32x32 (512x128-tile v6 kernel), 16x16 (512x64 tile) and 8x8 -- with their fused epilogues, each
 compared on images {0, 63, 127} of the batch against an fp64 evaluation of the SAME bf16 operands (reference:
 F.conv2d networks.py:37 and the elementwise chain networks.py:253-260 / 319-324 and its autograd), never against
 another HIP kernel; and the CIFAR-10 unconditional network at B = 128 against the oracle with bf16 rounding points."""
@@ -50,7 +50,7 @@ def _conv64(x, w):   # fp64 conv of the chosen images, NCHW
     return F.conv2d(nchw64(x[IMGS]), w.double(), padding=1)
 
 
-SHAPES = [(128, 32, 256, 256, "v4 512x128"), (128, 32, 512, 256, "v4 512x128"), (128, 16, 256, 256, "v4 512x64"),
+SHAPES = [(128, 32, 256, 256, "v6 512x128"), (128, 32, 512, 256, "v6 512x128"), (128, 16, 256, 256, "v6 512x64"),
           (128, 8, 256, 256, "8x8")]
 
 

@@ -238,3 +238,40 @@ def test_fused_clear_is_not_trusted_after_an_eval_mode_backward():
     torch.cuda.synchronize()
     assert float(base.arena.grad.abs().max()) == 0.0
     model.train()
+
+
+def test_copy_free_concat_matches_the_standalone_concat_kernels():
+    """FUSE_CAT (round 4): the producer of a decoder block's input writes it (and mp_silu of it) straight into the next
+    block's concatenated operands and the 1x1 dgrad splits d loss / d cat -- same values as the standalone concat kernels
+    (networks.py:311 and its autograd): the evaluation forward bit for bit, every parameter gradient up to the order of
+    the fp32 atomics both paths share."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import tinyedm_amd as T
+    from tinyedm_amd import networks as N
+    g = torch.Generator().manual_seed(9)
+    x = (0.5 * torch.randn(8, 3, 16, 16, generator=g)).to(DEV)
+    y = torch.randint(0, 10, (8,), generator=g).to(DEV)
+    sigma = torch.randn(8, generator=g).exp().to(DEV)
+    res = {}
+    old = N.FUSE_CAT
+    try:
+        for mode in (False, True):
+            N.FUSE_CAT = mode
+            model, _ = _build(pdrop=0.1)
+            opt, base, _ = _opt(model)
+            opt.zero_grad()
+            model.eval()
+            with torch.no_grad():
+                D = model(x, sigma, y).clone()
+            model.train()
+            T.manual_seed(11)
+            loss = model.training_step((x, y), 0)
+            loss.backward()
+            torch.cuda.synchronize()
+            res[mode] = (D, float(loss), base.arena.grad.clone())
+    finally:
+        N.FUSE_CAT = old
+    assert torch.equal(res[True][0], res[False][0])
+    assert abs(res[True][1] - res[False][1]) <= 1e-6 * abs(res[False][1])
+    assert rel(res[True][2], res[False][2]) <= 1e-5, rel(res[True][2], res[False][2])

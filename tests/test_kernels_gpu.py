@@ -75,8 +75,8 @@ CONV_SHAPES = [
 ]
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4, 5, 6],
-                ids=["igemm-auto", "igemm-v1", "igemm-v2", "igemm-v3", "igemm-v4", "igemm-s", "igemm-v6"])
+@pytest.fixture(params=[0, 1, 2, 3, 5, 6],
+                ids=["igemm-auto", "igemm-v1", "igemm-v2", "igemm-v3", "igemm-s", "igemm-v6"])
 def igemm_version(request, ops):
     """Every generation of the implicit-GEMM kernel must pass the same parity tests (the per-shape dispatcher
     picks v2/v3 only for full-size layers, so they are forced here on the small test shapes)."""
@@ -145,16 +145,16 @@ def test_conv_full_size_layer_properties(ops):
     old = ops.IGEMM_VERSION
     try:
         ys = {}
-        for v in (1, 2, 3, 4):
+        for v in (1, 2, 3, 6):
             ops.IGEMM_VERSION = v
             ys[v] = ops.conv_igemm(x1, wp, 9).float()
         ops.IGEMM_VERSION = 0
         y_auto = ops.conv_igemm(x1, wp, 9).float()
     finally:
         ops.IGEMM_VERSION = old
-    for v in (2, 3, 4):
+    for v in (2, 3, 6):
         assert rel(ys[v], ys[1]) < 3e-3, (v, rel(ys[v], ys[1]))
-    assert torch.equal(y_auto, ys[3]) or torch.equal(y_auto, ys[4])   # the dispatcher picks a tall-tile kernel here
+    assert torch.equal(y_auto, ys[6])                       # the dispatcher picks the static-schedule kernel here
     y2 = ops.conv_igemm(x2, wp, 9).float()
     y12 = ops.conv_igemm((x1.float() + x2.float()).to(torch.bfloat16), wp, 9).float()
     assert rel(y12, ys[3] + y2) < 1e-2                     # linearity (bf16 rounding of the summed input)
@@ -251,7 +251,7 @@ def test_conv_wgrad_1x1_ragged(ops, B, H, W, Cin, Cout):
                                                    (512, 8, 8, 64, 256, 0.1)])    # W = 8 through k_conv3x3_v6's validity-bit path
 def test_conv3x3_mod_epilogue_is_bit_identical_to_separate_kernels(ops, B, H, W, Cin, Cout, pdrop):
     """Fused modulation epilogue (edm_conv3x3_mod) == conv_igemm followed by mod_silu_drop_fwd, bit for bit (same bf16
-    rounding of u, same Philox counters), on a small-tile shape, ragged shapes and the full-size 32x32 layer (v4)."""
+    rounding of u, same Philox counters), on a small-tile shape, ragged shapes and the full-size 32x32 layer (v6)."""
     g = torch.Generator().manual_seed(B + Cin + Cout)
     x = nhwc(q(torch.randn(B, Cin, H, W, generator=g)))
     wp = pack_fwd(q(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)))
@@ -339,22 +339,67 @@ def test_conv3x3_silubwd_epilogue_is_bit_identical(ops, B, H, W, C1, C2, with_ex
     assert torch.equal(got, ref)
 
 
-def test_v4_32x32x16_fallback_is_covered():
-    """EDM_V4_MFMA16=0 keeps k_conv3x3_v4 on v_mfma_f32_32x32x16_bf16 (the documented fallback of k_conv3x3_v6).  The C
-    side reads the variable once per process, so the forced-v4 parity cases of this file run again in ONE child process
-    with it set (forward on every shape, the residual epilogue, and the three fused epilogues)."""
-    import os
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, EDM_V4_MFMA16="0", EDM_PARITY_LOG="0")
-    sel = ("(test_conv_igemm_forward and igemm-v4) or (test_conv_igemm_residual_epilogue and igemm-v4) or "
-           "test_conv3x3_mod_epilogue or test_conv3x3_modbwd_epilogue or test_conv3x3_silubwd_epilogue or "
-           "test_dropout_marks")
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_kernels_gpu.py"), "-x", "-q", "-m", "gpu",
-                          "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
-    assert " passed" in out.stdout and "failed" not in out.stdout, out.stdout[-500:]
+@pytest.mark.parametrize("B,H,W,Cin,Cout,taps,version", [
+    (2, 8, 8, 64, 64, 9, 1), (3, 5, 7, 128, 72, 1, 1), (4, 16, 16, 256, 256, 1, 1),        # k_conv_igemm (3x3 and 1x1)
+    (6, 32, 32, 64, 128, 1, 2), (128, 32, 32, 256, 512, 1, 2),                             # k_conv_igemm2 (the 32x32 1x1 layers)
+    (16, 8, 8, 256, 256, 9, 5), (128, 8, 8, 256, 256, 9, 5),                               # k_conv3x3_s
+    (4, 32, 32, 64, 128, 9, 6), (5, 16, 16, 64, 192, 9, 6), (128, 32, 32, 256, 256, 9, 6),  # k_conv3x3_v6
+    (128, 16, 16, 256, 256, 9, 6),
+])
+def test_conv_output_descriptor(ops, B, H, W, Cin, Cout, taps, version):
+    """edm_conv_igemm_o on every kernel generation that has the form: the strided output (the left column block of a wider
+    NHWC buffer), its mp_silu twin and the split output are the plain kernel's result bit for bit, mp_silu of it exactly
+    as the elementwise kernel computes it, and no byte outside the destination columns is touched."""
+    g = torch.Generator().manual_seed(B + Cin + Cout + taps)
+    x = torch.randn(B, H, W, Cin, generator=g).to(torch.bfloat16).to(DEV)
+    r = torch.randn(B, H, W, Cout, generator=g).to(torch.bfloat16).to(DEV)
+    wp = (torch.randn(taps, Cout, Cin, generator=g) / math.sqrt(Cin * taps)).to(torch.bfloat16).to(DEV)
+    old = ops.IGEMM_VERSION
+    ops.IGEMM_VERSION = version
+    try:
+        assert ops._KERNEL_ID[ops._igemm_entry(B * H * W, W, Cout, taps, Cin)] == version
+        ref = ops.conv_igemm(x, wp, taps, residual=r, alpha=0.8, beta=0.6)
+        Cs = 64
+        cat = torch.full((B, H, W, Cout + Cs), 7.0, device=DEV, dtype=torch.bfloat16)
+        sil = torch.full((B, H, W, Cout + Cs), 7.0, device=DEV, dtype=torch.bfloat16)
+        out = ops.conv_igemm(x, wp, taps, residual=r, alpha=0.8, beta=0.6, out=cat[..., :Cout], silu_out=sil[..., :Cout])
+        assert out.data_ptr() == cat.data_ptr()
+        assert torch.equal(cat[..., :Cout], ref) and torch.equal(sil[..., :Cout], ops.silu_fwd(ref))
+        assert bool((cat[..., Cout:] == 7.0).all()) and bool((sil[..., Cout:] == 7.0).all())
+        only = torch.full((B, H, W, Cout + Cs), 7.0, device=DEV, dtype=torch.bfloat16)
+        ops.conv_igemm(x, wp, taps, residual=r, alpha=0.8, beta=0.6, out=only[..., :Cout])     # strided, no silu twin
+        assert torch.equal(only[..., :Cout], ref) and bool((only[..., Cout:] == 7.0).all())
+        for c in sorted({8, Cout // 2, Cout - 8}):
+            if not (0 < c < Cout and c % 8 == 0):
+                continue
+            ya = torch.empty(B, H, W, c, device=DEV, dtype=torch.bfloat16)
+            yb = torch.empty(B, H, W, Cout - c, device=DEV, dtype=torch.bfloat16)
+            ops.conv_igemm(x, wp, taps, residual=r, alpha=0.8, beta=0.6, split=(c, ya, yb))
+            assert torch.equal(ya, ref[..., :c]) and torch.equal(yb, ref[..., c:]), c
+    finally:
+        ops.IGEMM_VERSION = old
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Cs", [(2, 8, 8, 64, 128), (3, 5, 7, 192, 192), (128, 32, 32, 256, 256)])
+def test_skip_half_kernels_match_the_concat_kernels(ops, B, H, W, Ci, Cs):
+    """edm_skip_half_fwd / _bwd (the skip half of the decoder's concatenated operands, the half of d loss / d cat that
+    belongs to the gated skip) against the standalone concat kernels they replace: bit for bit."""
+    g = torch.Generator().manual_seed(B + Ci + Cs)
+    inp = torch.randn(B, H, W, Ci, generator=g).to(torch.bfloat16).to(DEV)
+    skip = torch.randn(B, H, W, Cs, generator=g).to(torch.bfloat16).to(DEV)
+    gate = torch.rand(B, Cs, generator=g).to(DEV)
+    cat_ref, sil_ref = ops.concat_gate_fwd(inp, skip, gate, True)
+    cat = torch.empty_like(cat_ref)
+    sil = torch.empty_like(cat_ref)
+    cat[..., :Ci] = inp
+    sil[..., :Ci] = ops.silu_fwd(inp)
+    ops.skip_half_fwd(skip, gate, cat, sil)
+    assert torch.equal(cat, cat_ref) and torch.equal(sil, sil_ref)
+    gcat = torch.randn(B, H, W, Ci + Cs, generator=g).to(torch.bfloat16).to(DEV)
+    gmean = torch.randn(B, Cs, generator=g).to(DEV)
+    ginp_ref, gskip_ref = ops.concat_gate_bwd(gcat, gate, gmean, Ci)
+    gskip = ops.skip_half_bwd(gcat[..., Ci:].contiguous(), gate, gmean)
+    assert torch.equal(gskip, gskip_ref) and torch.equal(ginp_ref, gcat[..., :Ci])
 
 
 def test_weight_prep_padding_and_perm(ops):

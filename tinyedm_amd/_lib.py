@@ -37,6 +37,8 @@ SIGNATURES = {
     "edm_skip_gate_bwd": [P, L, I, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     "edm_concat_gate_fwd": [P, P, P, P, P, I, I, I, I, P],
     "edm_concat_gate_bwd": [P, P, P, P, P, I, I, I, I, P],
+    "edm_skip_half_fwd": [P, P, P, P, I, I, I, I, P],
+    "edm_skip_half_bwd": [P, P, P, P, I, I, I, P],
     "edm_precond_in": [P, P, I, F, P, I, I, I, I, P],
     "edm_conv_out_fwd": [P, P, P, P, P, I, F, P, P, I, I, I, I, P],
     "edm_conv_out_bwd": [P, P, P, P, P, P, I, F, P, P, P, I, I, I, I, P],
@@ -46,7 +48,7 @@ SIGNATURES = {
     "edm_conv_igemm": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_v2": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_v3": [P, P, P, P, F, F, I, I, I, I, I, I, P],
-    "edm_conv_igemm_v4": [P, P, P, P, F, F, I, I, I, I, I, I, P],
+    "edm_conv_igemm_o": [P, P, P, L, P, P, L, I, P, F, F, I, I, I, I, I, I, I, P],
     "edm_conv_igemm_v6": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_s": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv3x3_mod": [P, P, P, P, P, L, P, F, U64, U, U, I, I, I, I, I, I, P, P],

@@ -163,11 +163,22 @@ struct ModEpilogue {
   float* gm;          // modulation backward: [B][Cout] fp32, zero-filled by the caller, accumulated with atomics
   const bf16* ADD;    // silu backward: optional extra gradient, Y2 = mp_silu'(U)*g + add_scale*ADD
   float add_scale;
-  int mode;           // 0: none / forward modulation (Y2 set), 1: modulation backward, 2: mp_silu backward
+  int mode;           // 0: none / forward modulation (Y2 set), 1: modulation backward, 2: mp_silu backward,
+                      // 3: plain + Y2 = mp_silu(Y) (see ldY below)
   const StepParams* dyn;  // non-null: step / seed of the Philox stream come from device memory (captured steps)
   long gm_stride;         // row stride of gm in floats; 0 = Cout (a private contiguous [B][Cout] buffer)
   int u_marks;            // forward: write a NaN into Y (= U) where the element was dropped; backward: U carries those
                           // marks (dropped <=> NaN), no Philox stream is regenerated
+  // ---- output descriptor of the plain epilogue (round 4): where the result rows go.  The decoder's
+  // torch.cat((input, skip * gate)) (networks.py:311) is never a copy: the kernel that PRODUCES `input` writes its rows
+  // straight into the left half of the cat buffer (ldY = Ci + Cs) and mp_silu of them into the same half of the buffer the
+  // block's first conv reads (mode 3); the kernel that produces d loss / d cat writes the two halves to the two tensors
+  // their consumers read (split).
+  long ldY;               // row stride of Y (and of a mode-3 Y2) in elements; 0 = Cout.  R / U / ADD stay contiguous.
+  bf16* Yb;               // non-null: output channels >= split go to Yb[row * ldYb + (channel - split)]
+  long ldYb;
+  int split;              // multiple of 8
+  // mode 3 (plain epilogue, EPI 0): Y2 = mp_silu(Y), same addressing as Y
 };
 constexpr uint32_t U_DROPPED = 0x7FFFu;   // the bf16 pattern of a dropped element in a marked U
 __device__ __forceinline__ void apply_dyn(ModEpilogue& m) {
@@ -291,9 +302,10 @@ __device__ __forceinline__ void store_tile_core(Put&& put, char* stage, bf16* __
     if (R) prefetch_r(0);
   }
   // forward modulation / modulation backward with one sample per 32-pixel block: the factors m = lin*gain + 1 once per block
-  const bool block_mod = (EPI == 1) || (EPI == 0 && mod.Y2 && mod.HW % 32 == 0);
+  const bool silu_out = EPI == 0 && mod.mode == 3;   // Y2 = mp_silu(Y): no modulation operands
+  const bool block_mod = (EPI == 1) || (EPI == 0 && mod.Y2 && !silu_out && mod.HW % 32 == 0);
   float gain = 0.f;
-  if (EPI != 2 && mod.Y2) gain = *mod.gain;
+  if (EPI != 2 && mod.Y2 && !silu_out) gain = *mod.gain;
   float part[8];  // backward form: per-lane sums over a block's (gmred: the wave's) pixels
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
@@ -343,6 +355,21 @@ __device__ __forceinline__ void store_tile_core(Put&& put, char* stage, bf16* __
       const u32x4 ov = *reinterpret_cast<const u32x4*>(stage + px * EROW + c16 * 16);
       if (mb + px < Npix && co_c < Cout) {
         const long e = (mb + px) * Cout + co_c;
+        if constexpr (EPI == 0) {
+          if (mod.ldY || mod.Yb) {      // strided / split destination (plain and mode-3 forms only)
+            const bool second = mod.Yb && co_c >= mod.split;
+            const long ey = second ? (mb + px) * mod.ldYb + (co_c - mod.split) : (mb + px) * (mod.ldY ? mod.ldY : (long)Cout) + co_c;
+            *reinterpret_cast<u32x4*>((second ? mod.Yb : Y) + ey) = ov;
+            if (silu_out) {
+              const bf16x8 yv = __builtin_bit_cast(bf16x8, ov);
+              bf16x8 sv;
+#pragma unroll
+              for (int k = 0; k < 8; ++k) sv[k] = (bf16)mp_silu_b((float)yv[k]);
+              *reinterpret_cast<bf16x8*>(mod.Y2 + ey) = sv;
+            }
+            continue;
+          }
+        }
         if (Y && !(EPI == 0 && mod.Y2 && mod.u_marks)) *reinterpret_cast<u32x4*>(Y + e) = ov;
         if (mod.Y2) {
           if constexpr (EPI == 1) {

@@ -1,0 +1,137 @@
+// Dispatch of the convolution entry points that carry an epilogue descriptor: the fused forms of the residual blocks
+// (modulation forward / backward, mp_silu backward) and -- round 4 -- the strided / split output forms that make the
+// decoder's torch.cat((input, skip * gate)) (networks.py:311) copy-free.  The kernels themselves live in conv_igemm*.hip;
+// every one ends in common.h's store_tile_core, which is where the descriptor (ModEpilogue) is interpreted.
+#include "common.h"
+
+int edm_conv_igemm_v1_ex(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
+                         int W, int Cin, int Cout, int taps, const ModEpilogue& mod, hipStream_t st);
+int edm_conv_igemm_v2_ex(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
+                         int W, int Cin, int Cout, int taps, const ModEpilogue& mod, hipStream_t st);
+int edm_conv_igemm_v6_ex(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
+                         int W, int Cin, int Cout, int taps, const ModEpilogue& mod, hipStream_t st);
+// conv_igemm5.hip: small feature maps (reduction split over the waves of a workgroup)
+bool edm_conv_s_worthwhile(long npix, int W, int Cin, int Cout);
+int edm_conv_igemm_s_ex(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
+                        int W, int Cin, int Cout, int taps, const ModEpilogue& mod, hipStream_t st);
+
+// the static-schedule kernel pays off when it can give every CU a tile: >= 512 tiles of 512x128, or >= 256 of 512x64
+bool edm_conv_tall_worthwhile(long npix, int Cout) {
+  const long tm = (npix + 511) / 512;
+  return tm * ((Cout + 127) / 128) >= 512 || tm * ((Cout + 63) / 64) >= 256;
+}
+
+// Y = alpha * conv(X, Wp) + beta * R with an OUTPUT DESCRIPTOR (same operand contract as edm_conv_igemm otherwise):
+//   ldY    row stride of Y in elements (0 = Cout): Y may be a column block of a wider [pixels][ldY] buffer;
+//   Ysilu  optional: mp_silu(Y) (of the bf16-rounded result) at the same offsets of a second buffer with the same stride;
+//   Yb     optional: output channels >= split go to Yb[pixel * ldYb + channel - split] instead (split % 8 == 0);
+//   kernel which generation runs: 1 = k_conv_igemm, 2 = k_conv_igemm2, 5 = k_conv3x3_s, 6 = k_conv3x3_v6 (the caller picks
+//          per shape exactly as for the plain entry points; -3 = shape not covered by that generation).
+// Used by the decoder blocks: the producer of a block's `input` writes it (and mp_silu of it) into the left half of the
+// next block's concatenated operands, and the 1x1 dgrad that produces d loss / d cat writes its two halves to the
+// gradient of `input` and to the raw gradient of the gated skip (reference: networks.py:306-316 and its autograd).
+extern "C" int edm_conv_igemm_o(const void* X, const void* Wp, void* Y, long ldY, void* Ysilu, void* Yb, long ldYb,
+                                int split, const void* R, float alpha, float beta, int B, int H, int W, int Cin, int Cout,
+                                int taps, int kernel, hipStream_t st) {
+  EDM_REQUIRE(X && Wp && Y, "conv_igemm_o: null pointer");
+  EDM_REQUIRE(!Yb || (split > 0 && split < Cout && split % 8 == 0 && ldYb >= Cout - split && ldYb % 8 == 0),
+              "conv_igemm_o: bad split output");
+  EDM_REQUIRE(ldY == 0 || (ldY >= (Yb ? split : Cout) && ldY % 8 == 0),
+              "conv_igemm_o: ldY must be 0 or a multiple of 8 >= the columns written to Y");
+  EDM_REQUIRE(!(Yb && Ysilu), "conv_igemm_o: the split form has no mp_silu output");
+  ModEpilogue mod{};
+  mod.Y2 = (bf16*)Ysilu;
+  mod.mode = Ysilu ? 3 : 0;
+  mod.HW = H * W;
+  mod.ldY = ldY ? ldY : (long)(Yb ? split : (Ysilu ? Cout : 0));   // (a split destination's first half is [pixels][split]
+                                                                    // unless told otherwise; 0 = the plain contiguous form)
+  mod.Yb = (bf16*)Yb;
+  mod.ldYb = ldYb;
+  mod.split = split;
+  switch (kernel) {
+    case 1: return edm_conv_igemm_v1_ex(X, Wp, Y, R, alpha, beta, B, H, W, Cin, Cout, taps, mod, st);
+    case 2: return edm_conv_igemm_v2_ex(X, Wp, Y, R, alpha, beta, B, H, W, Cin, Cout, taps, mod, st);
+    case 5: return edm_conv_igemm_s_ex(X, Wp, Y, R, alpha, beta, B, H, W, Cin, Cout, taps, mod, st);
+    case 6: return edm_conv_igemm_v6_ex(X, Wp, Y, R, alpha, beta, B, H, W, Cin, Cout, taps, mod, st);
+    default: edm_set_error("conv_igemm_o: unknown kernel id %d", kernel); return EDM_ERR_ARG;
+  }
+}
+
+// 3x3 conv with the fused embedding modulation epilogue (networks.py:253-260 / 317-324):
+//   u  = conv3x3(X, Wp)                               -> Y  (bf16; may be null when the caller does not need it: eval)
+//   a2 = dropout(mp_silu(u * (lin[b,:]*gain + 1)))     -> Y2 (bf16)   [same values as edm_mod_silu_drop_fwd on u]
+// mark_dropped != 0: the elements of Y the dropout removed are written as NaN (bf16 | 0x7FFF) instead of u -- their value is
+// never needed again, and edm_conv3x3_modbwd(u_marked = 1) / edm_mod_silu_drop_bwd then read the mask from U.
+// Picks the static-schedule kernel (k_conv3x3_v6) for layers that give every CU a tall tile, the split-K small-map kernel
+// (k_conv3x3_s) for 8x8-class layers and the 128x128-tile kernel otherwise.
+extern "C" int edm_conv3x3_mod(const void* X, const void* Wp, void* Y, void* Y2, const float* lin, long lin_stride,
+                               const float* gain, float pdrop, unsigned long long seed, unsigned sub, unsigned step,
+                               int mark_dropped, int B, int H, int W, int Cin, int Cout, const void* dyn, hipStream_t st) {
+  EDM_REQUIRE(X && Wp && Y2 && lin && gain, "conv3x3_mod: null pointer");
+  EDM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0 && lin_stride >= Cout && pdrop >= 0.f && pdrop < 1.f,
+              "conv3x3_mod: bad args");
+  ModEpilogue mod{lin, gain, (bf16*)Y2, lin_stride, H * W, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), sub, step,
+                  nullptr, nullptr, nullptr, 0.f, 0, (const StepParams*)dyn, 0, (mark_dropped && pdrop > 0.f) ? 1 : 0};
+  if (edm_conv_tall_worthwhile((long)B * H * W, Cout)) {
+    const int rc = edm_conv_igemm_v6_ex(X, Wp, Y, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
+    if (rc != EDM_ERR_UNSUPPORTED) return rc;
+  }
+  if (edm_conv_s_worthwhile((long)B * H * W, W, Cin, Cout)) {
+    const int rc = edm_conv_igemm_s_ex(X, Wp, Y, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
+    if (rc != EDM_ERR_UNSUPPORTED) return rc;
+  }
+  return edm_conv_igemm_v1_ex(X, Wp, Y, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
+}
+
+// Backward counterpart: the dgrad of a block's second 3x3 conv with the modulation backward fused into its epilogue
+// (networks.py:253-263 under autograd).  With ga = alpha * conv3x3(dY, Wd) (bf16, never written):
+//   gr = ga * keep * mp_silu'(u*m) * m   -> GR (bf16),     gm[b,c] += sum_px ga * keep * mp_silu'(u*m) * u   (fp32 atomics)
+// where m = lin*gain + 1 and u = U is the forward's pre-activation.  gm must be zero-filled [B][Cout]; follow with
+// edm_mod_finish.  Same values as edm_conv_igemm + edm_mod_silu_drop_bwd (gm up to summation order).
+// Returns EDM_ERR_UNSUPPORTED (-3) when H*W is not a multiple of 32 (a 32-pixel block would straddle images).
+// gm_stride: row stride of gm in floats (>= Cout; 0 = Cout): gm may be a column slice of a buffer shared by all blocks of
+// a network, finished by ONE edm_mod_finish_multi launch at the end of the backward pass.
+// u_marked != 0: U comes from edm_conv3x3_mod(mark_dropped = 1) with the same pdrop -- an element is dropped iff U holds a
+// NaN there, and no Philox stream is regenerated (seed / sub / step are ignored).
+extern "C" int edm_conv3x3_modbwd(const void* dY, const void* Wd, float alpha, const void* U, const float* lin,
+                                  long lin_stride, const float* gain, void* GR, float* gm, long gm_stride, float pdrop,
+                                  unsigned long long seed, unsigned sub, unsigned step, int u_marked, int B, int H, int W,
+                                  int Cin, int Cout, const void* dyn, hipStream_t st) {
+  EDM_REQUIRE(dY && Wd && U && lin && gain && GR && gm, "conv3x3_modbwd: null pointer");
+  EDM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0 && lin_stride >= Cout && pdrop >= 0.f && pdrop < 1.f &&
+                  (gm_stride == 0 || gm_stride >= Cout),
+              "conv3x3_modbwd: bad args");
+  if ((H * W) % 32 != 0) return EDM_ERR_UNSUPPORTED;
+  ModEpilogue mod{lin, gain, (bf16*)GR, lin_stride, H * W, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), sub, step,
+                  (const bf16*)U, gm, nullptr, 0.f, 1, (const StepParams*)dyn, gm_stride, (u_marked && pdrop > 0.f) ? 1 : 0};
+  if (edm_conv_tall_worthwhile((long)B * H * W, Cout)) {
+    const int rc = edm_conv_igemm_v6_ex(dY, Wd, nullptr, nullptr, alpha, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
+    if (rc != EDM_ERR_UNSUPPORTED) return rc;
+  }
+  if (edm_conv_s_worthwhile((long)B * H * W, W, Cin, Cout)) {
+    const int rc = edm_conv_igemm_s_ex(dY, Wd, nullptr, nullptr, alpha, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
+    if (rc != EDM_ERR_UNSUPPORTED) return rc;
+  }
+  return edm_conv_igemm_v1_ex(dY, Wd, nullptr, nullptr, alpha, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
+}
+
+// dgrad of a block's FIRST 3x3 conv with the mp_silu backward of the block input fused into its epilogue
+// (networks.py:249-252 / 313-316 under autograd): with g = conv3x3(dY, Wd) (bf16, never written),
+//   GX = mp_silu'(Xpre) * g + add_scale * ADD        (ADD optional: the residual-path gradient)
+// Same values as edm_conv_igemm followed by edm_silu_bwd.
+extern "C" int edm_conv3x3_silubwd(const void* dY, const void* Wd, const void* Xpre, const void* ADD, float add_scale,
+                                   void* GX, int B, int H, int W, int Cin, int Cout, hipStream_t st) {
+  EDM_REQUIRE(dY && Wd && Xpre && GX, "conv3x3_silubwd: null pointer");
+  EDM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0, "conv3x3_silubwd: bad args");
+  ModEpilogue mod{nullptr, nullptr, (bf16*)GX, 0, H * W, 0.f, 0u, 0u, 0u, 0u, (const bf16*)Xpre, nullptr, (const bf16*)ADD,
+                  add_scale, 2, nullptr};
+  if (edm_conv_tall_worthwhile((long)B * H * W, Cout)) {
+    const int rc = edm_conv_igemm_v6_ex(dY, Wd, nullptr, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
+    if (rc != EDM_ERR_UNSUPPORTED) return rc;
+  }
+  if (edm_conv_s_worthwhile((long)B * H * W, W, Cin, Cout)) {
+    const int rc = edm_conv_igemm_s_ex(dY, Wd, nullptr, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
+    if (rc != EDM_ERR_UNSUPPORTED) return rc;
+  }
+  return edm_conv_igemm_v1_ex(dY, Wd, nullptr, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
+}

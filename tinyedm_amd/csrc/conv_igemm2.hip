@@ -49,7 +49,8 @@ __global__ __launch_bounds__(512, 4) void k_conv_igemm2(const bf16* __restrict__
                                                           bf16* __restrict__ Y, const bf16* __restrict__ R,
                                                           const bf16* __restrict__ zeros, float alpha, float beta,
                                                           int Npix, int H, int W, int Cin, int Cout, int tiles_m,
-                                                          int tiles_n, unsigned long long* dbg = nullptr) {
+                                                          int tiles_n, unsigned long long* dbg = nullptr,
+                                                          ModEpilogue mod = ModEpilogue{}) {
   constexpr int XBUFS = (TAPS == 9) ? 2 : 3;
   constexpr int XROWS = NX * 8 * 16;  // LDS rows per slab buffer (every DMA slot is backed by LDS)
   constexpr int XBYTES = XROWS * ROWB;
@@ -228,12 +229,12 @@ __global__ __launch_bounds__(512, 4) void k_conv_igemm2(const bf16* __restrict__
   // ---- epilogue: transposed through wave-private LDS (common.h: store_tile_transposed)
   __syncthreads();  // every wave is done with the staged tiles
   store_tile_transposed<2, 2>(acc, smem + (wm * 4 + wn) * (32 * (2 * 64 + 16)), Y, R, alpha, beta, (long)m0 + wn * 64, Npix,
-                              n0 + wm * 64, Cout);
+                              n0 + wm * 64, Cout, mod);
 }
 
 template <int TAPS, int NX>
 void launch2(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int Npix, int H, int W,
-             int Cin, int Cout, hipStream_t st) {
+             int Cin, int Cout, hipStream_t st, const ModEpilogue& mod) {
   constexpr int XBUFS = (TAPS == 9) ? 2 : 3;
   const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + BN - 1) / BN;
   const size_t lds = (size_t)XBUFS * NX * 8 * 16 * ROWB + WRING * WTILE;
@@ -246,7 +247,7 @@ void launch2(const void* X, const void* Wp, void* Y, const void* R, float alpha,
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const bf16*)X, (const bf16*)Wp, (bf16*)Y, (const bf16*)R,
                      (const bf16*)edm_zero_page(), alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n,
-                     (unsigned long long*)nullptr);
+                     (unsigned long long*)nullptr, mod);
 }
 
 }  // namespace
@@ -263,7 +264,7 @@ extern "C" int edm_conv_igemm_v2_stamp(const void* X, const void* Wp, void* Y, i
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(kern, dim3(((tiles_m + 7) / 8) * 8 * tiles_n), dim3(512), lds, st, (const bf16*)X, (const bf16*)Wp,
                      (bf16*)Y, (const bf16*)nullptr, (const bf16*)edm_zero_page(), 1.f, 0.f, Npix, H, W, Cin, Cout, tiles_m,
-                     tiles_n, dbg);
+                     tiles_n, dbg, ModEpilogue{});
   EDM_CHECK_LAUNCH("conv_igemm_v2_stamp");
   return EDM_OK;
 }
@@ -278,7 +279,7 @@ static void launch_abl(const void* X, const void* Wp, void* Y, int Npix, int H, 
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(kern, dim3(((tiles_m + 7) / 8) * 8 * tiles_n), dim3(512), lds, st, (const bf16*)X, (const bf16*)Wp,
                      (bf16*)Y, (const bf16*)nullptr, (const bf16*)edm_zero_page(), 1.f, 0.f, Npix, H, W, Cin, Cout, tiles_m,
-                     tiles_n, (unsigned long long*)nullptr);
+                     tiles_n, (unsigned long long*)nullptr, ModEpilogue{});
 }
 extern "C" int edm_conv_igemm_v2_ablate(const void* X, const void* Wp, void* Y, int B, int H, int W, int Cin, int Cout,
                                         int mode, hipStream_t st) {
@@ -300,9 +301,10 @@ extern "C" int edm_conv_igemm_v2_ablate(const void* X, const void* Wp, void* Y, 
 
 // Same contract as edm_conv_igemm (conv_igemm.hip); returns EDM_ERR_UNSUPPORTED for shapes it does not cover so the
 // dispatcher can fall back to generation 1.
-extern "C" int edm_conv_igemm_v2(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B,
-                                 int H, int W, int Cin, int Cout, int taps, hipStream_t st) {
+int edm_conv_igemm_v2_ex(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
+                         int W, int Cin, int Cout, int taps, const ModEpilogue& mod, hipStream_t st) {
   EDM_REQUIRE(X && Wp && Y, "conv_igemm_v2: null pointer");
+  EDM_REQUIRE(mod.mode == 0 || mod.mode == 3, "conv_igemm_v2: plain / strided-output epilogues only");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && (long)B * H * W < (1L << 31), "conv_igemm_v2: bad B/H/W");
   EDM_REQUIRE(taps == 1 || taps == 9, "conv_igemm_v2: taps must be 1 or 9");
   EDM_REQUIRE(Cin > 0 && Cin % 32 == 0 && Cout > 0 && Cout % 8 == 0, "conv_igemm_v2: Cin %% 32, Cout %% 8 required");
@@ -311,13 +313,18 @@ extern "C" int edm_conv_igemm_v2(const void* X, const void* Wp, void* Y, const v
   (void)zero_page_;
   const int Npix = B * H * W;
   if (taps == 1) {
-    launch2<1, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st);
+    launch2<1, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod);
   } else {
     const int xrows = BM + 2 * (W + 1);
     const int need = (xrows + 127) / 128;
-    if (need <= 3) launch2<9, 3>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st);
-    else launch2<9, 4>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st);
+    if (need <= 3) launch2<9, 3>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod);
+    else launch2<9, 4>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod);
   }
   EDM_CHECK_LAUNCH("conv_igemm_v2");
   return EDM_OK;
+}
+
+extern "C" int edm_conv_igemm_v2(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B,
+                                 int H, int W, int Cin, int Cout, int taps, hipStream_t st) {
+  return edm_conv_igemm_v2_ex(X, Wp, Y, R, alpha, beta, B, H, W, Cin, Cout, taps, ModEpilogue{}, st);
 }

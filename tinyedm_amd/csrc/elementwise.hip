@@ -904,6 +904,67 @@ __global__ void k_concat_gate_bwd(const bf16* __restrict__ gcat, const float* __
     }
   }
 }
+// The skip half alone (round 4): cat[b,p,Ci:] = skip*gate[b,:] and sil[b,p,Ci:] = mp_silu(of it), rows of Ci + Cs elements.
+// The input half of both buffers is written by the kernel that PRODUCES `input` (edm_conv_igemm_o: strided output +
+// mp_silu output), so torch.cat((input, skip * gate)) (networks.py:311) costs one read of the skip and two half-row writes.
+__global__ void k_skip_half_fwd(const bf16* __restrict__ skip, const float* __restrict__ gate, bf16* __restrict__ cat,
+                                bf16* __restrict__ sil, int HW, int Ci, int Cs, long n8) {
+  const int CLs = Cs >> 3;
+  const long ld = Ci + Cs;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const int cs = (int)(i % CLs) * 8;
+    const long pix = i / CLs;
+    const int b = (int)(pix / HW);
+    float v[8];
+    load8(skip + pix * Cs + cs, v);
+    const float* gp = gate + (long)b * Cs + cs;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)(bf16)(v[j] * gp[j]);
+    store8(cat + pix * ld + Ci + cs, v);
+    if (sil) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = mp_silu_b(v[j]);
+      store8(sil + pix * ld + Ci + cs, v);
+    }
+  }
+}
+// gskip = gcs*gate + gmean/HW  (gcs: the skip half of d loss / d cat, [B*HW][Cs], written by the split-output 1x1 dgrad)
+__global__ void k_skip_half_bwd(const bf16* __restrict__ gcs, const float* __restrict__ gate,
+                                const float* __restrict__ gmean, bf16* __restrict__ gskip, int HW, int Cs, long n8,
+                                float inv_hw) {
+  const int CLs = Cs >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const int cs = (int)(i % CLs) * 8;
+    const int b = (int)((i / CLs) / HW);
+    float v[8];
+    load8(gcs + i * 8, v);
+    const float* gp = gate + (long)b * Cs + cs;
+    const float* mp = gmean + (long)b * Cs + cs;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = v[j] * gp[j] + mp[j] * inv_hw;
+    store8(gskip + i * 8, v);
+  }
+}
+extern "C" int edm_skip_half_fwd(const void* skip, const float* gate, void* cat, void* silu_out, int B, int HW, int Ci,
+                                 int Cs, hipStream_t st) {
+  EDM_REQUIRE(skip && gate && cat, "skip_half_fwd: null pointer");
+  EDM_REQUIRE(B > 0 && HW > 0 && Ci % 8 == 0 && Cs % 8 == 0 && Ci > 0 && Cs > 0, "skip_half_fwd: bad args");
+  long n8 = (long)B * HW * Cs / 8;
+  hipLaunchKernelGGL(k_skip_half_fwd, dim3(grid_for(n8, 256)), dim3(256), 0, st, (const bf16*)skip, gate, (bf16*)cat,
+                     (bf16*)silu_out, HW, Ci, Cs, n8);
+  EDM_CHECK_LAUNCH("skip_half_fwd");
+  return EDM_OK;
+}
+extern "C" int edm_skip_half_bwd(const void* gcs, const float* gate, const float* gmean, void* gskip, int B, int HW, int Cs,
+                                 hipStream_t st) {
+  EDM_REQUIRE(gcs && gate && gmean && gskip, "skip_half_bwd: null pointer");
+  EDM_REQUIRE(B > 0 && HW > 0 && Cs % 8 == 0 && Cs > 0, "skip_half_bwd: bad args");
+  long n8 = (long)B * HW * Cs / 8;
+  hipLaunchKernelGGL(k_skip_half_bwd, dim3(grid_for(n8, 256)), dim3(256), 0, st, (const bf16*)gcs, gate, gmean,
+                     (bf16*)gskip, HW, Cs, n8, 1.0f / (float)HW);
+  EDM_CHECK_LAUNCH("skip_half_bwd");
+  return EDM_OK;
+}
 extern "C" int edm_concat_gate_fwd(const void* inp, const void* skip, const float* gate, void* cat, void* silu_out,
                                    int B, int HW, int Ci, int Cs, hipStream_t st) {
   EDM_REQUIRE(B > 0 && HW > 0 && Ci % 8 == 0 && Cs % 8 == 0 && Ci > 0 && Cs > 0, "concat_gate_fwd: bad args");

@@ -523,6 +523,30 @@ SKIP_GATE_FUSED = os.environ.get("EDM_SKIP_GATE_FUSED", "1") != "0"
 U_MARKS = os.environ.get("EDM_U_MARKS", "1") != "0"
 
 
+# Copy-free torch.cat((input, skip * gate)) (networks.py:311; round 4): the kernel that produces a decoder block's output
+# writes it -- and mp_silu of it -- straight into the left half of the NEXT block's concatenated operands
+# (ops.conv_igemm(out=, silu_out=)), the skip half is filled by one small kernel, and in the backward the 1x1 dgrad that
+# produces d loss / d cat writes its two halves to the tensors their consumers read (ops.conv_igemm(split=)).
+# EDM_FUSE_CAT=0 keeps the standalone concat kernels (A/B runs).
+FUSE_CAT = os.environ.get("EDM_FUSE_CAT", "1") != "0"
+
+
+def _col_block(buf: Tensor, C: int) -> Tensor:
+    """(B, H, W, C) alias of the left C columns of the NHWC buffer `buf` (no autograd view relation: the rows are written
+    by kernels through raw pointers, never by torch in-place ops)"""
+    B, H, W, Ct = buf.shape
+    return torch.empty(0, device=buf.device, dtype=buf.dtype).set_(buf.untyped_storage(), buf.storage_offset(),
+                                                                   (B, H, W, C), (H * W * Ct, W * Ct, Ct, 1))
+
+
+def _dest_ok(dest, x: Tensor, taps: int, Cin: int, Cout: int) -> bool:
+    """the producer's final conv can write through an output descriptor (its kernel generation has that form)"""
+    if dest is None:
+        return False
+    B, H, W, _ = x.shape
+    return ops._igemm_entry(B * H * W, W, Cout, taps, Cin) in ops._KERNEL_ID and dest[0].shape[:3] == (B, H, W)
+
+
 class _ConcatGateFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inp, skip, w1, w2, sl: ScaleLong, want_silu: bool = False):
@@ -669,8 +693,12 @@ class CosineAttention(nn.Module):
         self.out_conv = Conv2d(embedding_dim, embedding_dim, 1)
         self.qkv_conv._perm = _qkv_perm(embedding_dim, num_heads)
 
-    def forward_nhwc(self, x: Tensor) -> Tensor:
-        return _AttnFn.apply(x, self.qkv_conv.weight, self.out_conv.weight, self)
+    def forward_nhwc(self, x: Tensor, dest=None) -> Tensor:
+        """dest = (cat, sil) buffers of the next decoder block: see FUSE_CAT"""
+        out = _AttnFn.apply(x, self.qkv_conv.weight, self.out_conv.weight, self, dest)
+        if dest is not None and out.data_ptr() == dest[0].data_ptr():
+            out._edm_cat = dest
+        return out
 
     def forward(self, x: Tensor) -> Tensor:
         """NCHW API of the reference module."""
@@ -687,13 +715,19 @@ class CosineAttention(nn.Module):
 
 class _AttnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_qkv, w_out, mod: CosineAttention):
+    def forward(ctx, x, w_qkv, w_out, mod: CosineAttention, dest=None):
         wf_qkv, wd_qkv, _ = mod.qkv_conv.packs()
         wf_out, wd_out, _ = mod.out_conv.packs()
         qkv = ops.conv_igemm(x, wf_qkv, 1)
         y = ops.attention_fwd(qkv, mod.num_heads)
         a, b = _mp_coeffs(0.5)
-        out = ops.conv_igemm(y, wf_out, 1, residual=x, alpha=b, beta=a)
+        C = wf_out.shape[1]
+        if _dest_ok(dest, y, 1, y.shape[-1], C):     # the block's output goes straight into the next block's cat / mp_silu(cat)
+            out = ops.conv_igemm(y, wf_out, 1, residual=x, alpha=b, beta=a, out=_col_block(dest[0], C),
+                                 silu_out=_col_block(dest[1], C))
+            out._edm_cat = dest
+        else:
+            out = ops.conv_igemm(y, wf_out, 1, residual=x, alpha=b, beta=a)
         ctx.mod = mod
         ctx.save_for_backward(x, qkv, y, wd_qkv, wd_out)
         return out
@@ -709,7 +743,7 @@ class _AttnFn(torch.autograd.Function):
         gqkv = ops.attention_bwd(qkv, y, gy, mod.num_heads)
         gx = ops.conv_igemm(gqkv, wd_qkv, 1, residual=gout, alpha=1.0, beta=a)
         gw_qkv = _wgrad(mod.qkv_conv, x, gqkv, 1)
-        return gx, gw_qkv, gw_out, None
+        return gx, gw_qkv, gw_out, None, None
 
 
 # --------------------------------------------------------------------------------------
@@ -721,7 +755,11 @@ class _ResBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, u, emb, w1x1, w1, w2, wemb, gain, blk, lin_view, glin_view, token, s_pre=None, alias=False,
-                gm_view=None):
+                gm_view=None, skip=None, w_sl1=None, w_sl2=None, pre=None, dest=None):
+        # skip (decoder blocks with a U-Net skip and no upsample, FUSE_CAT): the concatenation of networks.py:311 happens
+        # HERE.  pre = (cat, sil) whose left halves the producer of u already wrote (u is that half of cat): only the gated
+        # skip half is filled in; otherwise the standalone concat kernel builds both.  dest = the (cat, sil) buffers of the
+        # NEXT block: this block's last kernel writes its output (and mp_silu of it) into their left halves.
         # alias=True: the block input u is handed back as a second output.  The Denoiser takes the U-Net skip from that
         # output, so the skip's gradient arrives in THIS backward (g_alias) and is added by the kernel that writes the
         # input gradient -- not by an autograd `add` launch per skip (9-16 ATen kernels, 0.8 GB per step, round 1).
@@ -734,6 +772,19 @@ class _ResBlockFn(torch.autograd.Function):
         batched = lin_view is not None          # embed Linear evaluated for all blocks at once (_EmbedAllFn)
         weh = None if batched else blk.embed.packs()[2]
         wd11 = None
+        ctx.has_skip = skip is not None
+        if skip is not None:
+            sl = blk.cat_factor
+            w1h, w2h = sl.layer1.packs()[2], sl.layer2.packs()[2]
+            mean, gate, z1 = ops.skip_gate_fwd(skip, w1h, w2h)      # mean over H*W + gate MLP: one launch
+            ctx.Ci = u.shape[-1]
+            if pre is not None and pre[0].shape[-1] == u.shape[-1] + skip.shape[-1] and pre[0].data_ptr() == u.data_ptr():
+                cat, s_pre = pre
+                ops.skip_half_fwd(skip, gate, cat, s_pre)
+            else:
+                cat, s_pre = ops.concat_gate_fwd(u.contiguous(), skip, gate, True)
+            u = cat
+            ctx.skip_saved = (skip, mean, gate, z1, w1h, w2h)
         if enc:
             x = u
             if has1:
@@ -759,7 +810,13 @@ class _ResBlockFn(torch.autograd.Function):
             r1 = ops.conv_igemm(s, wf1, taps)
             a2 = ops.mod_silu_drop_fwd(r1, lin, gain, pdrop, seed, sub, step, dyn=rng.dyn)
         a, b = _mp_coeffs(blk.add_factor)
-        out = ops.conv_igemm(a2, wf2, taps, residual=xres, alpha=b, beta=a)
+        Co = wf2.shape[1]
+        if _dest_ok(dest, a2, taps, a2.shape[-1], Co):
+            out = ops.conv_igemm(a2, wf2, taps, residual=xres, alpha=b, beta=a, out=_col_block(dest[0], Co),
+                                 silu_out=_col_block(dest[1], Co))
+            out._edm_cat = dest
+        else:
+            out = ops.conv_igemm(a2, wf2, taps, residual=xres, alpha=b, beta=a)
         ctx.blk, ctx.enc, ctx.has1 = blk, enc, has1
         ctx.drop = (pdrop, seed, sub, step, rng.dyn)
         ctx.u_marked = U_MARKS and ops.FUSE_MOD and ops.IGEMM_VERSION == 0
@@ -829,13 +886,39 @@ class _ResBlockFn(torch.autograd.Function):
         else:
             if has1:
                 t = ops.conv3x3_silubwd(gr1, wd1, u) if fuse else ops.silu_bwd(u, gs)
-                gu = ops.conv_igemm(gout, wd11, 1, residual=t, alpha=a, beta=1.0)
+                if ctx.has_skip and ops._igemm_entry(gout.numel() // gout.shape[-1], gout.shape[2], wd11.shape[1], 1,
+                                                     gout.shape[-1]) in ops._KERNEL_ID:
+                    # d loss / d cat leaves the 1x1 dgrad as its two halves: d loss / d input (final) and the raw gradient
+                    # of the gated skip -- no gcat tensor, no concat backward pass over it
+                    Ci = ctx.Ci
+                    B_, H_, W_, Ct = u.shape
+                    gu = torch.empty(B_, H_, W_, Ci, device=u.device, dtype=bf16)
+                    gcs = torch.empty(B_, H_, W_, Ct - Ci, device=u.device, dtype=bf16)
+                    ops.conv_igemm(gout, wd11, 1, residual=t, alpha=a, beta=1.0, split=(Ci, gu, gcs))
+                else:
+                    gu = ops.conv_igemm(gout, wd11, 1, residual=t, alpha=a, beta=1.0)
+                    gcs = None
                 gw11 = _wgrad(blk.conv_1x1, u, gout, 1, a)
             else:
                 gu = ops.conv3x3_silubwd(gr1, wd1, u, gout, a) if fuse else ops.silu_bwd(u, gs, gout, a)
+                gcs = None
+        gskip = gwsl1 = gwsl2 = None
+        if ctx.has_skip:
+            skip, mean, gate, z1, w1h, w2h = ctx.skip_saved
+            Ci = ctx.Ci
+            if gcs is None:             # (no split form for this shape: the skip half is read out of gcat in place)
+                gmean, gw1h, gw2h = ops.skip_gate_bwd(gu, Ci, skip, mean, w1h, w2h, gate, z1)
+                gu, gskip = ops.concat_gate_bwd(gu, gate, gmean, Ci)
+            else:
+                gmean, gw1h, gw2h = ops.skip_gate_bwd(gcs, 0, skip, mean, w1h, w2h, gate, z1)
+                gskip = ops.skip_half_bwd(gcs, gate, gmean)
+            sl = blk.cat_factor
+            gwsl1 = sl.layer1.finish_grad(gw1h.view(1, 1, *gw1h.shape))
+            gwsl2 = sl.layer2.finish_grad(gw2h.view(1, 1, *gw2h.shape))
         if g_alias is not None:         # decoder blocks are never asked for an alias; kept for completeness
             gu = ops.axpby(gu, 1.0, g_alias, 1.0)
-        return gu, gemb, gw11, gw1, gw2, gwemb, ggain, None, None, None, gtoken, None, None, None
+        return (gu, gemb, gw11, gw1, gw2, gwemb, ggain, None, None, None, gtoken, None, None, None, gskip, gwsl1, gwsl2,
+                None, None)
 
 
 _rng_sub_counter = [0]
@@ -853,21 +936,29 @@ class _BlockBase(nn.Module):
         _rng_sub_counter[0] += 1
         self.rng_sub = _rng_sub_counter[0]
 
-    def _res(self, u: Tensor, embedding: Tensor, lin=None, s_pre=None, alias=False):
-        """alias=True: returns (out, alias of u) -- see _ResBlockFn.forward"""
+    def _res(self, u: Tensor, embedding: Tensor, lin=None, s_pre=None, alias=False, skip=None, dest=None):
+        """alias=True: returns (out, alias of u) -- see _ResBlockFn.forward.  skip / dest: FUSE_CAT (decoder blocks)"""
         w11 = self.conv_1x1.weight if isinstance(self.conv_1x1, Conv2d) else None
+        has_attn = isinstance(self.attention, CosineAttention)
+        sk = ()
+        if skip is not None or dest is not None:
+            cf = self.cat_factor if skip is not None else None
+            sk = (skip, cf.layer1.weight if cf is not None else None, cf.layer2.weight if cf is not None else None,
+                  getattr(u, "_edm_cat", None) if skip is not None else None, None if has_attn else dest)
         if lin is None:
             out = _ResBlockFn.apply(u, embedding, w11, self.conv_3x3_1.weight, self.conv_3x3_2.weight,
-                                    self.embed.weight, self.gain, self, None, None, None, s_pre, alias)
+                                    self.embed.weight, self.gain, self, None, None, None, s_pre, alias, None, *sk)
         else:
             lin_view, glin_view, token, gm_view = lin
             out = _ResBlockFn.apply(u, None, w11, self.conv_3x3_1.weight, self.conv_3x3_2.weight, None, self.gain,
-                                    self, lin_view, glin_view, token, s_pre, alias, gm_view)
+                                    self, lin_view, glin_view, token, s_pre, alias, gm_view, *sk)
         ualias = None
         if alias:
             out, ualias = out
-        if isinstance(self.attention, CosineAttention):
-            out = self.attention.forward_nhwc(out)
+        if has_attn:
+            out = self.attention.forward_nhwc(out, dest)
+        elif dest is not None and out.data_ptr() == dest[0].data_ptr():
+            out._edm_cat = dest
         return (out, ualias) if alias else out
 
 
@@ -952,9 +1043,16 @@ class DecoderBlock(_BlockBase):
         self.conv_3x3_1 = Conv2d(total, out_channels, 3)
         self._common(out_channels, embedding_dim, attention, num_heads, dropout_rate)
 
-    def forward(self, input: Tensor, embedding: Tensor, skip: Tensor | None = None, _lin=None) -> Tensor:
+    def forward(self, input: Tensor, embedding: Tensor, skip: Tensor | None = None, _lin=None, _dest=None) -> Tensor:
         x, conv = _as_nhwc(input)
         s_pre = None
+        if skip is not None and FUSE_CAT and SKIP_GATE_FUSED and not isinstance(self.resample, UpSample) \
+                and isinstance(self.conv_1x1, Conv2d):
+            # the concatenation, the ScaleLong gate and their backward live inside the block's autograd node
+            assert self.cat_factor is not None
+            sk, _ = _as_nhwc(skip)
+            out = self._res(x, None if _lin is not None else _emb32(embedding, x.shape[0]), _lin, skip=sk, dest=_dest)
+            return ops.nhwc_bf16_to_nchw(out).to(input.dtype) if conv else _tag(out)
         if skip is not None:
             assert self.cat_factor is not None
             sk, _ = _as_nhwc(skip)
@@ -966,7 +1064,7 @@ class DecoderBlock(_BlockBase):
         if isinstance(self.resample, UpSample):
             x = _ResampleFn.apply(x, True)
             s_pre = None
-        out = self._res(x, None if _lin is not None else _emb32(embedding, x.shape[0]), _lin, s_pre)
+        out = self._res(x, None if _lin is not None else _emb32(embedding, x.shape[0]), _lin, s_pre, dest=_dest)
         return ops.nhwc_bf16_to_nchw(out).to(input.dtype) if conv else _tag(out)
 
     def forward_f32(self, x: Tensor, lin: Tensor, skip: Tensor | None = None) -> Tensor:
@@ -1316,8 +1414,25 @@ class Denoiser(nn.Module):
             x, x_in = block(_tag(x), None, _lin=lins[block], _alias=True)
             skips.append(x_in)
         skips.append(x)
-        for block, has_skip in zip(self.decoder_blocks, self.skip_connections):
-            x = block(_tag(x), None, _tag(skips.pop()) if has_skip else None, _lin=lins[block])
+        dec = list(zip(self.decoder_blocks, self.skip_connections))
+        for i, (block, has_skip) in enumerate(dec):
+            skip = skips.pop() if has_skip else None
+            dest = None
+            if FUSE_CAT and SKIP_GATE_FUSED and i + 1 < len(dec) and dec[i + 1][1]:
+                nxt = dec[i + 1][0]
+                if not isinstance(nxt.resample, UpSample) and isinstance(nxt.conv_1x1, Conv2d):
+                    # the next block concatenates this block's output with skips[-1]: this block's last kernel writes its
+                    # output and mp_silu of it into the left halves of those operands (no concat copy)
+                    up = 2 if isinstance(block.resample, UpSample) else 1
+                    Bx, Hx, Wx, _ = x.shape
+                    Ct = block.conv_3x3_2.weight.shape[0] + skips[-1].shape[-1]
+                    dest = (torch.empty(Bx, Hx * up, Wx * up, Ct, device=x.device, dtype=bf16),
+                            torch.empty(Bx, Hx * up, Wx * up, Ct, device=x.device, dtype=bf16))
+            xin = _tag(x)
+            cat_pre = getattr(x, "_edm_cat", None)
+            if cat_pre is not None:
+                xin._edm_cat = cat_pre
+            x = block(xin, None, _tag(skip) if has_skip else None, _lin=lins[block], _dest=dest)
         D = _ConvOutFn.apply(x, self.conv_out.weight, self.gain_out, noisy, sig, self)
         if self.training:
             rng.step += 1

@@ -381,6 +381,30 @@ def concat_gate_bwd(gcat, gate, gmean, Ci):
     return ginp, gskip
 
 
+def skip_half_fwd(skip, gate, cat, sil=None):
+    """cat[..., Ci:] = skip*gate (and sil[..., Ci:] = mp_silu of it) in place: the skip half of the decoder's concatenated
+    operands; the input half was written by the producer of `input` (conv_igemm(out=, silu_out=))."""
+    B, H, W, Cs = _nhwc(skip, "skip")
+    _chk(gate, f32, "gate", (B, Cs))
+    Ct = cat.shape[-1]
+    _chk(cat, bf16, "cat", (B, H, W, Ct))
+    if sil is not None:
+        _chk(sil, bf16, "sil", (B, H, W, Ct))
+    if Ct <= Cs:
+        raise ValueError("skip_half_fwd: cat must be wider than the skip")
+    _lib.call("edm_skip_half_fwd", _p(skip), _p(gate), _p(cat), _p(sil), B, H * W, Ct - Cs, Cs, _stream())
+
+
+def skip_half_bwd(gcs, gate, gmean):
+    """gskip = gcs*gate + gmean/HW from the skip half gcs of d loss / d cat (conv_igemm(split=) wrote it)"""
+    B, H, W, Cs = _nhwc(gcs, "gcs")
+    _chk(gate, f32, "gate", (B, Cs))
+    _chk(gmean, f32, "gmean", (B, Cs))
+    gskip = torch.empty_like(gcs)
+    _lib.call("edm_skip_half_bwd", _p(gcs), _p(gate), _p(gmean), _p(gskip), B, H * W, Cs, _stream())
+    return gskip
+
+
 def _sigma_arg(sigma, B):
     _chk(sigma, f32, "sigma")
     if sigma.numel() == 1:
@@ -444,7 +468,8 @@ def nhwc_bf16_to_nchw(x):
 
 
 # ------------------------------------------------------------------ convolution
-# 0 = pick per shape (default), 1 = register-staged 128x128 kernel, 2 = LDS-DMA 256x128 kernel
+# 0 = pick per shape (default), 1 = register-staged 128x128 kernel, 2 = LDS-DMA 256x128 kernel, 3 = tall 512x128 tile,
+# 5 = small-map split-K kernel, 6 = static-schedule 3x3 kernel (tests force each generation through this variable)
 IGEMM_VERSION = int(os.environ.get("EDM_IGEMM", "0"))
 
 
@@ -457,23 +482,21 @@ def _igemm_entry(npix, W, Cout, taps, Cin=0):
         return "edm_conv_igemm_v2"
     if IGEMM_VERSION == 3:
         return "edm_conv_igemm_v3"
-    if IGEMM_VERSION == 4:
-        return "edm_conv_igemm_v4" if (taps == 9 and Cin % 64 == 0 and Cin <= 2016) else "edm_conv_igemm_v3"
-    if IGEMM_VERSION == 6:      # v4's geometry on the 16x16x32 MFMA shape
+    if IGEMM_VERSION == 6:
         ok = taps == 9 and Cin % 64 == 0 and Cin <= 2016 and W <= 64
         return "edm_conv_igemm_v6" if ok else "edm_conv_igemm"
     if IGEMM_VERSION == 5:
         return "edm_conv_igemm_s" if (taps == 9 and Cin % 256 == 0 and Cin <= 2016 and W <= 16) else "edm_conv_igemm"
-    # per-shape choice from the r01 microbenchmarks (tools/microbench_conv.py): the LDS-DMA tall-tile kernels only pay
+    # per-shape choice from the microbenchmarks (tools/microbench_conv.py): the LDS-DMA tall-tile kernels only pay
     # off when they still give every CU >= 2 tiles; small feature maps keep the 128x128 register-staged kernel.
     if taps == 9:
         tm = (npix + 511) // 512
         tiles3 = tm * ((Cout + 127) // 128)
-        v4_ok = Cin % 64 == 0 and Cin <= 2016 and W <= 64
+        v6_ok = Cin % 64 == 0 and Cin <= 2016 and W <= 64
         if tiles3 >= 512:
-            return "edm_conv_igemm_v4" if v4_ok else "edm_conv_igemm_v3"
-        if v4_ok and tm * ((Cout + 63) // 64) >= 256:     # 512x64 tiles of the same kernel (16x16 layers at batch 128)
-            return "edm_conv_igemm_v4"
+            return "edm_conv_igemm_v6" if v6_ok else "edm_conv_igemm_v3"
+        if v6_ok and tm * ((Cout + 63) // 64) >= 256:     # 512x64 tiles of the same kernel (16x16 layers at batch 128)
+            return "edm_conv_igemm_v6"
         ts = ((npix + 127) // 128) * ((Cout + 63) // 64)
         if W <= 16 and Cin % 256 == 0 and Cin <= 2016 and 128 <= ts <= 1024:   # small maps: K split over the waves
             return "edm_conv_igemm_s"
@@ -482,23 +505,29 @@ def _igemm_entry(npix, W, Cout, taps, Cin=0):
     return "edm_conv_igemm_v2" if tiles2 >= 1024 else "edm_conv_igemm"
 
 
-# the static-schedule 3x3 kernel runs on v_mfma_f32_16x16x32_bf16 (k_conv3x3_v6) unless EDM_V4_MFMA16=0 selects the
-# 32x32x16 form (k_conv3x3_v4); the C side reads the same variable (csrc/conv_igemm4.hip)
-V46 = "_v6" if os.environ.get("EDM_V4_MFMA16", "1") != "0" else "_v4"
+V46 = "_v6"     # profile-key suffix of the static-schedule 3x3 kernel (its 32x32x16 predecessor, "_v4", was retired in round 4)
+# kernel ids of edm_conv_igemm_o (include/tinyedm_hip.h)
+_KERNEL_ID = {"edm_conv_igemm": 1, "edm_conv_igemm_v2": 2, "edm_conv_igemm_s": 5, "edm_conv_igemm_v6": 6}
 
 
 def _v4_suffix(entry, npix, Cout):
-    """profile-key suffix naming the kernel that runs: _v6 / _v4 = k_conv3x3_v6 / _v4 with 512x128 tiles, _v6s / _v4s =
-    the same kernel with 512x64 tiles (16x16 layers), _s = k_conv3x3_s (8x8 layers)"""
+    """profile-key suffix naming the kernel that runs: _v6 = k_conv3x3_v6 with 512x128 tiles, _v6s = the same kernel with
+    512x64 tiles (16x16 layers), _s = k_conv3x3_s (8x8 layers)"""
     if entry == "edm_conv_igemm_s":
         return "_s"
-    if entry != "edm_conv_igemm_v4":
+    if entry != "edm_conv_igemm_v6":
         return entry[len("edm_conv_igemm"):]
     return V46 if ((npix + 511) // 512) * ((Cout + 127) // 128) >= 512 else V46 + "s"
 
 
-def conv_igemm(x, wp, taps, residual=None, alpha=1.0, beta=0.0):
-    """Y = alpha*conv(x, wp) + beta*residual.  wp: bf16 (taps, Cout, Cin)."""
+def conv_igemm(x, wp, taps, residual=None, alpha=1.0, beta=0.0, out=None, silu_out=None, split=None):
+    """Y = alpha*conv(x, wp) + beta*residual.  wp: bf16 (taps, Cout, Cin).
+    Output descriptor (edm_conv_igemm_o; how the decoder's concat stops being a copy):
+      out       a (B, H, W, Cout) VIEW with unit channel stride and a row stride >= Cout (the left column block of a wider
+                NHWC buffer): the result is written there and `out` is returned;
+      silu_out  a view with the same strides as `out`: also receives mp_silu(Y);
+      split     (c, ya, yb): output channels < c go to ya (B, H, W, c), the others to yb (B, H, W, Cout - c), both
+                contiguous; returns (ya, yb)."""
     B, H, W, Cin = _nhwc(x, "x")
     _chk(wp, bf16, "wp")
     if wp.dim() != 3 or wp.shape[0] != taps or wp.shape[2] != Cin:
@@ -506,15 +535,50 @@ def conv_igemm(x, wp, taps, residual=None, alpha=1.0, beta=0.0):
     Cout = wp.shape[1]
     if residual is not None:
         _chk(residual, bf16, "residual", (B, H, W, Cout))
-    y = torch.empty(B, H, W, Cout, device=x.device, dtype=bf16)
     npix = B * H * W
     entry = _igemm_entry(npix, W, Cout, taps, Cin)
-    # profile key names the kernel generation that runs ("conv3x3_igemm_v4", "conv1x1_igemm", ...)
+    # profile key names the kernel generation that runs ("conv3x3_igemm_v6", "conv1x1_igemm", ...)
     pname = ("conv3x3_igemm" if taps == 9 else "conv1x1_igemm") + _v4_suffix(entry, npix, Cout)
-    with _prof(pname, 2.0 * npix * Cin * Cout * taps,
-               2.0 * (npix * (Cin + Cout * (2 if residual is not None else 1)) + wp.numel())):
-        _lib.call(entry, _p(x), _p(wp), _p(y), _p(residual), float(alpha), float(beta), B, H, W, Cin, Cout, taps, _stream())
-    return y
+    nbytes = 2.0 * (npix * (Cin + Cout * ((2 if residual is not None else 1) + (1 if silu_out is not None else 0))) + wp.numel())
+    if out is None and silu_out is None and split is None:
+        y = torch.empty(B, H, W, Cout, device=x.device, dtype=bf16)
+        with _prof(pname, 2.0 * npix * Cin * Cout * taps, nbytes):
+            _lib.call(entry, _p(x), _p(wp), _p(y), _p(residual), float(alpha), float(beta), B, H, W, Cin, Cout, taps, _stream())
+        return y
+    kid = _KERNEL_ID.get(entry)
+    if kid is None:
+        raise ValueError(f"conv_igemm: {entry} has no output-descriptor form (shape B={B} H={H} W={W} Cin={Cin} Cout={Cout})")
+    ld, ya, yb, ldb, c = 0, None, None, 0, 0
+    if split is not None:
+        if out is not None or silu_out is not None:
+            raise ValueError("conv_igemm: split excludes out / silu_out")
+        c, ya, yb = split
+        _chk(ya, bf16, "split[1]", (B, H, W, c))
+        _chk(yb, bf16, "split[2]", (B, H, W, Cout - c))
+        if c % 8 or not (0 < c < Cout):
+            raise ValueError("conv_igemm: split channel must be a multiple of 8 inside (0, Cout)")
+        ld, ldb = c, Cout - c
+    else:
+        if out is None:
+            out = torch.empty(B, H, W, Cout, device=x.device, dtype=bf16)
+        ld = _row_view(out, B, H, W, Cout, "out")
+        if silu_out is not None and _row_view(silu_out, B, H, W, Cout, "silu_out") != ld:
+            raise ValueError("conv_igemm: out and silu_out must have the same row stride")
+        ya = out
+    with _prof(pname, 2.0 * npix * Cin * Cout * taps, nbytes):
+        _lib.call("edm_conv_igemm_o", _p(x), _p(wp), _p(ya), ld, _p(silu_out), _p(yb), ldb, c, _p(residual), float(alpha),
+                  float(beta), B, H, W, Cin, Cout, taps, kid, _stream())
+    return (ya, yb) if split is not None else out
+
+
+def _row_view(t, B, H, W, C, name):
+    """row stride (elements) of a (B, H, W, C) bf16 view whose pixels are rows of one flat [B*H*W][ld] buffer"""
+    if t.dtype != bf16 or not t.is_cuda or tuple(t.shape) != (B, H, W, C):
+        raise ValueError(f"{name}: expected a cuda bf16 tensor of shape {(B, H, W, C)}, got {t.dtype} {tuple(t.shape)}")
+    sb, sh, sw, sc = t.stride()
+    if sc != 1 or sw < C or sw % 8 or sh != W * sw or sb != H * sh or (t.data_ptr() % 16):
+        raise ValueError(f"{name}: strides {t.stride()} are not those of a column block of an NHWC buffer")
+    return sw
 
 
 FUSE_MOD = os.environ.get("EDM_FUSE_MOD", "1") != "0"
@@ -536,7 +600,7 @@ def conv3x3_mod(x, wp, lin, gain, pdrop, seed, sub, step, want_u=True, dyn=None,
     a2 = torch.empty(B, H, W, Cout, device=x.device, dtype=bf16)
     npix = B * H * W
     entry = _igemm_entry(npix, W, Cout, 9, Cin)
-    pname = "conv3x3_igemm" + (_v4_suffix(entry, npix, Cout) if entry in ("edm_conv_igemm_v4", "edm_conv_igemm_s") else "")
+    pname = "conv3x3_igemm" + (_v4_suffix(entry, npix, Cout) if entry in ("edm_conv_igemm_v6", "edm_conv_igemm_s") else "")
     with _prof(pname, 2.0 * npix * Cin * Cout * 9, 2.0 * (npix * (Cin + Cout * (2 if want_u else 1)) + wp.numel())):
         _lib.call("edm_conv3x3_mod", _p(x), _p(wp), _p(u), _p(a2), _p(lin), ls, _p(gain), float(pdrop), int(seed),
                   int(sub), int(step), int(bool(mark_dropped)), B, H, W, Cin, Cout, _dyn(dyn), _stream())
@@ -574,7 +638,7 @@ def conv3x3_modbwd(gout, wd, alpha, r1, lin, gain, pdrop, seed, sub, step, glin_
         ggain = zeros_f32((), r1.device) if ggain_out is None else _chk(ggain_out, f32, "ggain_out", ())
     npix = B * H * W
     entry = _igemm_entry(npix, W, Cout, 9, Cin)
-    pname = "conv3x3_igemm" + (_v4_suffix(entry, npix, Cout) if entry in ("edm_conv_igemm_v4", "edm_conv_igemm_s") else "") + "_modbwd"
+    pname = "conv3x3_igemm" + (_v4_suffix(entry, npix, Cout) if entry in ("edm_conv_igemm_v6", "edm_conv_igemm_s") else "") + "_modbwd"
     with _prof(pname, 2.0 * npix * Cin * Cout * 9, 2.0 * (npix * (Cin + 2 * Cout) + wd.numel())):
         _lib.call("edm_conv3x3_modbwd", _p(gout), _p(wd), float(alpha), _p(r1), _p(lin), ls, _p(gain), _p(gr), _p(gm), gms,
                   float(pdrop), int(seed), int(sub), int(step), int(bool(u_marked)), B, H, W, Cin, Cout, _dyn(dyn), _stream())
@@ -611,7 +675,7 @@ def conv3x3_silubwd(g, wd, xpre, gextra=None, extra_scale=1.0):
     gx = torch.empty_like(xpre)
     npix = B * H * W
     entry = _igemm_entry(npix, W, Cout, 9, Cin)
-    pname = "conv3x3_igemm" + (_v4_suffix(entry, npix, Cout) if entry in ("edm_conv_igemm_v4", "edm_conv_igemm_s") else "") + "_silubwd"
+    pname = "conv3x3_igemm" + (_v4_suffix(entry, npix, Cout) if entry in ("edm_conv_igemm_v6", "edm_conv_igemm_s") else "") + "_silubwd"
     with _prof(pname, 2.0 * npix * Cin * Cout * 9,
                2.0 * (npix * (Cin + Cout * (3 if gextra is not None else 2)) + wd.numel())):
         _lib.call("edm_conv3x3_silubwd", _p(g), _p(wd), _p(xpre), _p(gextra), float(extra_scale), _p(gx), B, H, W, Cin,
