@@ -68,16 +68,19 @@ int edm_conv_igemm_s(const void* X, const void* Wp, void* Y, const void* R, floa
  * (the operand of that block's first 3x3 conv, networks.py:315); Yb (optional): output channels >= split go to
  * Yb[pixel * ldYb + channel - split] (the 1x1 dgrad that produces d loss / d cat writes d loss / d input and the raw
  * gradient of the gated skip to the two tensors their consumers read).  kernel: which generation runs (1 edm_conv_igemm,
- * 2 _v2, 5 _s, 6 _v6; -3 = shape not covered by it).  R stays contiguous [pixels][Cout]. */
+ * 2 _v2, 5 _s, 6 _v6; -3 = shape not covered by it).  R stays contiguous [pixels][Cout].
+ * wfrag != 0: Wp is a FRAGMENT-MAJOR pack (edm_weight_prep_multi, bits 8 / 9 of a record's taps field) -- the layout the
+ * 8x8 layers' kernel loads with coalesced 1-KiB instructions straight into MFMA operand registers; kernel 5 only.  The
+ * three fused 3x3 entry points below take the same flag (then they run kernel 5 whatever the shape heuristics say). */
 int edm_conv_igemm_o(const void* X, const void* Wp, void* Y, long ldY, void* Ysilu, void* Yb, long ldYb, int split,
                      const void* R, float alpha, float beta, int B, int H, int W, int Cin, int Cout, int taps, int kernel,
-                     edm_stream_t stream);
+                     int wfrag, edm_stream_t stream);
 /* first 3x3 conv of a block with the embedding modulation fused into its epilogue (networks.py:253-260 / 317-324):
  * Y = conv3x3(X) (bf16, may be NULL in eval), Y2 = dropout(mp_silu(Y * (lin[b,:]*gain + 1))) -- bit-identical to
  * edm_mod_silu_drop_fwd applied to Y (same Philox counters), so edm_mod_silu_drop_bwd serves as its backward. */
 int edm_conv3x3_mod(const void* X, const void* Wp, void* Y, void* Y2, const float* lin, long lin_stride,
                     const float* gain, float pdrop, unsigned long long seed, unsigned sub, unsigned step, int mark_dropped,
-                    int B, int H, int W, int Cin, int Cout, const void* dyn, edm_stream_t stream);
+                    int B, int H, int W, int Cin, int Cout, const void* dyn, int wfrag, edm_stream_t stream);
 /* backward counterpart: dgrad of the block's second 3x3 conv (ga = alpha*conv3x3(dY, Wd), never written) with the
  * modulation backward in the epilogue: GR = ga*keep*mp_silu'(u*m)*m, gm[b,c] += sum_px ga*keep*mp_silu'(u*m)*u (gm
  * zero-filled fp32, rows of gm_stride floats, 0 = Cout); finish with edm_mod_finish, or -- when gm is a column slice of a
@@ -88,11 +91,11 @@ int edm_conv3x3_mod(const void* X, const void* Wp, void* Y, void* Y2, const floa
 int edm_conv3x3_modbwd(const void* dY, const void* Wd, float alpha, const void* U, const float* lin, long lin_stride,
                        const float* gain, void* GR, float* gm, long gm_stride, float pdrop, unsigned long long seed,
                        unsigned sub, unsigned step, int u_marked, int B, int H, int W, int Cin, int Cout, const void* dyn,
-                       edm_stream_t stream);
+                       int wfrag, edm_stream_t stream);
 /* dgrad of a block's first 3x3 conv with the mp_silu backward of the block input in its epilogue
  * (g = conv3x3(dY, Wd) never written): GX = mp_silu'(Xpre)*g + add_scale*ADD (ADD may be NULL). */
 int edm_conv3x3_silubwd(const void* dY, const void* Wd, const void* Xpre, const void* ADD, float add_scale, void* GX,
-                        int B, int H, int W, int Cin, int Cout, edm_stream_t stream);
+                        int B, int H, int W, int Cin, int Cout, int wfrag, edm_stream_t stream);
 int edm_mod_finish(const float* gm, const float* lin, long lin_stride, const float* gain, float* glin, long glin_stride,
                    float* ggain, int B, int C, edm_stream_t stream);
 /* every block's finish in one launch: gm_all / lin_all / glin_all are [B][stride] fp32, items a DEVICE array of

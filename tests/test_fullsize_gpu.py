@@ -170,3 +170,57 @@ def test_cifar10_unconditional_forward_b128_vs_oracle():
     err32 = rel(D32[IMGS] - base, D_or32 - base)
     record("fullsize/cifar10_uncond_B128_forward_f32_path_vs_fp32_oracle", err32, 1e-4)
     assert err32 <= 1e-4, err32
+
+
+def test_fragment_major_packs_b128():
+    """Round 4: at batch 128 the 8x8 layers of the CIFAR-10 net run on k_conv3x3_s with FRAGMENT-MAJOR weight packs
+    (csrc/weights.hip; coalesced 1-KiB loads straight into MFMA operand registers).  Same values as the [tap][co][ci] packs:
+    the evaluation forward bit for bit, every parameter gradient of a training step up to the order of the fp32 atomics
+    both paths share -- and the plan really marks those layers (the 16 convs of the eight 8x8 blocks: 16 forward + 16 dgrad packs)."""
+    import tinyedm_amd as T
+    from tinyedm_amd import networks as N
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    ecfg, dcfg = O.cifar10_cfg()
+    P = O.init_params(ecfg, dcfg, torch.Generator().manual_seed(1), gains_nonzero=True)
+    g = torch.Generator().manual_seed(12)
+    B = 128
+    clean = (0.5 * torch.randn(B, 3, 32, 32, generator=g)).to(DEV)
+    sigma = (torch.randn(B, generator=g) * 1.2 - 1.2).exp().to(DEV)
+    res = {}
+    old = N.FRAG_PACKS
+    try:
+        for mode in (False, True):
+            N.FRAG_PACKS = mode
+            N._rng_sub_counter[0] = 0
+            T.manual_seed(5)
+            emb = T.Embedding(ecfg.fourier_dim, ecfg.embedding_dim, ecfg.num_classes, ecfg.add_factor)
+            den = T.Denoiser(dcfg.in_channels, dcfg.out_channels, tuple(dcfg.encoder_block_types),
+                             tuple(dcfg.decoder_block_types), tuple(dcfg.encoder_out_channels),
+                             tuple(dcfg.decoder_out_channels), tuple(dcfg.skip_connections), dcfg.dropout_rate,
+                             dcfg.sigma_data, dcfg.encoder_add_factor, dcfg.decoder_add_factor, dcfg.embedding_dim,
+                             dcfg.num_heads)
+            emb.load_state_dict({k[len("embedding."):]: v for k, v in P.items() if k.startswith("embedding.")})
+            den.load_state_dict({k[len("denoiser."):]: v for k, v in P.items() if k.startswith("denoiser.")})
+            model = T.EDM(diffuser=T.Diffuser(-1.2, 1.2), embedding=emb, denoiser=den, use_ema=False, use_uncertainty=False,
+                          steady_steps=10, rampup_steps=2, scheduler_interval="step", lr=1e-3).to(DEV)
+            base = model.configure_optimizers()["optimizer"]
+            model.eval()
+            with torch.no_grad():
+                D = model(clean, sigma, None).clone()
+            nfrag = sum(1 for plan in den._plans.values() for (wf, wd, _) in plan.caches
+                        for t in (wf, wd) if t is not None and getattr(t, "_edm_frag", False))
+            model.train()
+            base.zero_grad()
+            T.manual_seed(5)
+            loss = model.training_step((clean, None), 0)
+            loss.backward()
+            torch.cuda.synchronize()
+            res[mode] = (D, float(loss), base.arena.grad.clone(), nfrag)
+    finally:
+        N.FRAG_PACKS = old
+    assert res[False][3] == 0 and res[True][3] == 32, (res[False][3], res[True][3])
+    assert torch.equal(res[True][0], res[False][0])
+    assert abs(res[True][1] - res[False][1]) <= 1e-6 * abs(res[False][1])
+    e = rel(res[True][2], res[False][2])
+    assert e <= 1e-5, e

@@ -48,13 +48,13 @@ SIGNATURES = {
     "edm_conv_igemm": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_v2": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_v3": [P, P, P, P, F, F, I, I, I, I, I, I, P],
-    "edm_conv_igemm_o": [P, P, P, L, P, P, L, I, P, F, F, I, I, I, I, I, I, I, P],
+    "edm_conv_igemm_o": [P, P, P, L, P, P, L, I, P, F, F, I, I, I, I, I, I, I, I, P],
     "edm_conv_igemm_v6": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_s": [P, P, P, P, F, F, I, I, I, I, I, I, P],
-    "edm_conv3x3_mod": [P, P, P, P, P, L, P, F, U64, U, U, I, I, I, I, I, I, P, P],
-    "edm_conv3x3_modbwd": [P, P, F, P, P, L, P, P, P, L, F, U64, U, U, I, I, I, I, I, I, P, P],
+    "edm_conv3x3_mod": [P, P, P, P, P, L, P, F, U64, U, U, I, I, I, I, I, I, P, I, P],
+    "edm_conv3x3_modbwd": [P, P, F, P, P, L, P, P, P, L, F, U64, U, U, I, I, I, I, I, I, P, I, P],
     "edm_mod_finish_multi": [P, P, P, L, P, I, I, P],
-    "edm_conv3x3_silubwd": [P, P, P, P, F, P, I, I, I, I, I, P],
+    "edm_conv3x3_silubwd": [P, P, P, P, F, P, I, I, I, I, I, I, P],
     "edm_mod_finish": [P, P, L, P, P, L, P, I, I, P],
     "edm_conv_wgrad_nsplit": [I, I, I, I, I, I],
     "edm_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, P],

@@ -179,6 +179,8 @@ struct ModEpilogue {
   long ldYb;
   int split;              // multiple of 8
   // mode 3 (plain epilogue, EPI 0): Y2 = mp_silu(Y), same addressing as Y
+  int wfrag;              // (not an epilogue matter, but it travels with the launch): the weight pack is FRAGMENT-MAJOR
+                          // (weights.hip; only k_conv3x3_s reads that layout -- every other kernel refuses it)
 };
 constexpr uint32_t U_DROPPED = 0x7FFFu;   // the bf16 pattern of a dropped element in a marked U
 __device__ __forceinline__ void apply_dyn(ModEpilogue& m) {

@@ -25,6 +25,7 @@ bool edm_conv_tall_worthwhile(long npix, int Cout) {
 //   ldY    row stride of Y in elements (0 = Cout): Y may be a column block of a wider [pixels][ldY] buffer;
 //   Ysilu  optional: mp_silu(Y) (of the bf16-rounded result) at the same offsets of a second buffer with the same stride;
 //   Yb     optional: output channels >= split go to Yb[pixel * ldYb + channel - split] instead (split % 8 == 0);
+//   wfrag  the pack is fragment-major (edm_weight_prep_multi, bits 8 / 9 of a record's taps field): kernel 5 only;
 //   kernel which generation runs: 1 = k_conv_igemm, 2 = k_conv_igemm2, 5 = k_conv3x3_s, 6 = k_conv3x3_v6 (the caller picks
 //          per shape exactly as for the plain entry points; -3 = shape not covered by that generation).
 // Used by the decoder blocks: the producer of a block's `input` writes it (and mp_silu of it) into the left half of the
@@ -32,7 +33,7 @@ bool edm_conv_tall_worthwhile(long npix, int Cout) {
 // gradient of `input` and to the raw gradient of the gated skip (reference: networks.py:306-316 and its autograd).
 extern "C" int edm_conv_igemm_o(const void* X, const void* Wp, void* Y, long ldY, void* Ysilu, void* Yb, long ldYb,
                                 int split, const void* R, float alpha, float beta, int B, int H, int W, int Cin, int Cout,
-                                int taps, int kernel, hipStream_t st) {
+                                int taps, int kernel, int wfrag, hipStream_t st) {
   EDM_REQUIRE(X && Wp && Y, "conv_igemm_o: null pointer");
   EDM_REQUIRE(!Yb || (split > 0 && split < Cout && split % 8 == 0 && ldYb >= Cout - split && ldYb % 8 == 0),
               "conv_igemm_o: bad split output");
@@ -48,6 +49,8 @@ extern "C" int edm_conv_igemm_o(const void* X, const void* Wp, void* Y, long ldY
   mod.Yb = (bf16*)Yb;
   mod.ldYb = ldYb;
   mod.split = split;
+  mod.wfrag = wfrag;
+  EDM_REQUIRE(!wfrag || kernel == 5, "conv_igemm_o: a fragment-major pack (wfrag) is read by kernel 5 (k_conv3x3_s) only");
   switch (kernel) {
     case 1: return edm_conv_igemm_v1_ex(X, Wp, Y, R, alpha, beta, B, H, W, Cin, Cout, taps, mod, st);
     case 2: return edm_conv_igemm_v2_ex(X, Wp, Y, R, alpha, beta, B, H, W, Cin, Cout, taps, mod, st);
@@ -66,12 +69,16 @@ extern "C" int edm_conv_igemm_o(const void* X, const void* Wp, void* Y, long ldY
 // (k_conv3x3_s) for 8x8-class layers and the 128x128-tile kernel otherwise.
 extern "C" int edm_conv3x3_mod(const void* X, const void* Wp, void* Y, void* Y2, const float* lin, long lin_stride,
                                const float* gain, float pdrop, unsigned long long seed, unsigned sub, unsigned step,
-                               int mark_dropped, int B, int H, int W, int Cin, int Cout, const void* dyn, hipStream_t st) {
+                               int mark_dropped, int B, int H, int W, int Cin, int Cout, const void* dyn, int wfrag,
+                               hipStream_t st) {
   EDM_REQUIRE(X && Wp && Y2 && lin && gain, "conv3x3_mod: null pointer");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0 && lin_stride >= Cout && pdrop >= 0.f && pdrop < 1.f,
               "conv3x3_mod: bad args");
   ModEpilogue mod{lin, gain, (bf16*)Y2, lin_stride, H * W, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), sub, step,
                   nullptr, nullptr, nullptr, 0.f, 0, (const StepParams*)dyn, 0, (mark_dropped && pdrop > 0.f) ? 1 : 0};
+  mod.wfrag = wfrag;
+  if (wfrag)      // fragment-major pack: the caller has established that this shape runs on k_conv3x3_s
+    return edm_conv_igemm_s_ex(X, Wp, Y, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
   if (edm_conv_tall_worthwhile((long)B * H * W, Cout)) {
     const int rc = edm_conv_igemm_v6_ex(X, Wp, Y, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
     if (rc != EDM_ERR_UNSUPPORTED) return rc;
@@ -96,7 +103,7 @@ extern "C" int edm_conv3x3_mod(const void* X, const void* Wp, void* Y, void* Y2,
 extern "C" int edm_conv3x3_modbwd(const void* dY, const void* Wd, float alpha, const void* U, const float* lin,
                                   long lin_stride, const float* gain, void* GR, float* gm, long gm_stride, float pdrop,
                                   unsigned long long seed, unsigned sub, unsigned step, int u_marked, int B, int H, int W,
-                                  int Cin, int Cout, const void* dyn, hipStream_t st) {
+                                  int Cin, int Cout, const void* dyn, int wfrag, hipStream_t st) {
   EDM_REQUIRE(dY && Wd && U && lin && gain && GR && gm, "conv3x3_modbwd: null pointer");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0 && lin_stride >= Cout && pdrop >= 0.f && pdrop < 1.f &&
                   (gm_stride == 0 || gm_stride >= Cout),
@@ -104,6 +111,8 @@ extern "C" int edm_conv3x3_modbwd(const void* dY, const void* Wd, float alpha, c
   if ((H * W) % 32 != 0) return EDM_ERR_UNSUPPORTED;
   ModEpilogue mod{lin, gain, (bf16*)GR, lin_stride, H * W, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), sub, step,
                   (const bf16*)U, gm, nullptr, 0.f, 1, (const StepParams*)dyn, gm_stride, (u_marked && pdrop > 0.f) ? 1 : 0};
+  mod.wfrag = wfrag;
+  if (wfrag) return edm_conv_igemm_s_ex(dY, Wd, nullptr, nullptr, alpha, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
   if (edm_conv_tall_worthwhile((long)B * H * W, Cout)) {
     const int rc = edm_conv_igemm_v6_ex(dY, Wd, nullptr, nullptr, alpha, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
     if (rc != EDM_ERR_UNSUPPORTED) return rc;
@@ -120,11 +129,13 @@ extern "C" int edm_conv3x3_modbwd(const void* dY, const void* Wd, float alpha, c
 //   GX = mp_silu'(Xpre) * g + add_scale * ADD        (ADD optional: the residual-path gradient)
 // Same values as edm_conv_igemm followed by edm_silu_bwd.
 extern "C" int edm_conv3x3_silubwd(const void* dY, const void* Wd, const void* Xpre, const void* ADD, float add_scale,
-                                   void* GX, int B, int H, int W, int Cin, int Cout, hipStream_t st) {
+                                   void* GX, int B, int H, int W, int Cin, int Cout, int wfrag, hipStream_t st) {
   EDM_REQUIRE(dY && Wd && Xpre && GX, "conv3x3_silubwd: null pointer");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0, "conv3x3_silubwd: bad args");
   ModEpilogue mod{nullptr, nullptr, (bf16*)GX, 0, H * W, 0.f, 0u, 0u, 0u, 0u, (const bf16*)Xpre, nullptr, (const bf16*)ADD,
                   add_scale, 2, nullptr};
+  mod.wfrag = wfrag;
+  if (wfrag) return edm_conv_igemm_s_ex(dY, Wd, nullptr, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
   if (edm_conv_tall_worthwhile((long)B * H * W, Cout)) {
     const int rc = edm_conv_igemm_v6_ex(dY, Wd, nullptr, nullptr, 1.0f, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
     if (rc != EDM_ERR_UNSUPPORTED) return rc;

@@ -214,6 +214,7 @@ int launch(const void* X, const void* Wp, void* Y, const void* R, float alpha, f
 int edm_conv_igemm_v1_ex(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
                          int W, int Cin, int Cout, int taps, const ModEpilogue& mod, hipStream_t st) {
   EDM_REQUIRE(X && Wp && (Y || mod.Y2), "conv_igemm: null pointer");
+  EDM_REQUIRE(!mod.wfrag, "conv_igemm: fragment-major weight packs are read by k_conv3x3_s only");
   EDM_REQUIRE(mod.mode == 0 || mod.mode == 3 || taps == 9, "conv_igemm: the backward epilogues are 3x3 only");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && (long)B * H * W < (1L << 31), "conv_igemm: bad B/H/W");
   EDM_REQUIRE(taps == 1 || taps == 9, "conv_igemm: taps must be 1 or 9 (got %d)", taps);

@@ -304,6 +304,7 @@ extern "C" int edm_conv_igemm_v2_ablate(const void* X, const void* Wp, void* Y, 
 int edm_conv_igemm_v2_ex(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
                          int W, int Cin, int Cout, int taps, const ModEpilogue& mod, hipStream_t st) {
   EDM_REQUIRE(X && Wp && Y, "conv_igemm_v2: null pointer");
+  EDM_REQUIRE(!mod.wfrag, "conv_igemm_v2: fragment-major weight packs are read by k_conv3x3_s only");
   EDM_REQUIRE(mod.mode == 0 || mod.mode == 3, "conv_igemm_v2: plain / strided-output epilogues only");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && (long)B * H * W < (1L << 31), "conv_igemm_v2: bad B/H/W");
   EDM_REQUIRE(taps == 1 || taps == 9, "conv_igemm_v2: taps must be 1 or 9");

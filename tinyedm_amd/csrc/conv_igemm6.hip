@@ -426,6 +426,7 @@ void launch6(const void* X, const void* Wp, void* Y, const void* R, float alpha,
 int edm_conv_igemm_v6_ex(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
                          int W, int Cin, int Cout, int taps, const ModEpilogue& mod, hipStream_t st) {
   EDM_REQUIRE(X && Wp && (Y || mod.Y2), "conv_igemm_v6: null pointer");
+  EDM_REQUIRE(!mod.wfrag, "conv_igemm_v6: fragment-major weight packs are read by k_conv3x3_s only");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && (long)B * H * W < (1L << 31), "conv_igemm_v6: bad B/H/W");
   EDM_REQUIRE(Cout > 0 && Cout % 8 == 0, "conv_igemm_v6: Cout %% 8 required");
   if (taps != 9 || Cin <= 0 || Cin % 64 != 0 || Cin * 2 + 64 > ZERO_PAGE || W > 64) return EDM_ERR_UNSUPPORTED;

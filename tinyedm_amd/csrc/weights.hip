@@ -91,7 +91,10 @@ __global__ __launch_bounds__(256) void k_weight_prep_multi(const PrepDesc* __res
   extern __shared__ __attribute__((aligned(16))) char tile_raw[];
   bf16* tile = reinterpret_cast<bf16*>(tile_raw);  // [rb][n]
   const int2 gr = groups[blockIdx.x];               // (descriptor, first packed row)
-  const PrepDesc d = descs[gr.x];
+  PrepDesc d = descs[gr.x];
+  // bits 8 / 9 of the taps field: the forward / dgrad pack of this tensor is written FRAGMENT-MAJOR (see the pack phase)
+  const bool frag_fwd = (d.taps & 0x100) != 0, frag_dgrad = (d.taps & 0x200) != 0;
+  d.taps &= 0xFF;
   const int r0 = gr.y;
   const int rbc = min(d.rb, d.O - r0);
   const int n = d.I * d.taps;
@@ -231,7 +234,45 @@ __global__ __launch_bounds__(256) void k_weight_prep_multi(const PrepDesc* __res
   __syncthreads();
   // pack phase: index arithmetic is kept to adds (runtime integer division per element made this pass ALU-bound)
   const int taps = d.taps, I = d.I, Ipad = d.Ipad, O = d.O;
-  if (d.fwd) {  // [t][O][Ipad], ci fast: one (row, tap) pair per wave pass, lanes along ci
+  // Fragment-major packs (round 4, the 8x8 layers' kernel k_conv3x3_s): the 16 bytes lane (l31, lhi) of a wave feeds to
+  // v_mfma_f32_32x32x16_bf16 as its share of an A fragment -- row co = 32 cb + l31, channels 32 c + 16 ks + 8 lhi .. + 7 --
+  // are stored at [tap][c][cb][ks][lane = 32 lhi + l31][8]: a fragment is ONE contiguous KiB, so the kernel loads its
+  // weights straight into the registers it multiplies from with fully coalesced 1-KiB instructions (the [tap][co][ci] pack
+  // gives such a load 32 rows x 32 bytes: 64 cache-line look-ups per instruction, which bound the kernel).
+  // Host-checked for these tensors: I % 32 == 0, O % 32 == 0, Ipad == I, rb % 8 == 0, rb | 32.
+  if (d.fwd && frag_fwd) {
+    const int NC = I >> 5, NCB = O >> 5, cb = r0 >> 5, rl0 = r0 & 31;
+    const int items = taps * NC * 4 * rbc;                   // (t, c, ks, g, rr), rr fastest: runs of 16 rbc bytes
+    for (int idx = threadIdx.x; idx < items; idx += 256) {
+      const int rr = idx % rbc, q = idx / rbc;
+      const int g = q & 1, ks = (q >> 1) & 1, tc = q >> 2;
+      const int c = tc % NC, t = tc / NC;
+      const bf16* src = tile + (long)rr * n + (long)(c * 32 + ks * 16 + g * 8) * taps + t;
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = src[e * taps];
+      bf16* dst = d.fwd + ((((long)(t * NC + c) * NCB + cb) * 2 + ks) * 64 + g * 32 + rl0 + rr) * 8;
+      *reinterpret_cast<bf16x8*>(dst) = v;
+    }
+  }
+  if (d.dgrad && frag_dgrad) {
+    // the dgrad conv: taps flipped, "input" channels = O (this workgroup's rows), "output" channels = I
+    const int NC = O >> 5, NCB = I >> 5;
+    const int items = taps * (rbc >> 3) * I;                 // (t, og, i), i fastest: runs of 512 bytes
+    for (int idx = threadIdx.x; idx < items; idx += 256) {
+      const int i = idx % I, q = idx / I;
+      const int og = q % (rbc >> 3), t = q / (rbc >> 3);
+      const int o0 = r0 + og * 8;
+      const int c = o0 >> 5, ks = (o0 >> 4) & 1, g = (o0 >> 3) & 1;
+      const bf16* src = tile + (long)(og * 8) * n + (long)i * taps + t;
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = src[(long)e * n];
+      bf16* dst = d.dgrad + ((((long)((taps - 1 - t) * NC + c) * NCB + (i >> 5)) * 2 + ks) * 64 + g * 32 + (i & 31)) * 8;
+      *reinterpret_cast<bf16x8*>(dst) = v;
+    }
+  }
+  if (d.fwd && !frag_fwd) {  // [t][O][Ipad], ci fast: one (row, tap) pair per wave pass, lanes along ci
     for (int pair = wave; pair < rbc * taps; pair += 4) {
       const int rr = pair / taps, t = pair - rr * taps;  // wave-uniform (scalar unit)
       bf16* dst = d.fwd + ((long)t * O + r0 + rr) * Ipad;
@@ -248,7 +289,7 @@ __global__ __launch_bounds__(256) void k_weight_prep_multi(const PrepDesc* __res
       }
     }
   }
-  if (d.dgrad) {  // [(taps-1-t)][ci][O], co fast: rbc contiguous values per (t, ci); threads along ci
+  if (d.dgrad && !frag_dgrad) {  // [(taps-1-t)][ci][O], co fast: rbc contiguous values per (t, ci); threads along ci
     const bool vec = (rbc & 7) == 0 && (O & 7) == 0;
     for (int i = threadIdx.x; i < I; i += 256) {
       for (int t = 0; t < taps; ++t) {

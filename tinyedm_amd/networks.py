@@ -294,8 +294,11 @@ class _PrepPlan:
     """Multi-tensor weight preparation: ONE launch normalises and packs every weight of a network
     (edm_weight_prep_multi) into persistent kernel-layout buffers, instead of one launch per layer."""
 
-    def __init__(self, mods):
+    def __init__(self, mods, frag=None):
+        """frag: {module: (fwd, dgrad)} -- the 3x3 convs whose forward / dgrad pack is written FRAGMENT-MAJOR (csrc/weights.hip)
+        because k_conv3x3_s, the 8x8 layers' kernel, runs them at the current input shape (Denoiser._frag_flags)"""
         self.mods = mods
+        frag = frag or {}
         dev = mods[0].weight.device
         self.ptr_key = tuple(m.weight.data_ptr() for m in mods)
         desc = np.zeros(len(mods), dtype=np.dtype([
@@ -318,9 +321,17 @@ class _PrepPlan:
             while rb > 1 and (rb * I * taps * 2 > 96 * 1024 or rb > O):
                 rb //= 2
             lds = max(lds, rb * I * taps * 2)
+            ff, fd = frag.get(m, (False, False))
+            if not (taps == 9 and I % 32 == 0 and O % 32 == 0 and ipad == I and rb % 8 == 0 and m._perm is None):
+                ff = fd = False
+            if ff and wf is not None:
+                wf._edm_frag = True
+            if fd and wd is not None:
+                wd._edm_frag = True
             desc[k] = (w.data_ptr(), wf.data_ptr() if wf is not None else 0, wd.data_ptr() if wd is not None else 0,
                        wh.data_ptr() if wh is not None else 0, m._perm.data_ptr() if m._perm is not None else 0,
-                       O, I, taps, ipad, row0, rb)
+                       O, I, taps | (0x100 if ff and wf is not None else 0) | (0x200 if fd and wd is not None else 0), ipad,
+                       row0, rb)
             groups += [(k, r) for r in range(0, O, rb)]
             row0 += O
             self.caches.append((wf, wd, wh))
@@ -529,6 +540,8 @@ U_MARKS = os.environ.get("EDM_U_MARKS", "1") != "0"
 # produces d loss / d cat writes its two halves to the tensors their consumers read (ops.conv_igemm(split=)).
 # EDM_FUSE_CAT=0 keeps the standalone concat kernels (A/B runs).
 FUSE_CAT = os.environ.get("EDM_FUSE_CAT", "1") != "0"
+# fragment-major weight packs for the layers k_conv3x3_s runs (Denoiser._frag_flags); EDM_FRAG_PACKS=0: plain packs (A/B runs)
+FRAG_PACKS = os.environ.get("EDM_FRAG_PACKS", "1") != "0"
 
 
 def _col_block(buf: Tensor, C: int) -> Tensor:
@@ -1326,12 +1339,48 @@ class Denoiser(nn.Module):
             cached = self._modfin = (key, torch.from_numpy(rec.view(np.uint8).copy()).to(gains[0].device))
         return cached[1]
 
-    def _prep_all(self):
-        """One multi-tensor launch for every weight of the U-Net (forced normalisation in training + packs)."""
+    def _frag_flags(self, B: int, H: int, W: int):
+        """{conv module: (forward pack, dgrad pack) fragment-major?} for an input of this shape: the 3x3 convs that the
+        default dispatch runs on k_conv3x3_s (the 8x8 layers at batch 128) get packs in the layout that kernel loads with
+        coalesced 1-KiB instructions.  Depends on the shape only (the resolution of every block follows from the
+        architecture), cached per shape."""
+        cache = self.__dict__.setdefault("_fragcache", {})
+        key = (B, H, W)
+        if key not in cache:
+            flags = {}
+            h, w = H, W
+
+            def mark(conv, hh, ww):
+                O, I = conv.weight.shape[:2]
+                npix = B * hh * ww
+                f = (ops.uses_s_kernel(npix, ww, I, O), ops.uses_s_kernel(npix, ww, O, I))
+                if f[0] or f[1]:
+                    flags[conv] = f
+            for blk in self.encoder_blocks:
+                if isinstance(blk.resample, DownSample):
+                    h, w = h // 2, w // 2
+                mark(blk.conv_3x3_1, h, w)
+                mark(blk.conv_3x3_2, h, w)
+            for blk in self.decoder_blocks:
+                if isinstance(blk.resample, UpSample):
+                    h, w = h * 2, w * 2
+                mark(blk.conv_3x3_1, h, w)
+                mark(blk.conv_3x3_2, h, w)
+            cache[key] = flags
+        return cache[key]
+
+    def _prep_all(self, shape=None):
+        """One multi-tensor launch for every weight of the U-Net (forced normalisation in training + packs).
+        Plans (the persistent pack buffers) are kept per (weights, wanted packs, fragment-major set) and never freed: a
+        captured step or solve holds the addresses of the plan it was captured with."""
         mods = [m for m in self.modules() if isinstance(m, _WNBase)]
-        plan = getattr(self, "_plan", None)
-        if plan is None or not plan.valid_for(mods):
-            plan = self._plan = _PrepPlan(mods)
+        frag = self._frag_flags(*shape) if (shape is not None and FRAG_PACKS) else {}
+        key = (tuple(m.weight.data_ptr() for m in mods), tuple(m._want for m in mods),
+               tuple((k, v) for k, v in enumerate(frag.get(m) for m in mods) if v))
+        plans = self.__dict__.setdefault("_plans", {})
+        plan = plans.get(key)
+        if plan is None:
+            plan = plans[key] = _PrepPlan(mods, frag)
         plan.run(self.training)
 
     # ---- reference-precision evaluation (round 3): the reference samples / validates in fp32 (generate.py:39-44,
@@ -1349,7 +1398,6 @@ class Denoiser(nn.Module):
                 if isinstance(m, _WNBase) and "hat" not in m._want:
                     m._want = tuple(m._want) + ("hat",)
                     m._cache = None
-            self._plan = None
         self.eval_dtype = dtype
         return self
 
@@ -1388,7 +1436,7 @@ class Denoiser(nn.Module):
             global FORWARD_EPOCH
             FORWARD_EPOCH += 1
         with torch.no_grad():
-            self._prep_all()
+            self._prep_all((noisy_image.shape[0], noisy_image.shape[2], noisy_image.shape[3]))
         noisy = noisy_image.float().contiguous()
         B = noisy.shape[0]
         sig = sigma.detach().float().flatten().contiguous()

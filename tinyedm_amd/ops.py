@@ -505,6 +505,22 @@ def _igemm_entry(npix, W, Cout, taps, Cin=0):
     return "edm_conv_igemm_v2" if tiles2 >= 1024 else "edm_conv_igemm"
 
 
+def uses_s_kernel(npix, W, Cin, Cout):
+    """the default dispatch runs a 3x3 conv of this shape on k_conv3x3_s (the 8x8 layers' kernel) AND that kernel can take
+    a fragment-major weight pack for it (networks._PrepPlan writes one for such layers)"""
+    return (IGEMM_VERSION == 0 and Cout % 64 == 0 and Cin % 32 == 0
+            and _igemm_entry(npix, W, Cout, 9, Cin) == "edm_conv_igemm_s")
+
+
+def _wfrag(wp, entry, who):
+    """1 when wp is a fragment-major pack (tagged by the plan that wrote it); such a pack is only valid on k_conv3x3_s"""
+    if not getattr(wp, "_edm_frag", False):
+        return 0
+    if entry != "edm_conv_igemm_s":
+        raise ValueError(f"{who}: a fragment-major weight pack reached a shape that does not run on k_conv3x3_s ({entry})")
+    return 1
+
+
 V46 = "_v6"     # profile-key suffix of the static-schedule 3x3 kernel (its 32x32x16 predecessor, "_v4", was retired in round 4)
 # kernel ids of edm_conv_igemm_o (include/tinyedm_hip.h)
 _KERNEL_ID = {"edm_conv_igemm": 1, "edm_conv_igemm_v2": 2, "edm_conv_igemm_s": 5, "edm_conv_igemm_v6": 6}
@@ -540,7 +556,8 @@ def conv_igemm(x, wp, taps, residual=None, alpha=1.0, beta=0.0, out=None, silu_o
     # profile key names the kernel generation that runs ("conv3x3_igemm_v6", "conv1x1_igemm", ...)
     pname = ("conv3x3_igemm" if taps == 9 else "conv1x1_igemm") + _v4_suffix(entry, npix, Cout)
     nbytes = 2.0 * (npix * (Cin + Cout * ((2 if residual is not None else 1) + (1 if silu_out is not None else 0))) + wp.numel())
-    if out is None and silu_out is None and split is None:
+    wfrag = _wfrag(wp, entry, "conv_igemm")
+    if out is None and silu_out is None and split is None and not wfrag:
         y = torch.empty(B, H, W, Cout, device=x.device, dtype=bf16)
         with _prof(pname, 2.0 * npix * Cin * Cout * taps, nbytes):
             _lib.call(entry, _p(x), _p(wp), _p(y), _p(residual), float(alpha), float(beta), B, H, W, Cin, Cout, taps, _stream())
@@ -567,7 +584,7 @@ def conv_igemm(x, wp, taps, residual=None, alpha=1.0, beta=0.0, out=None, silu_o
         ya = out
     with _prof(pname, 2.0 * npix * Cin * Cout * taps, nbytes):
         _lib.call("edm_conv_igemm_o", _p(x), _p(wp), _p(ya), ld, _p(silu_out), _p(yb), ldb, c, _p(residual), float(alpha),
-                  float(beta), B, H, W, Cin, Cout, taps, kid, _stream())
+                  float(beta), B, H, W, Cin, Cout, taps, kid, wfrag, _stream())
     return (ya, yb) if split is not None else out
 
 
@@ -603,7 +620,8 @@ def conv3x3_mod(x, wp, lin, gain, pdrop, seed, sub, step, want_u=True, dyn=None,
     pname = "conv3x3_igemm" + (_v4_suffix(entry, npix, Cout) if entry in ("edm_conv_igemm_v6", "edm_conv_igemm_s") else "")
     with _prof(pname, 2.0 * npix * Cin * Cout * 9, 2.0 * (npix * (Cin + Cout * (2 if want_u else 1)) + wp.numel())):
         _lib.call("edm_conv3x3_mod", _p(x), _p(wp), _p(u), _p(a2), _p(lin), ls, _p(gain), float(pdrop), int(seed),
-                  int(sub), int(step), int(bool(mark_dropped)), B, H, W, Cin, Cout, _dyn(dyn), _stream())
+                  int(sub), int(step), int(bool(mark_dropped)), B, H, W, Cin, Cout, _dyn(dyn), _wfrag(wp, entry, "conv3x3_mod"),
+                  _stream())
     return u, a2
 
 
@@ -641,7 +659,8 @@ def conv3x3_modbwd(gout, wd, alpha, r1, lin, gain, pdrop, seed, sub, step, glin_
     pname = "conv3x3_igemm" + (_v4_suffix(entry, npix, Cout) if entry in ("edm_conv_igemm_v6", "edm_conv_igemm_s") else "") + "_modbwd"
     with _prof(pname, 2.0 * npix * Cin * Cout * 9, 2.0 * (npix * (Cin + 2 * Cout) + wd.numel())):
         _lib.call("edm_conv3x3_modbwd", _p(gout), _p(wd), float(alpha), _p(r1), _p(lin), ls, _p(gain), _p(gr), _p(gm), gms,
-                  float(pdrop), int(seed), int(sub), int(step), int(bool(u_marked)), B, H, W, Cin, Cout, _dyn(dyn), _stream())
+                  float(pdrop), int(seed), int(sub), int(step), int(bool(u_marked)), B, H, W, Cin, Cout, _dyn(dyn),
+                  _wfrag(wd, entry, "conv3x3_modbwd"), _stream())
     if gm_out is not None:
         return gr, None, None
     _lib.call("edm_mod_finish", _p(gm), _p(lin), ls, _p(gain), _p(glin), gs, _p(ggain), B, Cout, _stream())
@@ -679,7 +698,7 @@ def conv3x3_silubwd(g, wd, xpre, gextra=None, extra_scale=1.0):
     with _prof(pname, 2.0 * npix * Cin * Cout * 9,
                2.0 * (npix * (Cin + Cout * (3 if gextra is not None else 2)) + wd.numel())):
         _lib.call("edm_conv3x3_silubwd", _p(g), _p(wd), _p(xpre), _p(gextra), float(extra_scale), _p(gx), B, H, W, Cin,
-                  Cout, _stream())
+                  Cout, _wfrag(wd, entry, "conv3x3_silubwd"), _stream())
     return gx
 
 
