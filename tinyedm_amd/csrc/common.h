@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include <atomic>
 
 typedef __bf16 bf16;
@@ -40,6 +41,22 @@ extern "C" const void* edm_zero_page(void);
       edm_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
       return EDM_ERR_LAUNCH;                                          \
     }                                                                 \
+  } while (0)
+
+// Launch TABLES live in device memory (round 4).  The grouped weight-gradient / finish kernels used to take their layer
+// tables (1.3-2 KB) as by-value kernel arguments; under hipGraph capture those sat in the one suspect of the round-2
+// corruption that could not be ruled out.  Now the host builds the table in caller-provided PINNED memory, one
+// stream-ordered copy puts it into caller-provided device memory, and the kernels take a pointer: no kernel of a captured
+// step carries more than ~200 bytes of arguments.  Caller contract: `host_stage` stays valid and unmodified until the copy
+// has executed (for a captured stream: for the life of the graph), `dev` until the kernels have.
+#define EDM_UPLOAD_TABLE(dev, host_stage, src, bytes, st, name)                                                        \
+  do {                                                                                                                 \
+    EDM_REQUIRE((dev) && (host_stage), name ": the launch table needs a pinned host staging buffer and a device buffer"); \
+    memcpy((host_stage), (src), (bytes));                                                                              \
+    if (hipMemcpyAsync((dev), (host_stage), (bytes), hipMemcpyHostToDevice, (st)) != hipSuccess) {                      \
+      edm_set_error("%s: uploading the launch table failed: %s", name, hipGetErrorString(hipGetLastError()));         \
+      return EDM_ERR_LAUNCH;                                                                                           \
+    }                                                                                                                  \
   } while (0)
 
 #define SILU_DIV 0.596f

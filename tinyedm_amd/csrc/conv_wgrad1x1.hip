@@ -185,7 +185,8 @@ struct W1Group {
 // placement; layer ranges start at multiples of 8) and the second..last read of a row hits that XCD's L2 instead of HBM:
 // within a chunk of 8 * tiles consecutive blocks, block j is split (chunk * 8 + j % 8), tile j / 8.  Splits past the
 // layer's count (its block range is padded to whole chunks) exit at once.
-__global__ __launch_bounds__(512, 1) void k_wgrad1x1_group(W1Group g) {
+__global__ __launch_bounds__(512, 1) void k_wgrad1x1_group(const W1Group* __restrict__ gp) {
+  const W1Group& g = *gp;   // (device memory: common.h EDM_UPLOAD_TABLE)
   int i = 0;
   const int b = blockIdx.x;
   while (i + 1 < g.n && b >= g.wg_end[i]) ++i;
@@ -256,7 +257,9 @@ struct edm_wgrad1_item_ {
   long npix;
   int Cin, Cout, nsplit, pad;
 };
-extern "C" int edm_conv_wgrad_1x1_group(const void* items_, int n, hipStream_t st) {
+extern "C" long edm_conv_wgrad_1x1_group_table_bytes(void) { return (long)sizeof(W1Group); }
+
+extern "C" int edm_conv_wgrad_1x1_group(const void* items_, int n, void* table_host, void* table_dev, hipStream_t st) {
   const edm_wgrad1_item_* items = (const edm_wgrad1_item_*)items_;
   EDM_REQUIRE(items && n > 0 && n <= W1_MAX, "conv_wgrad_1x1_group: 1..%d layers per group", W1_MAX);
   EDM_ZERO_PAGE(zero_page_, "conv_wgrad_1x1_group");
@@ -301,7 +304,8 @@ extern "C" int edm_conv_wgrad_1x1_group(const void* items_, int n, hipStream_t s
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad1x1_group), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set.store(true, std::memory_order_release);
   }
-  hipLaunchKernelGGL(k_wgrad1x1_group, dim3((unsigned)total), dim3(512), (size_t)RING * STAGE, st, g);
+  EDM_UPLOAD_TABLE(table_dev, table_host, &g, sizeof(W1Group), st, "conv_wgrad_1x1_group");
+  hipLaunchKernelGGL(k_wgrad1x1_group, dim3((unsigned)total), dim3(512), (size_t)RING * STAGE, st, (const W1Group*)table_dev);
   EDM_CHECK_LAUNCH("conv_wgrad_1x1_group");
   return EDM_OK;
 }

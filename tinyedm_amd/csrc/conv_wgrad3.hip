@@ -100,7 +100,8 @@ __device__ __forceinline__ bf16x8 frag_of(const u32x2_t& lo, const u32x2_t& hi) 
 // ds_read_b64_tr_b16 of rows 8g..8g+3 and 8g+4..8g+7 per 16-lane group g -- and the wave's 64(co) x 32(ci) x 9 taps are
 // 72 accumulator blocks of 4 registers (64 in AGPRs, tap 8 in VGPRs, as before).
 template <int LEADS, int ABL = 0, bool MF16 = false>
-__global__ __launch_bounds__(256, 1) void k_wgrad3(const W3Group g) {
+__global__ __launch_bounds__(256, 1) void k_wgrad3(const W3Group* __restrict__ gp) {
+  const W3Group& g = *gp;   // (device memory: uniform scalar loads, as from the kernel-argument segment)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int XR = Ring<LEADS>::XR, MIRR = Ring<LEADS>::MIRR, XSLOTS = Ring<LEADS>::XSLOTS;
   char* dYb = smem;                          // [DYRING][4 sub][64 rows][64 B]
@@ -460,7 +461,8 @@ __device__ __forceinline__ float block_sum_f(float v, float* red) {
   return s;
 }
 
-__global__ __launch_bounds__(256) void k_wgrad3_finish(const F3Group g) {
+__global__ __launch_bounds__(256) void k_wgrad3_finish(const F3Group* __restrict__ gp) {
+  const F3Group& g = *gp;
   extern __shared__ __attribute__((aligned(16))) float gsm[];  // [n] gradient row in master order (i*9 + t)
   __shared__ float red[8];
   int li = 0;
@@ -617,8 +619,10 @@ extern "C" long edm_wgrad3_workspace(const edm_wgrad3_item* items, int n) {
 
 // Weight gradients of up to 16 3x3 layers: one stream-K launch + one finish launch.  `items` is HOST memory (read
 // during the call only); workspace is device memory of at least edm_wgrad3_workspace(items, n) bytes.
+extern "C" long edm_wgrad3_table_bytes(void) { return (long)(sizeof(W3Group) + sizeof(F3Group)); }
+
 extern "C" int edm_wgrad3_group(const edm_wgrad3_item* items, int n, void* workspace, long workspace_bytes,
-                                hipStream_t st) {
+                                void* table_host, void* table_dev, hipStream_t st) {
   Plan P;
   const int rc = make_plan(items, n, P);
   if (rc != EDM_OK) return rc;
@@ -629,12 +633,22 @@ extern "C" int edm_wgrad3_group(const edm_wgrad3_item* items, int n, void* works
   P.wg.work = (float*)workspace;
   P.wg.zeros = zeros;
   P.fg.work = (const float*)workspace;
+  // the two layer tables go to device memory with ONE stream-ordered copy (common.h: EDM_UPLOAD_TABLE)
+  static_assert(sizeof(W3Group) % 16 == 0, "F3Group must start aligned behind W3Group");
+  {
+    char stage[sizeof(W3Group) + sizeof(F3Group)];
+    memcpy(stage, &P.wg, sizeof(W3Group));
+    memcpy(stage + sizeof(W3Group), &P.fg, sizeof(F3Group));
+    EDM_UPLOAD_TABLE(table_dev, table_host, stage, sizeof(stage), st, "wgrad3");
+  }
+  const W3Group* const wgp = (const W3Group*)table_dev;
+  const F3Group* const fgp = (const F3Group*)((const char*)table_dev + sizeof(W3Group));
   static std::atomic<bool> set1{false}, set2{false}, setf{false};   // (idempotent calls: a race only repeats them)
   static const int abl = [] { const char* e = getenv("EDM_W3_ABLATE"); return e ? atoi(e) : 0; }();   // tools only
   if (P.leads == 1 && abl) {
     auto go = [&](auto kern) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipLaunchKernelGGL(kern, dim3(P.wg.nwg), dim3(256), Ring<1>::LDS, st, P.wg);
+      hipLaunchKernelGGL(kern, dim3(P.wg.nwg), dim3(256), Ring<1>::LDS, st, wgp);
     };
     switch (abl) {
       case 1: go(k_wgrad3<1, 1>); break;
@@ -660,7 +674,7 @@ extern "C" int edm_wgrad3_group(const edm_wgrad3_item* items, int n, void* works
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         once = true;
       }
-      hipLaunchKernelGGL(kern, dim3(P.wg.nwg), dim3(256), lds, st, P.wg);
+      hipLaunchKernelGGL(kern, dim3(P.wg.nwg), dim3(256), lds, st, wgp);
     };
     static std::atomic<bool> set1m{false}, set2m{false};
     if (P.leads == 1) { if (mf16) go(k_wgrad3<1, 0, true>, Ring<1>::LDS, set1m); else go(k_wgrad3<1>, Ring<1>::LDS, set1); }
@@ -671,7 +685,7 @@ extern "C" int edm_wgrad3_group(const edm_wgrad3_item* items, int n, void* works
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3_finish), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     setf = true;
   }
-  hipLaunchKernelGGL(k_wgrad3_finish, dim3(P.rows_total), dim3(256), (size_t)P.max_n * 4, st, P.fg);
+  hipLaunchKernelGGL(k_wgrad3_finish, dim3(P.rows_total), dim3(256), (size_t)P.max_n * 4, st, fgp);
   EDM_CHECK_LAUNCH("wgrad3_finish");
   return EDM_OK;
 }

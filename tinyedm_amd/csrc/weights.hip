@@ -424,7 +424,8 @@ struct FinGroup {
   FinItem it[MAXF];
   int n;
 };
-__global__ __launch_bounds__(512) void k_wgrad_finish_multi(const FinGroup g) {
+__global__ __launch_bounds__(512) void k_wgrad_finish_multi(const FinGroup* __restrict__ gp) {
+  const FinGroup& g = *gp;   // (device memory: common.h EDM_UPLOAD_TABLE)
   extern __shared__ __attribute__((aligned(16))) float smm[];
   __shared__ float red[16];
   int k = 0;
@@ -510,7 +511,9 @@ typedef struct {
 }
 
 // Reduce + project up to 40 weight gradients in one launch (`items` is HOST memory, read during the call).
-extern "C" int edm_wgrad_finish_multi(const edm_finish_item* items, int n, hipStream_t st) {
+extern "C" long edm_wgrad_finish_multi_table_bytes(void) { return (long)sizeof(FinGroup); }
+
+extern "C" int edm_wgrad_finish_multi(const edm_finish_item* items, int n, void* table_host, void* table_dev, hipStream_t st) {
   EDM_REQUIRE(items && n > 0 && n <= MAXF, "wgrad_finish_multi: need 1..%d tensors, got %d", MAXF, n);
   FinGroup g;
   g.n = n;
@@ -535,7 +538,8 @@ extern "C" int edm_wgrad_finish_multi(const edm_finish_item* items, int n, hipSt
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_finish_multi), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     attr_set.store(true, std::memory_order_release);
   }
-  hipLaunchKernelGGL(k_wgrad_finish_multi, dim3(row), dim3(512), lds, st, g);
+  EDM_UPLOAD_TABLE(table_dev, table_host, &g, sizeof(FinGroup), st, "wgrad_finish_multi");
+  hipLaunchKernelGGL(k_wgrad_finish_multi, dim3(row), dim3(512), lds, st, (const FinGroup*)table_dev);
   EDM_CHECK_LAUNCH("wgrad_finish_multi");
   return EDM_OK;
 }

@@ -105,6 +105,62 @@ def capture_begin():
 capture_end = capture_begin
 
 
+class _LaunchTables:
+    """Staging for the launch tables of the grouped kernels (edm_wgrad3_group, edm_conv_wgrad_1x1_group,
+    edm_wgrad_finish_multi; include/tinyedm_hip.h "LAUNCH TABLES"): the C side writes a table into PINNED host memory and
+    copies it, stream-ordered, into device memory that the kernels read -- nothing larger than a few hundred bytes travels
+    as a by-value kernel argument.
+    Eager steps take (host, device) slot pairs from a ring; a slot is reused only after the event recorded behind its last
+    use has completed.  While a stream is being CAPTURED the copy becomes a memcpy node that every replay executes again
+    from the same host address, so those slots come from a bump-allocated pinned pool that is never reused or freed
+    (allocated up front: pinning memory is not a capturable call)."""
+    RING, POOL = 64, 512
+
+    def __init__(self):
+        self.dev = {}
+
+    def _state(self, device):
+        key = torch.device(device).index
+        key = torch.cuda.current_device() if key is None else key
+        st = self.dev.get(key)
+        if st is None:
+            nb = max(int(_lib.call("edm_wgrad3_table_bytes")), int(_lib.call("edm_conv_wgrad_1x1_group_table_bytes")),
+                     int(_lib.call("edm_wgrad_finish_multi_table_bytes")))
+            nb = (nb + 255) // 256 * 256
+            d = torch.device("cuda", key)
+            st = self.dev[key] = {
+                "nb": nb, "i": 0, "events": [None] * self.RING,
+                "host": torch.empty(self.RING, nb, dtype=torch.uint8).pin_memory(),
+                "devb": torch.empty(self.RING, nb, dtype=torch.uint8, device=d),
+                "pool": torch.empty(self.POOL, nb, dtype=torch.uint8).pin_memory(), "pool_i": 0, "pool_dev": []}
+        return st
+
+    def take(self, device):
+        """-> (host pointer, device pointer, release()): call release() right after the launch that uses the table"""
+        st = self._state(device)
+        if torch.cuda.is_current_stream_capturing():
+            k = st["pool_i"]
+            if k >= self.POOL:
+                raise RuntimeError("tinyedm_amd: out of pinned launch-table slots for captured graphs (ops._LaunchTables.POOL)")
+            st["pool_i"] = k + 1
+            dev = torch.empty(st["nb"], dtype=torch.uint8, device=st["devb"].device)   # from the capturing graph's pool
+            st["pool_dev"].append(dev)
+            return st["pool"][k].data_ptr(), dev.data_ptr(), (lambda: None)
+        k = st["i"] % self.RING
+        st["i"] += 1
+        if st["events"][k] is not None:
+            st["events"][k].synchronize()
+
+        def release(st=st, k=k):
+            ev = torch.cuda.Event()
+            ev.record()
+            st["events"][k] = ev
+        return st["host"][k].data_ptr(), st["devb"][k].data_ptr(), release
+
+
+_tables = _LaunchTables()
+
+
 class GraphCorruptionError(RuntimeError):
     """raised by check_health(): a training step or a sampler solve produced non-finite values"""
 
@@ -755,8 +811,10 @@ def conv_wgrad_1x1_group(pairs):
         out.append(slabs)
         flops += 2.0 * npix * Cin * Cout
         nbytes += 2.0 * npix * (Cin + Cout) + 4.0 * slabs.numel()
+    th, td, release = _tables.take(pairs[0][0].device)
     with _prof("conv1x1_wgrad", flops, nbytes):
-        _lib.call("edm_conv_wgrad_1x1_group", ctypes.byref(arr), n, _stream())
+        _lib.call("edm_conv_wgrad_1x1_group", ctypes.byref(arr), n, ctypes.c_void_p(th), ctypes.c_void_p(td), _stream())
+    release()
     return out
 
 
@@ -804,8 +862,10 @@ def wgrad3_group(items):
     if nb <= 0:
         raise _lib.HipKernelError(f"edm_wgrad3_workspace failed: {_lib.lib().edm_last_error().decode()}")
     work = torch.empty(nb // 4, device=items[0][0].device, dtype=f32)
+    th, td, release = _tables.take(items[0][0].device)
     with _prof("conv3x3_wgrad", flops, nbytes):
-        _lib.call("edm_wgrad3_group", ctypes.byref(arr), n, _p(work), nb, _stream())
+        _lib.call("edm_wgrad3_group", ctypes.byref(arr), n, _p(work), nb, ctypes.c_void_p(th), ctypes.c_void_p(td), _stream())
+    release()
     return work
 
 
@@ -873,7 +933,9 @@ def wgrad_finish_multi(items):
                 _chk(perm, torch.int32, "perm", (O,))
             arr[k] = _lib.FinishItem(slabs.data_ptr(), w.data_ptr(), grad.data_ptr(), None if perm is None else perm.data_ptr(),
                                      S, O, I, Ipad, taps, float(scale), int(bool(accumulate)))
-        _lib.call("edm_wgrad_finish_multi", ctypes.byref(arr), len(chunk), _stream())
+        th, td, release = _tables.take(chunk[0][0].device)
+        _lib.call("edm_wgrad_finish_multi", ctypes.byref(arr), len(chunk), ctypes.c_void_p(th), ctypes.c_void_p(td), _stream())
+        release()
 
 
 # ------------------------------------------------------------------ attention
