@@ -403,7 +403,8 @@ def sampler_bench(args, model, device, network_dtype="bf16"):
     model.denoiser.set_eval_dtype(network_dtype)
     solver = tinyedm.DeterministicSolver(num_steps=32)
     f32 = network_dtype == "f32"
-    B = args.sampler_f32_batch if f32 else args.sampler_batch
+    split = network_dtype == "f32x3"
+    B = args.sampler_f32_batch if (f32 or split) else args.sampler_batch
     iters = 1 if f32 else args.sampler_iters
     graph = _RE.GRAPH_REPLAY_SAFE
     g = torch.Generator().manual_seed(7)
@@ -421,10 +422,11 @@ def sampler_bench(args, model, device, network_dtype="bf16"):
         raise RuntimeError("bench: the sampler produced non-finite images")
     model.denoiser.set_eval_dtype("bf16")
     peak = F32_MFMA_PEAK_TFLOPS if f32 else MFMA_PEAK_TFLOPS
+    passes = 3 if split else 1      # split-bf16: every conv product is three bf16 MFMA passes (hi.w_hi + hi.w_lo + lo.w_hi)
     return {"img_per_s": B / dt, "batch": B, "heun_steps": 32, "nfe": 63, "ms_per_solve": dt * 1e3,
             "hipgraph": bool(graph), "state_dtype": "f32", "network_dtype": network_dtype,
-            "mfma_frac": round(B / dt * 63 * FWD_GFLOP_PER_IMG / 1e3 / peak, 4),
-            "mfma_peak_tflops": peak}
+            "mfma_frac": round(B / dt * 63 * FWD_GFLOP_PER_IMG * passes / 1e3 / peak, 4),
+            "mfma_peak_tflops": peak, "mfma_passes_per_product": passes}
 
 
 def cpu_baseline(args):
@@ -604,6 +606,9 @@ def main():
             if not args.no_sampler_fp32:
                 # the reference-faithful figure: the reference samples in fp32; priced against the f32-input MFMA peak
                 out["sampler_fp32"] = sampler_bench(args, model, device, "f32")
+                # the same precision class (2^-17 per operand; 32-step trajectory 2e-6 from the exact path) on the bf16 kernels:
+                # split-bf16, three MFMA passes per product (tinyedm_amd/networks.py _conv_f32)
+                out["sampler_fp32_split"] = sampler_bench(args, model, device, "f32x3")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
     if dist.is_initialized():

@@ -307,6 +307,16 @@ int edm_scale_f32(const float* x, float s, float* y, long n, edm_stream_t stream
 int edm_f32_conv(const float* X, const float* w_hat, float* Y, const float* R, float alpha, float beta, const float* lin,
                  long lin_stride, const float* gain, int B, int H, int W, int Cin, int I, int Cout, int taps,
                  edm_stream_t stream);
+/* Split-bf16 form of the same evaluation (round 4): an fp32-accurate convolution at a third of the bf16 kernels' rate
+ * instead of the f32-MFMA rate (1/16).  An fp32 value travels as a PAIR of bf16, hi = bf16(x), lo = bf16(x - hi):
+ * edm_f32_to_pairs turns [rows][C] floats into [rows][2 C] bf16 = [hi | lo]; edm_split_pack turns w_hat [O][I*taps] into
+ * [taps][O][3 Ip] bf16 = [w_hi | w_lo | w_hi]; edm_split_conv accumulates hi.w_hi + hi.w_lo + lo.w_hi in fp32 (what is
+ * dropped, lo.w_lo, is 2^-18 of a product) and writes FLOATS: Y = alpha*conv + beta*R (R floats), or, with lin,
+ * Y = mp_silu(conv * (lin[b,:]*gain + 1)).  C % 32 == 0, Cout % 8 == 0, taps in {1, 9}. */
+int edm_f32_to_pairs(const float* x, void* pairs, long rows, int C, edm_stream_t stream);
+int edm_split_pack(const float* w_hat, void* pack, int O, int I, int taps, int Ip, edm_stream_t stream);
+int edm_split_conv(const void* Xp, const void* Wp3, float* Y, const float* R, float alpha, float beta, const float* lin,
+                   long lin_stride, const float* gain, int B, int H, int W, int C, int Cout, int taps, edm_stream_t stream);
 /* cosine attention (networks.py:194-202) on the qkv conv's own output order: channel head*3d + 3*dd + {q,k,v};
  * y [B*N][C] with channel head*d + dd.  head_dim in {32, 64, 128, 144, 192}; any number of tokens (key tiles of 64). */
 int edm_f32_attention(const float* qkv, float* y, int B, int N, int C, int heads, edm_stream_t stream);

@@ -210,8 +210,8 @@ def test_latent_pipeline_datamodule_fit_and_generate_callback(ops, tmp_path, siz
     # Reference semantics, kept: the EMA callback has ALREADY swapped the EMA weights in for validation (ema.py:83-100) and
     # the callback's own `swap_ema_weights` (callbacks.py:110-113) swaps back, so this sample runs on the training weights
     model.eval()
-    assert cb.network_dtype == "f32" and model.denoiser.eval_dtype == "bf16"   # the callback samples in fp32 (the reference's
-    model.denoiser.set_eval_dtype("f32")                                        # precision) and restores the module's setting
+    assert cb.network_dtype == "f32x3" and model.denoiser.eval_dtype == "bf16"  # the callback samples at fp32 accuracy (the
+    model.denoiser.set_eval_dtype("f32x3")                                       # reference's) and restores the module's setting
     with torch.no_grad():
         xT = T.DeterministicSolver(num_steps=3).solve(model, cb.x0, cb.class_labels)
         with model.swap_ema_weights(tr):

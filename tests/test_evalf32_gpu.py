@@ -204,6 +204,15 @@ def test_heun_32_step_trajectory_f32_vs_fp32_oracle():
     e = rel(x_hip, x_or)
     record("evalf32/heun32_trajectory_vs_fp32_oracle", e, 2e-4)
     assert e <= 2e-4, e
+    # the split-bf16 back end ("f32x3": the DEFAULT of generate / the sampling callbacks since round 4) against the same
+    # oracle trajectory: limit 1e-4 (a TF32-conv oracle sits at 1.8e-4)
+    model.denoiser.set_eval_dtype("f32x3")
+    with torch.no_grad():
+        x_s = solver.solve(model, x0.to(DEV), None).cpu()
+    model.denoiser.set_eval_dtype("f32")
+    es = rel(x_s, x_or)
+    record("evalf32/heun32_trajectory_f32x3_vs_fp32_oracle", es, 1e-4)
+    assert es <= 1e-4, es
     if _runtime_env.GRAPH_REPLAY_SAFE:
         with torch.no_grad():
             x_g = solver.solve(model, x0.to(DEV), None, graph=True).cpu()
@@ -217,3 +226,79 @@ def test_heun_32_step_trajectory_f32_vs_fp32_oracle():
         model.denoiser.set_eval_dtype("f32")
         with torch.no_grad():
             assert torch.equal(solver.solve(model, x0.to(DEV), None, graph=True).cpu(), x_g)
+
+
+# ---------------------------------------------------------------------------------------------- split-bf16 ("f32x3")
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k", [
+    (2, 8, 8, 64, 64, 3), (3, 16, 16, 128, 192, 3), (5, 7, 7, 64, 72, 3), (2, 14, 14, 32, 64, 3),     # k_conv_igemm
+    (4, 16, 16, 256, 768, 1), (3, 5, 7, 96, 72, 1), (16, 8, 8, 512, 256, 1),
+    (128, 32, 32, 256, 256, 3), (64, 32, 32, 512, 256, 3), (128, 16, 16, 256, 256, 3), (32, 64, 64, 64, 128, 3)])  # k_conv3x3_v6
+@pytest.mark.parametrize("res", [False, True])
+def test_split_conv_vs_fp64(ops, B, H, W, Cin, Cout, k, res):
+    """ops.split_conv (hi/lo bf16 pairs, three MFMA passes, fp32 out) against an fp64 convolution of the fp32 operands:
+    2^-17 per operand -> a few 1e-6 on the sum (limit 1e-5; the exact f32-MFMA kernel is at 2e-6, one bf16 pass at 3e-3)"""
+    g = torch.Generator().manual_seed(B * 100 + H + Cin + Cout + k)
+    sel = list(range(B)) if B <= 8 else [0, B // 2 - 1, B // 2, B - 1]
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    r = torch.randn(B, Cout, H, W, generator=g) if res else None
+    ref = 0.8 * F.conv2d(x[sel].double(), w.double(), padding=k // 2)
+    if res:
+        ref = ref + 0.6 * r[sel].double()
+    pk = ops.split_pack(w.reshape(Cout, -1).contiguous().to(DEV), k * k)
+    y = ops.split_conv(ops.f32_to_pairs(nhwc(x)), pk, k * k, residual=None if r is None else nhwc(r), alpha=0.8,
+                       beta=0.6 if res else 0.0)
+    e = rel(nchw(y)[sel], ref)
+    record(f"evalf32/split_conv[{B}x{H}x{W} {Cin}->{Cout} k{k}{' +R' if res else ''}]", e, 1e-5)
+    assert e <= 1e-5, e
+
+
+def test_split_conv_modulation_epilogue(ops):
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Cin, Cout = 3, 16, 16, 64, 128
+    lin_all = torch.randn(B, Cout + 24, generator=g).to(DEV)
+    lin = lin_all[:, 8:8 + Cout]
+    gain = torch.tensor(0.7, device=DEV)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / 24
+    y = ops.split_conv(ops.f32_to_pairs(nhwc(x)), ops.split_pack(w.reshape(Cout, -1).contiguous().to(DEV), 9), 9, lin=lin,
+                       gain=gain)
+    yx = ops.f32_conv(nhwc(x), w.reshape(Cout, -1).contiguous().to(DEV), 9, lin=lin, gain=gain)
+    assert rel(y, yx) <= 1e-5
+
+
+def test_cifar10_forward_and_trajectory_f32x3():
+    """set_eval_dtype("f32x3"): the 35.6 M-parameter net through the split-bf16 convs against the FP32 oracle (forward,
+    limit 1e-4 like the exact path) and the 32-step Heun trajectory against the exact-fp32 path of this library from the
+    same x0 (limit 1e-4; the oracle-vs-exact figure is 3e-7, a TF32-conv oracle sits at 1.8e-4), eager == hipGraph replay"""
+    import tinyedm_amd as T
+    from tinyedm_amd import _runtime_env
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ecfg, dcfg = O.cifar10_cfg()
+    P = O.init_params(ecfg, dcfg, torch.Generator().manual_seed(31), gains_nonzero=True)
+    model = _cifar(P, ecfg, dcfg, "f32x3")
+    g = torch.Generator().manual_seed(8)
+    B = 4
+    noisy = torch.randn(B, 3, 32, 32, generator=g) * 1.3
+    sigma = torch.exp(torch.randn(B, generator=g) * 1.2 - 1.2)
+    with torch.no_grad():
+        D = model(noisy.to(DEV), sigma.to(DEV), None)
+        D_or = O.edm_forward(P, ecfg, dcfg, noisy, sigma, None, bf16=False)
+    c_skip, _, _ = O.precond_scalars(sigma, dcfg.sigma_data)
+    base = c_skip * noisy
+    e = rel(D.cpu() - base, D_or - base)
+    record("evalf32/f32x3_uncond_forward_vs_fp32_oracle", e, 1e-4)
+    assert e <= 1e-4, e
+    x0 = torch.randn(2, 3, 32, 32, generator=g).to(DEV)
+    solver = T.DeterministicSolver(num_steps=32)
+    with torch.no_grad():
+        xs = solver.solve(model, x0, None).cpu()
+        model.denoiser.set_eval_dtype("f32")
+        xe = solver.solve(model, x0, None).cpu()
+        model.denoiser.set_eval_dtype("f32x3")
+    et = rel(xs, xe)
+    record("evalf32/f32x3_heun32_trajectory_vs_exact_f32_path", et, 1e-4)
+    assert et <= 1e-4, et
+    if _runtime_env.GRAPH_REPLAY_SAFE:
+        with torch.no_grad():
+            assert torch.equal(solver.solve(model, x0, None, graph=True).cpu(), xs)

@@ -310,7 +310,7 @@ def test_generate_cli_reference_precision(tmp_path):
     import numpy as np
     from PIL import Image
     outs = {}
-    for dt in ("bf16", "f32", "default"):
+    for dt in ("bf16", "f32", "f32x3", "default"):
         out = tmp_path / dt
         r = subprocess.run([sys.executable, "-m", "tinyedm.generate", "--config_name", "cifar10", "--output_dir", str(out),
                             "--num_samples", "6", "--image_size", "32", "--num_classes", "10", "--batch_size", "4",
@@ -320,6 +320,7 @@ def test_generate_cli_reference_precision(tmp_path):
         files = sorted(glob.glob(str(out / "*.png")), key=lambda f: int(os.path.basename(f)[:-4]))
         assert [os.path.basename(f) for f in files] == [f"{i}.png" for i in range(6)]
         outs[dt] = np.stack([np.asarray(Image.open(f)).astype(int) for f in files])
-    assert np.array_equal(outs["default"], outs["f32"])      # no flag = the reference's precision (round 4)
+    assert np.array_equal(outs["default"], outs["f32x3"])    # no flag = fp32-accurate evaluation (round 4), and it
+    assert np.abs(outs["f32x3"] - outs["f32"]).max() <= 1    # rounds to the exact-fp32 path's bytes (a grey level at most)
     d = np.abs(outs["bf16"] - outs["f32"])
     assert d.max() <= 3 and (d > 0).mean() < 0.2, (d.max(), (d > 0).mean())

@@ -95,6 +95,9 @@ SIGNATURES = {
     # eval_f32.hip (reference-precision evaluation path)
     "edm_f32_conv": [P, P, P, P, F, F, P, L, P, I, I, I, I, I, I, I, P],
     "edm_f32_attention": [P, P, I, I, I, I, P],
+    "edm_f32_to_pairs": [P, P, L, I, P],
+    "edm_split_pack": [P, P, I, I, I, I, P],
+    "edm_split_conv": [P, P, P, P, F, F, P, L, P, I, I, I, I, I, I, P],
     "edm_f32_pixelnorm_silu": [P, P, P, L, I, P],
     "edm_f32_silu": [P, P, L, P],
     "edm_f32_pool2": [P, P, I, I, I, I, P],

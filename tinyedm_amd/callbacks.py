@@ -62,11 +62,12 @@ class GenerateCallback:
     swapped in, denormalise to uint8 on the GPU and write a PNG mosaic (the reference logs it to wandb)."""
 
     def __init__(self, solver, img_shape: tuple[int, int, int], num_samples: int = 8, every_n_epochs=5,
-                 output_dir: str = "generated", network_dtype: str = "f32"):
+                 output_dir: str = "generated", network_dtype: str = "f32x3"):
         self.solver, self.num_samples, self.img_shape = solver, num_samples, tuple(img_shape)
         self.every_n_epochs, self.output_dir = every_n_epochs, Path(output_dir)
-        # the reference's callback samples outside Lightning's autocast context, i.e. in fp32 (callbacks.py:41-49): the
-        # default here too; "bf16" = the training path's kernels (fast mode)
+        # the reference's callback samples outside Lightning's autocast context, i.e. in fp32 (callbacks.py:41-49): the default
+        # here is fp32-accurate too ("f32x3": split-bf16 convs; "f32": exact fp32 products); "bf16" = the training path's
+        # kernels (fast mode)
         self.network_dtype = network_dtype
         self.class_labels, self.x0, self.last_grid = None, None, None
 
@@ -137,8 +138,8 @@ class LatentsGenerateCallback:
 
     def __init__(self, solver, img_shape: tuple[int, int, int], mean: tuple, std: tuple,
                  value_range: tuple[float, float] = (0, 1), num_samples_per_class: int = 8, num_classes=10,
-                 every_n_epochs=100, output_dir: str = "generated", network_dtype: str = "f32"):
-        self.network_dtype = network_dtype          # fp32 like the reference's callback (callbacks.py:95-104); "bf16" = fast mode
+                 every_n_epochs=100, output_dir: str = "generated", network_dtype: str = "f32x3"):
+        self.network_dtype = network_dtype          # fp32-accurate like the reference's callback (callbacks.py:95-104); "bf16" = fast mode
         self.solver, self.img_shape = solver, tuple(img_shape)
         self.num_samples_per_class, self.num_classes, self.every_n_epochs = num_samples_per_class, num_classes, every_n_epochs
         self.value_range, self.mean, self.std = tuple(value_range), mean, std

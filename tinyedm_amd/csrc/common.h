@@ -198,6 +198,11 @@ struct ModEpilogue {
   // mode 3 (plain epilogue, EPI 0): Y2 = mp_silu(Y), same addressing as Y
   int wfrag;              // (not an epilogue matter, but it travels with the launch): the weight pack is FRAGMENT-MAJOR
                           // (weights.hip; only k_conv3x3_s reads that layout -- every other kernel refuses it)
+  // ---- split-bf16 evaluation (mode 4, EPI 4): X rows are [hi | lo] bf16 pairs of an fp32 activation (row stride ldX
+  // elements = 2 C), the pack is [tap][co][3 C] = [w_hi | w_lo | w_hi], and K chunk c reads X channels of chunk
+  // (c < kwrap ? c : c - kwrap): hi.w_hi, hi.w_lo, lo.w_hi -- three bf16 passes, an fp32-accurate sum; Y and R are FLOATS
+  int ldX;                // 0 = Cin
+  int kwrap;              // 0 = off; chunks of 32 channels
 };
 constexpr uint32_t U_DROPPED = 0x7FFFu;   // the bf16 pattern of a dropped element in a marked U
 __device__ __forceinline__ void apply_dyn(ModEpilogue& m) {
@@ -486,4 +491,59 @@ __device__ __forceinline__ void store_tile_transposed16(const f32x4 (&acc)[2 * N
                    acc[i][2 * j + h][2], acc[i][2 * j + h][3], alpha, beta, R != nullptr);
       },
       stage, Y, R, mb0, Npix, cw0, Cout, mod, gmred);
+}
+
+// ---- fp32-out epilogues of the split-bf16 evaluation path (EPI 4; round 4, csrc/eval_f32.hip "split"): the accumulators
+// hold an fp32-accurate sum (three bf16 MFMA passes over hi/lo operand pairs), so the result leaves as FLOATS:
+//   Y = alpha * acc + beta * R          (R fp32, contiguous [pixels][Cout]; mp_add of networks.py:87-88), or
+//   Y = mp_silu(acc * (lin[b,:] * gain + 1))   when mod.lin is set (the block's modulation, networks.py:253-260; eval: no
+//                                               dropout) -- the exact functions, as k_conv_f32's epilogue.
+// Straight from the accumulator layout: a lane holds 4 consecutive channels of one pixel -> one 16-byte load / store per
+// block (64-byte row segments per instruction: an evaluation-path epilogue, not tuned).
+__device__ __forceinline__ void f32_out4(float* __restrict__ Y, const float* __restrict__ R, float alpha, float beta,
+                                         long px, long Npix, int co, int Cout, const ModEpilogue& mod, float gain,
+                                         float v0, float v1, float v2, float v3) {
+  if (px >= Npix || co >= Cout) return;
+  f32x4 v = {alpha * v0, alpha * v1, alpha * v2, alpha * v3};
+  const long e = px * Cout + co;
+  if (R) {
+    const f32x4 r = *reinterpret_cast<const f32x4*>(R + e);
+    v += beta * r;
+  }
+  if (mod.lin) {
+    const f32x4 l = *reinterpret_cast<const f32x4*>(mod.lin + (px / mod.HW) * mod.lin_stride + co);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = mp_silu_f(v[k] * (l[k] * gain + 1.0f));
+  }
+  *reinterpret_cast<f32x4*>(Y + e) = v;
+}
+// v_mfma_f32_32x32x16 accumulators (k_conv_igemm): rows = channels 32 i + 8 g + 4 lhi + r, columns = pixels 32 j + l31
+template <int NI, int NJ>
+__device__ __forceinline__ void store_tile_f32(const f32x16 (&acc)[NI][NJ], float* __restrict__ Y, const float* __restrict__ R,
+                                               float alpha, float beta, long mb0, long Npix, int cw0, int Cout,
+                                               const ModEpilogue& mod) {
+  const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
+  const float gain = mod.lin ? *mod.gain : 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        f32_out4(Y, R, alpha, beta, mb0 + 32 * j + l31, Npix, cw0 + 32 * i + 8 * g + 4 * lhi, Cout, mod, gain,
+                 acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+}
+// v_mfma_f32_16x16x32 accumulators (k_conv3x3_v6): rows = channels 16 i + 4 (lane >> 4) + r, columns = pixels 16 j + (lane & 15)
+template <int NI, int NJ>
+__device__ __forceinline__ void store_tile_f32_16(const f32x4 (&acc)[2 * NI][2 * NJ], float* __restrict__ Y,
+                                                  const float* __restrict__ R, float alpha, float beta, long mb0, long Npix,
+                                                  int cw0, int Cout, const ModEpilogue& mod) {
+  const int lane = threadIdx.x & 63, l15 = lane & 15, lq = lane >> 4;
+  const float gain = mod.lin ? *mod.gain : 0.f;
+#pragma unroll
+  for (int j = 0; j < 2 * NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < 2 * NI; ++i)
+      f32_out4(Y, R, alpha, beta, mb0 + 16 * j + l15, Npix, cw0 + 16 * i + 4 * lq, Cout, mod, gain, acc[i][j][0], acc[i][j][1],
+               acc[i][j][2], acc[i][j][3]);
 }

@@ -60,6 +60,35 @@ extern "C" int edm_conv_igemm_o(const void* X, const void* Wp, void* Y, long ldY
   }
 }
 
+// Split-bf16 convolution of the reference-precision evaluation path (round 4; csrc/eval_f32.hip "split"): an fp32-accurate
+// conv at the rate of the bf16 kernels / 3.  Xp: [pixels][2 C] bf16 = [hi | lo] pairs of the fp32 activation
+// (edm_f32_to_pairs), Wp3: [taps][Cout][3 C] bf16 = [w_hi | w_lo | w_hi] of the fp32 effective weight (edm_split_pack);
+// three MFMA passes hi.w_hi + hi.w_lo + lo.w_hi accumulate in fp32 (the dropped lo.w_lo term is 2^-18 of a product);
+// Y = alpha * conv + beta * R, or Y = mp_silu(conv * (lin[b,:] * gain + 1)) when lin is given -- Y, R FLOATS.
+// C % 32 == 0 (3x3 on the static-schedule kernel: C % 64 == 0, W <= 64; anything else on k_conv_igemm).
+extern "C" int edm_split_conv(const void* Xp, const void* Wp3, float* Y, const float* R, float alpha, float beta,
+                              const float* lin, long lin_stride, const float* gain, int B, int H, int W, int C, int Cout,
+                              int taps, hipStream_t st) {
+  EDM_REQUIRE(Xp && Wp3 && Y, "split_conv: null pointer");
+  EDM_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 32 == 0 && Cout > 0 && Cout % 8 == 0 && (taps == 1 || taps == 9),
+              "split_conv: bad args (C %% 32, Cout %% 8, taps 1 or 9)");
+  EDM_REQUIRE(!lin || (gain && lin_stride >= Cout), "split_conv: the modulation epilogue needs gain and lin_stride >= Cout");
+  ModEpilogue mod{};
+  mod.mode = 4;
+  mod.lin = lin;
+  mod.gain = gain;
+  mod.lin_stride = lin_stride;
+  mod.HW = H * W;
+  mod.ldX = 2 * C;
+  mod.kwrap = C / 32;
+  const int K = 3 * C;
+  if (taps == 9 && C % 64 == 0 && W <= 64 && edm_conv_tall_worthwhile((long)B * H * W, Cout)) {
+    const int rc = edm_conv_igemm_v6_ex(Xp, Wp3, Y, R, alpha, beta, B, H, W, K, Cout, 9, mod, st);
+    if (rc != EDM_ERR_UNSUPPORTED) return rc;
+  }
+  return edm_conv_igemm_v1_ex(Xp, Wp3, Y, R, alpha, beta, B, H, W, K, Cout, taps, mod, st);
+}
+
 // 3x3 conv with the fused embedding modulation epilogue (networks.py:253-260 / 317-324):
 //   u  = conv3x3(X, Wp)                               -> Y  (bf16; may be null when the caller does not need it: eval)
 //   a2 = dropout(mp_silu(u * (lin[b,:]*gain + 1)))     -> Y2 (bf16)   [same values as edm_mod_silu_drop_fwd on u]

@@ -86,6 +86,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nchunks = Cin / KC;
+  // split-bf16 evaluation (common.h, mode 4): X rows are [hi | lo] pairs of ldX elements; K chunk c reads X chunk
+  // (c < kwrap ? c : c - kwrap) (kwrap counted in chunks of KC channels here)
+  const long ldX = mod.ldX ? mod.ldX : Cin;
+  const int kwrapc = mod.kwrap ? mod.kwrap * 32 / KC : (1 << 30);
+  auto xchunk = [&](int c) { return c >= kwrapc ? c - kwrapc : c; };
   const int T = nchunks * TAPS;
   const int xchunks = xrows * CPR;
 
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ 
       const int row = q / CPR, kc = q % CPR;
       const long pix = (long)m0 - HALO + row;
       xreg[i] = (q < xchunks && pix >= 0 && pix < Npix)
-                    ? *reinterpret_cast<const bf16x8*>(X + pix * Cin + chunk * KC + kc * 8)
+                    ? *reinterpret_cast<const bf16x8*>(X + pix * ldX + xchunk(chunk) * KC + kc * 8)
                     : zero8;
     }
   };
@@ -177,6 +182,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ 
 
   // ---- epilogue: transposed through wave-private LDS (common.h: store_tile_transposed)
   __syncthreads();  // every wave is done with the staged tiles
+  if constexpr (EPI == 4)
+    store_tile_f32<2, NJ>(acc, reinterpret_cast<float*>(Y), reinterpret_cast<const float*>(R), alpha, beta,
+                          (long)m0 + wn * (32 * NJ), Npix, n0 + wm * 64, Cout, mod);
+  else
   store_tile_transposed<2, NJ, EPI>(acc, smem + (wm * 2 + wn) * (32 * (2 * 64 + 16)), Y, R, alpha, beta,
                                (long)m0 + wn * (32 * NJ), Npix, n0 + wm * 64, Cout, mod);
 }
@@ -205,7 +214,11 @@ int launch(const void* X, const void* Wp, void* Y, const void* R, float alpha, f
 #define LAUNCH9(KC, XL, NJ)                                                                                      \
   (mod.mode == 1   ? launch<9, KC, XL, NJ, 1>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod)          \
    : mod.mode == 2 ? launch<9, KC, XL, NJ, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod)          \
+   : mod.mode == 4 ? launch<9, KC, XL, NJ, 4>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod)          \
                    : launch<9, KC, XL, NJ, 0>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod))
+#define LAUNCH1(KC, XL, NJ)                                                                                      \
+  (mod.mode == 4 ? launch<1, KC, XL, NJ, 4>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod)            \
+                 : launch<1, KC, XL, NJ, 0>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod))
 
 }  // namespace
 
@@ -215,7 +228,7 @@ int edm_conv_igemm_v1_ex(const void* X, const void* Wp, void* Y, const void* R, 
                          int W, int Cin, int Cout, int taps, const ModEpilogue& mod, hipStream_t st) {
   EDM_REQUIRE(X && Wp && (Y || mod.Y2), "conv_igemm: null pointer");
   EDM_REQUIRE(!mod.wfrag, "conv_igemm: fragment-major weight packs are read by k_conv3x3_s only");
-  EDM_REQUIRE(mod.mode == 0 || mod.mode == 3 || taps == 9, "conv_igemm: the backward epilogues are 3x3 only");
+  EDM_REQUIRE(mod.mode == 0 || mod.mode == 3 || mod.mode == 4 || taps == 9, "conv_igemm: the backward epilogues are 3x3 only");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && (long)B * H * W < (1L << 31), "conv_igemm: bad B/H/W");
   EDM_REQUIRE(taps == 1 || taps == 9, "conv_igemm: taps must be 1 or 9 (got %d)", taps);
   EDM_REQUIRE(Cin > 0 && Cin % 32 == 0, "conv_igemm: Cin=%d must be a multiple of 32", Cin);
@@ -225,7 +238,7 @@ int edm_conv_igemm_v1_ex(const void* X, const void* Wp, void* Y, const void* R, 
   // small feature maps (fewer than ~1.5 tiles per CU at 128 pixels): halve the pixel tile to fill the chip
   const long tiles128 = (long)((Npix + 127) / 128) * ((Cout + 127) / 128);
   if (Cin % 64 == 0 && tiles128 < 384 && W <= 30) {
-    if (taps == 1) launch<1, 64, 2, 1>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod);
+    if (taps == 1) LAUNCH1(64, 2, 1);
     else LAUNCH9(64, 4, 1);   // (64 + 2*(W+1)) * 8 <= 1024 chunks
     EDM_CHECK_LAUNCH("conv_igemm");
     return EDM_OK;
@@ -233,12 +246,12 @@ int edm_conv_igemm_v1_ex(const void* X, const void* Wp, void* Y, const void* R, 
   const int xrows = 128 + (taps == 9 ? 2 * (W + 1) : 0);
   if (Cin % 64 == 0) {
     const int need = (xrows * 8 + 255) / 256;
-    if (taps == 1) launch<1, 64, 4>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod);
+    if (taps == 1) LAUNCH1(64, 4, 2);
     else if (need <= 7) LAUNCH9(64, 7, 2);
     else LAUNCH9(64, 9, 2);
   } else {
     const int need = (xrows * 4 + 255) / 256;
-    if (taps == 1) launch<1, 32, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod);
+    if (taps == 1) LAUNCH1(32, 2, 2);
     else if (need <= 4) LAUNCH9(32, 4, 2);
     else LAUNCH9(32, 5, 2);
   }

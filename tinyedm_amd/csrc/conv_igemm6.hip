@@ -146,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
     if (real) {
       long pix = (long)m0 - HALO + row;
       pix = pix < 0 ? 0 : (pix >= Npix ? Npix - 1 : pix);  // out-of-range rows only feed masked taps
-      xsrc[i] = reinterpret_cast<const char*>(X + pix * Cin + c * 8);
+      xsrc[i] = reinterpret_cast<const char*>(X + pix * (mod.ldX ? mod.ldX : Cin) + c * 8);
     } else {
       xsrc[i] = zeros + c * 16;
     }
@@ -213,6 +213,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
       for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
   const int nchunks = Cin / KC;  // even (host-checked)
+  // split-bf16 evaluation (mod.kwrap != 0): K chunk c reads the X channels of chunk (c < kwrap ? c : c - kwrap) -- X rows
+  // are [hi | lo] pairs, the pack [w_hi | w_lo | w_hi] (common.h)
+  const int kwrap = mod.kwrap ? mod.kwrap : (1 << 30);
 
   // ---- prologue: slab 0, then weight tiles 0..D-1 (issue order fixes the counted waits)
 #pragma unroll
@@ -306,9 +309,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
           dma16(ub + woff, Wb + ((u + D) % WRING) * WTILE + wave * (WROWS * ROWB));
         }
         if (tap == 0 && more_chunks) {
+          const int xc_next = chunk + 1 >= kwrap ? chunk + 1 - kwrap : chunk + 1;
 #pragma unroll
           for (int i = 0; i < NX; ++i)
-            dma16(xsrc[i] + (long)(chunk + 1) * (KC * 2), Xb + (cpar ^ 1) * XBYTES + (wave + 8 * i) * 1024);
+            dma16(xsrc[i] + (long)xc_next * (KC * 2), Xb + (cpar ^ 1) * XBYTES + (wave + 8 * i) * 1024);
         }
       };
       if (!late) issue_dma();
@@ -391,6 +395,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
         atomicAdd(mod.gm + cur * gstride + n0 + tid, sum);
       }
     }
+  } else if constexpr (EPI == 4) {
+    store_tile_f32_16<NI, NJ>(acc, reinterpret_cast<float*>(Y), reinterpret_cast<const float*>(R), alpha, beta,
+                              (long)m0 + wave * (32 * NJ), Npix, n0, Cout, mod);
   } else {
     store_tile_transposed16<NI, NJ, EPI>(acc, smem + wave * (32 * (NI * 64 + 16)), Y, R, alpha, beta,
                                          (long)m0 + wave * (32 * NJ), Npix, n0, Cout, mod);
@@ -452,6 +459,7 @@ int edm_conv_igemm_v6_ex(const void* X, const void* Wp, void* Y, const void* R, 
 #define L6(EPIV) (nx5 ? (wide ? L6A(EPIV, 4) : L6A(EPIV, 2)) : (wide ? L6B(EPIV, 4) : L6B(EPIV, 2)))
   if (mod.mode == 1) L6(1);
   else if (mod.mode == 2) L6(2);
+  else if (mod.mode == 4) L6(4);
   else L6(0);
 #undef L6
 #undef L6A

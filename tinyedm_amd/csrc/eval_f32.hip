@@ -527,6 +527,59 @@ __global__ void k_nhwc_to_nchw_f32(const float* __restrict__ x, float* __restric
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------ split-bf16 operands
+// An fp32 value as a PAIR of bf16: hi = bf16(x) (round to nearest even), lo = bf16(x - hi): x = hi + lo up to 2^-18 |x|.
+// Activations: [rows][C] floats -> [rows][2 C] bf16 = [hi | lo] (the same bytes).  Weights: w_hat [O][I * taps] (master
+// order) -> [taps][O][3 Ip] = [w_hi | w_lo | w_hi].  edm_split_conv (conv_dispatch.hip) multiplies them in three bf16 passes.
+namespace {
+__global__ void k_f32_to_pairs(const float* __restrict__ x, bf16* __restrict__ p, int C, long n8) {
+  const int CL = C >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / CL;
+    const int c8 = (int)(i % CL) * 8;
+    const f32x4 a = ld4(x + i * 8), b = ld4(x + i * 8 + 4);
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = j < 4 ? a[j] : b[j - 4];
+      const bf16 h = (bf16)v;
+      hi[j] = h;
+      lo[j] = (bf16)(v - (float)h);
+    }
+    *reinterpret_cast<bf16x8*>(p + row * 2 * C + c8) = hi;
+    *reinterpret_cast<bf16x8*>(p + row * 2 * C + C + c8) = lo;
+  }
+}
+__global__ void k_split_pack(const float* __restrict__ wh, bf16* __restrict__ pk, int O, int I, int taps, int Ip, long n) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(e % Ip);
+    const long to = e / Ip;
+    const int o = (int)(to % O), t = (int)(to / O);
+    const float v = i < I ? wh[((long)o * I + i) * taps + t] : 0.f;
+    const bf16 h = (bf16)v, l = (bf16)(v - (float)h);
+    bf16* row = pk + to * 3 * Ip;
+    row[i] = h;
+    row[Ip + i] = l;
+    row[2 * Ip + i] = h;
+  }
+}
+}  // namespace
+extern "C" int edm_f32_to_pairs(const float* x, void* pairs, long rows, int C, hipStream_t st) {
+  EDM_REQUIRE(x && pairs && rows > 0 && C > 0 && C % 8 == 0, "f32_to_pairs: bad args (C %% 8)");
+  const long n8 = rows * C / 8;
+  hipLaunchKernelGGL(k_f32_to_pairs, dim3(gridf(n8, 256)), dim3(256), 0, st, x, (bf16*)pairs, C, n8);
+  EDM_CHECK_LAUNCH("f32_to_pairs");
+  return EDM_OK;
+}
+// w_hat [O][I * taps] fp32 -> pack [taps][O][3 Ip] bf16, Ip >= I (channels I .. Ip-1 zero)
+extern "C" int edm_split_pack(const float* w_hat, void* pack, int O, int I, int taps, int Ip, hipStream_t st) {
+  EDM_REQUIRE(w_hat && pack && O > 0 && I > 0 && taps > 0 && Ip >= I, "split_pack: bad args");
+  const long n = (long)taps * O * Ip;
+  hipLaunchKernelGGL(k_split_pack, dim3(gridf(n, 256)), dim3(256), 0, st, w_hat, (bf16*)pack, O, I, taps, Ip, n);
+  EDM_CHECK_LAUNCH("split_pack");
+  return EDM_OK;
+}
+
 // X [B*H*W][Cin] fp32, w_hat [Cout][I*taps] fp32 (master OIHW order; I <= Cin: X may be zero-padded), Y / R [B*H*W][Cout].
 // lin != NULL: Y = mp_silu(conv * (lin[b,:]*gain + 1)) (alpha/beta/R ignored except alpha).  taps in {1, 9}; W <= 64.
 extern "C" int edm_f32_conv(const float* X, const float* w_hat, float* Y, const float* R, float alpha, float beta,

@@ -5,9 +5,12 @@ signature and the same command-line flags (`--ckpt_path --load_ema --output_dir 
     python -m tinyedm.generate --ckpt_path last.ckpt --load_ema --output_dir samples --num_samples 50000 \\
         --image_size 32 --num_classes 10 --batch_size 512
 
-Precision: the denoiser is evaluated in fp32 BY DEFAULT, as the reference does (generate.py:39-44: `L.Trainer(accelerator="gpu")`,
-i.e. 32-bit precision; exact-fp32 kernels, csrc/eval_f32.hip).  `--network_dtype bf16` is the opt-in fast mode: the training
-path's kernels, ~9x faster, 1.3e-3 from the fp32 trajectory.
+Precision: the denoiser is evaluated at fp32 accuracy BY DEFAULT, as the reference does (generate.py:39-44:
+`L.Trainer(accelerator="gpu")`, i.e. 32-bit precision).  `--network_dtype f32x3` (default): fp32 activations, every conv product
+as three bf16 MFMA passes over (hi, lo) operand pairs accumulated in fp32 -- 32-step trajectories 2e-6 from the exact-fp32 path
+and <= 1e-4 from the fp32 oracle (tests/test_evalf32_gpu.py), 158 img/s on the CIFAR-10 net; `f32`: exact fp32 products
+(the f32-input matrix instruction; the checker: 3e-7 from the oracle, 58 img/s); `bf16`: the opt-in fast mode, the training
+path's kernels, 540 img/s, 1.3e-3 from the fp32 trajectory.
 Extensions (all optional): `--network_dtype`,
 `--in_channels` (the reference's noise dataset hard-codes 3; default = the checkpoint's
 denoiser.in_channels), `--mean/--std` (default: the reference's CIFAR-10 constants), `--seed`, `--no_graph`, and
@@ -28,7 +31,7 @@ CIFAR_STD = (0.24703223, 0.24348513, 0.26158784)
 
 def generate(ckpt_path, load_ema, output_dir, num_samples, image_size, num_classes, batch_size, num_workers=16,
              num_steps=32, *, in_channels=None, mean=None, std=None, seed=0, graph=True, model=None,
-             network_dtype="f32") -> None:
+             network_dtype="f32x3") -> None:
     from .callbacks import PreditionWriter
     from .datamodules import RandomNoiseDataModule
     from .edm import EDM
@@ -79,8 +82,9 @@ def main(argv=None):
     parser.add_argument("--std", type=float, nargs="+", default=None)
     parser.add_argument("--seed", type=int, default=0)
     parser.add_argument("--no_graph", action="store_true", help="eager Heun loop instead of the captured hipGraph")
-    parser.add_argument("--network_dtype", choices=["bf16", "f32"], default="f32",
-                        help="denoiser evaluation precision: f32 (default) = the reference's (exact-fp32 kernels), bf16 = fast mode")
+    parser.add_argument("--network_dtype", choices=["bf16", "f32", "f32x3"], default="f32x3",
+                        help="denoiser evaluation precision: f32x3 (default) = fp32-accurate (split-bf16, 3 MFMA passes), "
+                             "f32 = exact fp32 products (checker, slower), bf16 = fast mode")
     parser.add_argument("--config_name", type=str, default=None,
                         help="sample from random-init weights of experiments/conf/<name>.yaml (no checkpoint)")
     parser.add_argument("--config_path", type=str, default=None)

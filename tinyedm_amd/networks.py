@@ -720,10 +720,10 @@ class CosineAttention(nn.Module):
 
     def forward_f32(self, x: Tensor) -> Tensor:
         """reference-precision evaluation (NHWC fp32 in / out): qkv conv in the master row order, exact-fp32 attention"""
-        qkv = ops.f32_conv(x, self.qkv_conv.packs()[2], 1)
+        qkv = _conv_f32(self.qkv_conv, x, 1)
         y = ops.f32_attention(qkv, self.num_heads)
         a, b = _mp_coeffs(0.5)
-        return ops.f32_conv(y, self.out_conv.packs()[2], 1, residual=x, alpha=b, beta=a)
+        return _conv_f32(self.out_conv, y, 1, residual=x, alpha=b, beta=a)
 
 
 class _AttnFn(torch.autograd.Function):
@@ -975,12 +975,31 @@ class _BlockBase(nn.Module):
         return (out, ualias) if alias else out
 
 
+# Reference-precision evaluation, two conv back ends (Denoiser.set_eval_dtype): "f32" = exact fp32 products on the
+# f32-input MFMA (csrc/eval_f32.hip k_conv_f32, 1/16 of the bf16 rate); "f32x3" (round 4) = split-bf16: activations and
+# weights as (hi, lo) bf16 pairs, three bf16 MFMA passes hi.w_hi + hi.w_lo + lo.w_hi accumulated in fp32 on the tuned bf16
+# kernels (ops.split_conv) -- 2^-17 per operand instead of exact, a third of the bf16 rate instead of a sixteenth.  Everything
+# between the convs (fp32 activations, elementwise kernels, attention) is shared.
+_SPLIT_EVAL = [False]
+
+
+def _conv_f32(mod: "_WNBase", x: Tensor, taps: int, **kw) -> Tensor:
+    w_hat = mod.packs()[2]
+    I = w_hat.shape[1] // taps
+    if _SPLIT_EVAL[0] and x.shape[-1] % 32 == 0 and I == x.shape[-1] and w_hat.shape[0] % 8 == 0:
+        key = (mod.weight.data_ptr(), mod.weight._version, _WEIGHT_EPOCH)
+        if getattr(mod, "_split_key", None) != key:
+            mod._split_pack, mod._split_key = ops.split_pack(w_hat, taps), key
+        return ops.split_conv(ops.f32_to_pairs(x), mod._split_pack, taps, **kw)
+    return ops.f32_conv(x, w_hat, taps, **kw)
+
+
 def _res_f32(blk, xres: Tensor, s: Tensor, lin: Tensor) -> Tensor:
     """the residual branch of a block in the reference-precision evaluation path: conv3x3 -> modulation + mp_silu (fused
     epilogue; eval: no dropout) -> conv3x3 + mp_add with the skip path (networks.py:253-263 / 317-327)"""
-    a2 = ops.f32_conv(s, blk.conv_3x3_1.packs()[2], 9, lin=lin, gain=blk.gain.detach())
+    a2 = _conv_f32(blk.conv_3x3_1, s, 9, lin=lin, gain=blk.gain.detach())
     a, b = _mp_coeffs(blk.add_factor)
-    out = ops.f32_conv(a2, blk.conv_3x3_2.packs()[2], 9, residual=xres, alpha=b, beta=a)
+    out = _conv_f32(blk.conv_3x3_2, a2, 9, residual=xres, alpha=b, beta=a)
     if isinstance(blk.attention, CosineAttention):
         out = blk.attention.forward_f32(out)
     return out
@@ -1035,7 +1054,7 @@ class EncoderBlock(_BlockBase):
         if isinstance(self.resample, DownSample):
             x = ops.f32_pool2(x)
         if isinstance(self.conv_1x1, Conv2d):
-            x = ops.f32_conv(x, self.conv_1x1.packs()[2], 1)
+            x = _conv_f32(self.conv_1x1, x, 1)
         xn, s = ops.f32_pixelnorm_silu(x)
         return _res_f32(self, xn, s, lin)
 
@@ -1090,7 +1109,7 @@ class DecoderBlock(_BlockBase):
         if isinstance(self.resample, UpSample):
             x = ops.f32_up2(x)
             s = None
-        xres = ops.f32_conv(x, self.conv_1x1.packs()[2], 1) if isinstance(self.conv_1x1, Conv2d) else x
+        xres = _conv_f32(self.conv_1x1, x, 1) if isinstance(self.conv_1x1, Conv2d) else x
         if s is None:
             s = ops.f32_silu(x)
         return _res_f32(self, xres, s, lin)
@@ -1389,11 +1408,12 @@ class Denoiser(nn.Module):
     eval_dtype = "bf16"
 
     def set_eval_dtype(self, dtype: str) -> "Denoiser":
-        """"bf16" (default: the training path's kernels) or "f32" (reference precision, ~10x slower)"""
-        dtype = {"float32": "f32", "fp32": "f32", "bfloat16": "bf16"}.get(str(dtype).replace("torch.", ""), str(dtype))
-        if dtype not in ("bf16", "f32"):
-            raise ValueError("Denoiser.set_eval_dtype: 'bf16' or 'f32'")
-        if dtype == "f32":          # every conv also keeps its fp32 effective weight ("hat") from now on
+        """"bf16" (default: the training path's kernels), "f32" (reference precision: exact fp32 products, ~9x slower) or
+        "f32x3" (reference precision to 2^-17 per operand: split-bf16 on the bf16 kernels, see _conv_f32)"""
+        dtype = {"float32": "f32", "fp32": "f32", "bfloat16": "bf16", "split": "f32x3"}.get(str(dtype).replace("torch.", ""), str(dtype))
+        if dtype not in ("bf16", "f32", "f32x3"):
+            raise ValueError("Denoiser.set_eval_dtype: 'bf16', 'f32' (exact fp32 products) or 'f32x3' (split-bf16, fp32-accurate)")
+        if dtype != "bf16":         # every conv also keeps its fp32 effective weight ("hat") from now on
             for m in self.modules():
                 if isinstance(m, _WNBase) and "hat" not in m._want:
                     m._want = tuple(m._want) + ("hat",)
@@ -1422,14 +1442,18 @@ class Denoiser(nn.Module):
     def forward(self, noisy_image: Tensor, sigma: Tensor, embedding: Tensor):
         if not noisy_image.is_cuda:
             raise RuntimeError("tinyedm_amd.Denoiser: inputs must be GPU tensors (there is no CPU path)")
-        if self.eval_dtype == "f32" and not self.training:
+        if self.eval_dtype != "bf16" and not self.training:
             if torch.is_grad_enabled() and (noisy_image.requires_grad or embedding.requires_grad):
                 raise RuntimeError("tinyedm_amd.Denoiser: the fp32 evaluation path is forward-only (use torch.no_grad())")
             with torch.no_grad():
                 self._prep_all()
                 noisy = noisy_image.float().contiguous()
-                D = self._forward_f32(noisy, sigma.detach().float().flatten().contiguous(),
-                                      _emb32(embedding.detach(), noisy.shape[0]))
+                _SPLIT_EVAL[0] = self.eval_dtype == "f32x3"
+                try:
+                    D = self._forward_f32(noisy, sigma.detach().float().flatten().contiguous(),
+                                          _emb32(embedding.detach(), noisy.shape[0]))
+                finally:
+                    _SPLIT_EVAL[0] = False
             return D.to(noisy_image.dtype)
         reset_backward_state()
         if torch.is_grad_enabled():      # eval-mode forwards with autograd on (fine-tuning, parity runs) write gradients too

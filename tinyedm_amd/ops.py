@@ -1154,6 +1154,49 @@ def f32_conv(x, w_hat, taps, residual=None, alpha=1.0, beta=0.0, lin=None, gain=
     return y
 
 
+def f32_to_pairs(x):
+    """(B,H,W,C) fp32 -> (B,H,W,2C) bf16 = [hi | lo], hi = bf16(x), lo = bf16(x - hi): the operand format of split_conv"""
+    B, H, W, C = _nhwc32(x, "x")
+    if C % 8:
+        raise ValueError("f32_to_pairs: C % 8 required")
+    p = torch.empty(B, H, W, 2 * C, device=x.device, dtype=bf16)
+    _lib.call("edm_f32_to_pairs", _p(x), _p(p), B * H * W, C, _stream())
+    return p
+
+
+def split_pack(w_hat, taps):
+    """w_hat (Cout, I*taps) fp32 -> (taps, Cout, 3*Ip) bf16 = [w_hi | w_lo | w_hi], Ip = I rounded up to 32"""
+    _chk(w_hat, f32, "w_hat")
+    Cout, I = w_hat.shape[0], w_hat.shape[1] // taps
+    Ip = (I + 31) // 32 * 32
+    pk = torch.empty(taps, Cout, 3 * Ip, device=w_hat.device, dtype=bf16)
+    _lib.call("edm_split_pack", _p(w_hat), _p(pk), Cout, I, taps, Ip, _stream())
+    return pk
+
+
+def split_conv(xp, pack3, taps, residual=None, alpha=1.0, beta=0.0, lin=None, gain=None):
+    """fp32-accurate conv in three bf16 MFMA passes: xp (B,H,W,2C) bf16 pairs (f32_to_pairs), pack3 (taps,Cout,3C) bf16
+    (split_pack) -> (B,H,W,Cout) fp32 = alpha*conv + beta*residual, or with lin/gain mp_silu(alpha*conv*(lin*gain+1))"""
+    B, H, W, C2 = _nhwc(xp, "xp")
+    C = C2 // 2
+    _chk(pack3, bf16, "pack3")
+    if pack3.dim() != 3 or pack3.shape[0] != taps or pack3.shape[2] != 3 * C or C % 32:
+        raise ValueError(f"split_conv: pack {tuple(pack3.shape)} does not match taps={taps}, C={C} (C % 32 required)")
+    Cout = pack3.shape[1]
+    if residual is not None:
+        _chk(residual, f32, "residual", (B, H, W, Cout))
+    ls = 0
+    if lin is not None:
+        ls = _lin_view(lin, B, Cout, "lin")
+        _chk(gain, f32, "gain")
+    y = torch.empty(B, H, W, Cout, device=xp.device, dtype=f32)
+    with _prof("split_conv3x3" if taps == 9 else "split_conv1x1", 2.0 * B * H * W * C * Cout * taps,
+               4.0 * B * H * W * (C + Cout * (2 if residual is not None else 1)) + 2.0 * pack3.numel()):
+        _lib.call("edm_split_conv", _p(xp), _p(pack3), _p(y), _p(residual), float(alpha), float(beta), _p(lin), ls, _p(gain),
+                  B, H, W, C, Cout, taps, _stream())
+    return y
+
+
 def f32_attention(qkv, heads):
     B, H, W, C3 = _nhwc32(qkv, "qkv")
     C = C3 // 3
