@@ -48,13 +48,11 @@ int edm_conv_igemm(const void* X, const void* Wp, void* Y, const void* R, float 
  * it does not cover. */
 int edm_conv_igemm_v2(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
                       int W, int Cin, int Cout, int taps, edm_stream_t stream);
-/* third-generation kernel, same contract (512x128 "tall" tile, 128x64 per wave); -3 for shapes it does not cover */
-int edm_conv_igemm_v3(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
-                      int W, int Cin, int Cout, int taps, edm_stream_t stream);
 /* the 3x3 kernel of the 32x32 / 16x16 layers ("static schedule": 512 pixels x 128 or 64 channels per workgroup, the
  * (tap, 2 channel-chunk) loop unrolled 18x, per-lane fragment addresses computed once, counted waits) on
  * v_mfma_f32_16x16x32_bf16; -3 for shapes it does not cover (taps != 9, Cin % 64 != 0, W > 64).  (Its 32x32x16
- * predecessor edm_conv_igemm_v4 was retired in round 4: no dispatch reached it.) */
+ * predecessor edm_conv_igemm_v4 and the tall-tile edm_conv_igemm_v3 were retired in round 4: no dispatch reached the
+ * first, and the second ran one launch per step -- conv_in -- 10 us slower than edm_conv_igemm.) */
 int edm_conv_igemm_v6(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
                       int W, int Cin, int Cout, int taps, edm_stream_t stream);
 /* small feature maps (8x8 layers; W <= 16, Cin % 256 == 0), 3x3 only: 128x64 tile whose reduction dimension is split

@@ -8,9 +8,6 @@
 extern "C" {
 #endif
 
-/* diagnostic : in-kernel shader clock of the v3 kernel (dbg[0] cycles, dbg[1] 100 MHz ticks, dbg[2] WGs) */
-int edm_conv_igemm_v3_clock(const void* X, const void* Wp, void* Y, int B, int H, int W, int Cin, int Cout,
-                            unsigned long long* dbg, edm_stream_t stream);
 /* diagnostic : s_memtime stamps per loop segment of the v2 kernel, summed over waves into dbg[0..5] */
 int edm_conv_igemm_v2_stamp(const void* X, const void* Wp, void* Y, int B, int H, int W, int Cin, int Cout,
                             unsigned long long* dbg, edm_stream_t stream);

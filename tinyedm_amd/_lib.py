@@ -47,7 +47,6 @@ SIGNATURES = {
     # conv_igemm.hip / conv_wgrad.hip
     "edm_conv_igemm": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_v2": [P, P, P, P, F, F, I, I, I, I, I, I, P],
-    "edm_conv_igemm_v3": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_o": [P, P, P, L, P, P, L, I, P, F, F, I, I, I, I, I, I, I, I, P],
     "edm_conv_igemm_v6": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_s": [P, P, P, P, F, F, I, I, I, I, I, I, P],
@@ -115,7 +114,6 @@ SIGNATURES = {
 }
 # include/tinyedm_hip_diag.h: tools-only entry points, bound on demand by call()
 DIAG_SIGNATURES = {
-    "edm_conv_igemm_v3_clock": [P, P, P, I, I, I, I, I, P, P],
     "edm_conv_igemm_v2_stamp": [P, P, P, I, I, I, I, I, P, P],
     "edm_conv_igemm_v2_ablate": [P, P, P, I, I, I, I, I, I, P],
 }

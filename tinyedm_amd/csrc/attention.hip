@@ -113,7 +113,13 @@ __global__ __launch_bounds__(attn_threads<NT>()) void k_attn_fwd(const bf16* __r
   stage_normalised<false, 3, NP, attn_threads<NT>()>(src, 3L * C, Qn, N, nullptr);
   __syncthreads();
 
-  const float scale = 0.125f;  // 1/sqrt(64)
+  // The softmax is the vector-ALU bill of this kernel (128 scores per lane against 64 MFMAs per wave, two waves per SIMD):
+  // round 4 cut it from ~9 to ~4 instructions per score -- the 1/sqrt(d) scale and log2(e) ride in ONE fma in front of
+  // v_exp_f32 (the max is taken on the raw scores), the key mask is compiled out when every tile is full (N = 32 NT: the
+  // 16x16 and 8x8 maps), and the 1/sum normalisation is applied to the 32 output values instead of the 128 probabilities
+  // (the probabilities go to the second MFMA unnormalised, in (0, 1]: the same relative bf16 rounding).
+  const float sl2 = 0.125f * 1.44269504088896341f;  // 1/sqrt(64) * log2(e)
+  const bool full = N == NT * 32;
   // transposing-read geometry for V^T fragments
   const int tr_row = (lane & 15) >> 2;
   const int tr_col = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
@@ -129,19 +135,21 @@ __global__ __launch_bounds__(attn_threads<NT>()) void k_attn_fwd(const bf16* __r
       St[kt] = score_tile(Kn + (kt * 32 + l31) * RS + lhi * 16, bq);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        float s = key < N ? St[kt][r] * scale : -1e30f;
-        St[kt][r] = s;
-        m = fmaxf(m, s);
+        if (!full) {
+          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          St[kt][r] = key < N ? St[kt][r] : -1e30f;
+        }
+        m = fmaxf(m, St[kt][r]);
       }
     }
     m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float mb = m * sl2;
     float l = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float p = __expf(St[kt][r] - m);
+        float p = __builtin_amdgcn_exp2f(fmaf(St[kt][r], sl2, -mb));
         St[kt][r] = p;
         l += p;
       }
@@ -154,8 +162,6 @@ __global__ __launch_bounds__(attn_threads<NT>()) void k_attn_fwd(const bf16* __r
       for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) St[kt][r] *= linv;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 pb = pack8(St[kt], s2);
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(attn_threads<NT>()) void k_attn_fwd(const bf16* __r
         for (int g = 0; g < 4; ++g) {
           bf16x4 o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (bf16)acc[dt][4 * g + r];
+          for (int r = 0; r < 4; ++r) o[r] = (bf16)(acc[dt][4 * g + r] * linv);
           *reinterpret_cast<bf16x4*>(dst + dt * 32 + 8 * g + 4 * lhi) = o;
         }
     }
@@ -266,6 +272,8 @@ __global__ __launch_bounds__(attn_threads<NT>()) void k_attn_bwd(const bf16* __r
   __syncthreads();
 
   const float scale = 0.125f;
+  const float sl2 = 0.125f * 1.44269504088896341f;  // scale * log2(e): see k_attn_fwd
+  const bool full = N == NT * 32;
   const int tr_row = (lane & 15) >> 2;
   const int tr_col = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 
@@ -285,29 +293,32 @@ __global__ __launch_bounds__(attn_threads<NT>()) void k_attn_bwd(const bf16* __r
       St[kt] = score_tile(Kn + (kt * 32 + l31) * RS + lhi * 16, bq);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        float s = key < N ? St[kt][r] * scale : -1e30f;
-        St[kt][r] = s;
-        m = fmaxf(m, s);
+        if (!full) {
+          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          St[kt][r] = key < N ? St[kt][r] : -1e30f;
+        }
+        m = fmaxf(m, St[kt][r]);
       }
     }
     m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float mb = m * sl2;
     float l = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float p = __expf(St[kt][r] - m);
+        float p = __builtin_amdgcn_exp2f(fmaf(St[kt][r], sl2, -mb));
         St[kt][r] = p;
         l += p;
       }
     l += __shfl_xor(l, 32, 64);
     const float linv = (qi < N) ? 1.0f / l : 0.f;
     if (lhi == 0) {
-      st_m[qi] = m;
+      st_m[qi] = mb;          // (the row maximum times scale * log2(e): pass 2 feeds it to the same fma)
       st_l[qi] = linv;
     }
     const float delta = st_d[qi];
+    const float ls = linv * scale;
     f32x16 accq[D / 32];
 #pragma unroll
     for (int dt = 0; dt < D / 32; ++dt)
@@ -317,7 +328,7 @@ __global__ __launch_bounds__(attn_threads<NT>()) void k_attn_bwd(const bf16* __r
     for (int kt = 0; kt < NT; ++kt) {
       f32x16 dP = score_tile(Vn + (kt * 32 + l31) * RS + lhi * 16, bdo);  // dP^T tile: keys x queries
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dP[r] = St[kt][r] * linv * (dP[r] - delta) * scale;
+      for (int r = 0; r < 16; ++r) dP[r] = St[kt][r] * ls * (dP[r] - delta);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 ds = pack8(dP, s2);
@@ -364,9 +375,10 @@ __global__ __launch_bounds__(attn_threads<NT>()) void k_attn_bwd(const bf16* __r
         const f32x4 dd = *reinterpret_cast<const f32x4*>(st_d + q0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float p = (ki < N) ? __expf(S[4 * g + r] * scale - mm[r]) * ll[r] : 0.f;
+          float p = __builtin_amdgcn_exp2f(fmaf(S[4 * g + r], sl2, -mm[r])) * ll[r];
+          if (!full) p = (ki < N) ? p : 0.f;
           S[4 * g + r] = p;
-          dP[4 * g + r] = p * (dP[4 * g + r] - dd[r]) * scale;
+          dP[4 * g + r] = p * scale * (dP[4 * g + r] - dd[r]);
         }
       }
 #pragma unroll

@@ -524,7 +524,7 @@ def nhwc_bf16_to_nchw(x):
 
 
 # ------------------------------------------------------------------ convolution
-# 0 = pick per shape (default), 1 = register-staged 128x128 kernel, 2 = LDS-DMA 256x128 kernel, 3 = tall 512x128 tile,
+# 0 = pick per shape (default), 1 = register-staged 128x128 kernel, 2 = LDS-DMA 256x128 kernel,
 # 5 = small-map split-K kernel, 6 = static-schedule 3x3 kernel (tests force each generation through this variable)
 IGEMM_VERSION = int(os.environ.get("EDM_IGEMM", "0"))
 
@@ -536,8 +536,6 @@ def _igemm_entry(npix, W, Cout, taps, Cin=0):
         return "edm_conv_igemm"
     if IGEMM_VERSION == 2:
         return "edm_conv_igemm_v2"
-    if IGEMM_VERSION == 3:
-        return "edm_conv_igemm_v3"
     if IGEMM_VERSION == 6:
         ok = taps == 9 and Cin % 64 == 0 and Cin <= 2016 and W <= 64
         return "edm_conv_igemm_v6" if ok else "edm_conv_igemm"
@@ -550,7 +548,8 @@ def _igemm_entry(npix, W, Cout, taps, Cin=0):
         tiles3 = tm * ((Cout + 127) // 128)
         v6_ok = Cin % 64 == 0 and Cin <= 2016 and W <= 64
         if tiles3 >= 512:
-            return "edm_conv_igemm_v6" if v6_ok else "edm_conv_igemm_v3"
+            return "edm_conv_igemm_v6" if v6_ok else "edm_conv_igemm"    # (conv_in, Cin = 32: 37 us there; the tall-tile
+                                                                             #  k_conv_igemm3 it used to take needed 47 and was retired)
         if v6_ok and tm * ((Cout + 63) // 64) >= 256:     # 512x64 tiles of the same kernel (16x16 layers at batch 128)
             return "edm_conv_igemm_v6"
         ts = ((npix + 127) // 128) * ((Cout + 63) // 64)
