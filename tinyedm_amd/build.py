@@ -52,11 +52,16 @@ def build(verbose: bool = True, force: bool = False) -> str:
     stale = [o for o in os.listdir(OBJ) if o.endswith(".o") and os.path.join(OBJ, o) not in objs]
     for o in stale:                     # object of a source that no longer exists: drop it and relink
         os.remove(os.path.join(OBJ, o))
-    if jobs or stale or not os.path.exists(LIB):
+    manifest = os.path.join(OBJ, "link_manifest.txt")     # the object list the library was last linked from
+    linked = open(manifest).read().split() if os.path.exists(manifest) else None
+    names = [os.path.basename(o) for o in objs]
+    if jobs or stale or not os.path.exists(LIB) or linked != names:
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
+        with open(manifest, "w") as f:
+            f.write("\n".join(names))
         if verbose:
             print(f"[build] linked {LIB}", flush=True)
     return LIB
