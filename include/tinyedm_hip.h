@@ -310,23 +310,27 @@ int edm_f32_conv(const float* X, const float* w_hat, float* Y, const float* R, f
  * edm_f32_to_pairs turns [rows][C] floats into [rows][2 C] bf16 = [hi | lo]; edm_split_pack turns w_hat [O][I*taps] into
  * [taps][O][3 Ip] bf16 = [w_hi | w_lo | w_hi]; edm_split_conv accumulates hi.w_hi + hi.w_lo + lo.w_hi in fp32 (what is
  * dropped, lo.w_lo, is 2^-18 of a product) and writes FLOATS: Y = alpha*conv + beta*R (R floats), or, with lin,
- * Y = mp_silu(conv * (lin[b,:]*gain + 1)).  C % 32 == 0, Cout % 8 == 0, taps in {1, 9}. */
+ * Y = mp_silu(conv * (lin[b,:]*gain + 1)); Ypairs (optional; Y may then be NULL) receives the same result as pairs, the
+ * next conv's Xp.  C % 32 == 0, Cout % 8 == 0, taps in {1, 9}. */
 int edm_f32_to_pairs(const float* x, void* pairs, long rows, int C, edm_stream_t stream);
 int edm_split_pack(const float* w_hat, void* pack, int O, int I, int taps, int Ip, edm_stream_t stream);
-int edm_split_conv(const void* Xp, const void* Wp3, float* Y, const float* R, float alpha, float beta, const float* lin,
-                   long lin_stride, const float* gain, int B, int H, int W, int C, int Cout, int taps, edm_stream_t stream);
+int edm_split_conv(const void* Xp, const void* Wp3, float* Y, void* Ypairs, const float* R, float alpha, float beta,
+                   const float* lin, long lin_stride, const float* gain, int B, int H, int W, int C, int Cout, int taps,
+                   edm_stream_t stream);
 /* cosine attention (networks.py:194-202) on the qkv conv's own output order: channel head*3d + 3*dd + {q,k,v};
  * y [B*N][C] with channel head*d + dd.  head_dim in {32, 64, 128, 144, 192}; any number of tokens (key tiles of 64). */
 int edm_f32_attention(const float* qkv, float* y, int B, int N, int C, int heads, edm_stream_t stream);
-int edm_f32_pixelnorm_silu(const float* x, float* xn, float* s, long P, int C, edm_stream_t stream);
-int edm_f32_silu(const float* x, float* s, long n, edm_stream_t stream);
+/* (s_pairs / pairs_row / pairs != 0 in the three entry points below: the mp_silu / concat outputs are written as split-bf16
+ * PAIRS -- rows [hi(C) | lo(C)] of bf16 in the same bytes -- ready to be edm_split_conv's Xp) */
+int edm_f32_pixelnorm_silu(const float* x, float* xn, float* s, long P, int C, int s_pairs, edm_stream_t stream);
+int edm_f32_silu(const float* x, float* s, long n, int pairs_row, edm_stream_t stream);
 int edm_f32_pool2(const float* x, float* y, int B, int Hout, int Wout, int C, edm_stream_t stream);
 int edm_f32_up2(const float* x, float* y, int B, int Hout, int Wout, int C, edm_stream_t stream);
 /* ScaleLong gate of a skip tensor (networks.py:112-118): mean over H*W in a fixed order + the gate MLP, per sample */
 int edm_f32_skip_gate(const float* skip, const float* W1h, const float* W2h, float* gate, int B, int HW, int C, int R,
                       edm_stream_t stream);
 int edm_f32_concat_gate(const float* inp, const float* skip, const float* gate, float* cat, float* silu_out, int B,
-                        int HW, int Ci, int Cs, edm_stream_t stream);
+                        int HW, int Ci, int Cs, int pairs, edm_stream_t stream);
 int edm_f32_precond_in(const float* noisy, const float* sigma, int sigma_stride, float sigma_data, float* out, int B,
                        int Cimg, int HW, int CP, edm_stream_t stream);
 int edm_f32_conv_out(const float* x, const float* w_hat, const float* gain_out, const float* noisy, const float* sigma,

@@ -96,13 +96,13 @@ SIGNATURES = {
     "edm_f32_attention": [P, P, I, I, I, I, P],
     "edm_f32_to_pairs": [P, P, L, I, P],
     "edm_split_pack": [P, P, I, I, I, I, P],
-    "edm_split_conv": [P, P, P, P, F, F, P, L, P, I, I, I, I, I, I, P],
-    "edm_f32_pixelnorm_silu": [P, P, P, L, I, P],
-    "edm_f32_silu": [P, P, L, P],
+    "edm_split_conv": [P, P, P, P, P, F, F, P, L, P, I, I, I, I, I, I, P],
+    "edm_f32_pixelnorm_silu": [P, P, P, L, I, I, P],
+    "edm_f32_silu": [P, P, L, I, P],
     "edm_f32_pool2": [P, P, I, I, I, I, P],
     "edm_f32_up2": [P, P, I, I, I, I, P],
     "edm_f32_skip_gate": [P, P, P, P, I, I, I, I, P],
-    "edm_f32_concat_gate": [P, P, P, P, P, I, I, I, I, P],
+    "edm_f32_concat_gate": [P, P, P, P, P, I, I, I, I, I, P],
     "edm_f32_precond_in": [P, P, I, F, P, I, I, I, I, P],
     "edm_f32_conv_out": [P, P, P, P, P, I, F, P, I, I, I, I, P],
     "edm_f32_nchw_to_nhwc": [P, P, I, I, I, P],

@@ -515,7 +515,17 @@ __device__ __forceinline__ void f32_out4(float* __restrict__ Y, const float* __r
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = mp_silu_f(v[k] * (l[k] * gain + 1.0f));
   }
-  *reinterpret_cast<f32x4*>(Y + e) = v;
+  if (Y) *reinterpret_cast<f32x4*>(Y + e) = v;
+  if (mod.Y2) {   // the same values as a (hi, lo) bf16 pair, rows [hi(Cout) | lo(Cout)]: the next conv's operand format
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hi[k] = (bf16)v[k];
+      lo[k] = (bf16)(v[k] - (float)hi[k]);
+    }
+    *reinterpret_cast<bf16x4*>(mod.Y2 + px * 2 * Cout + co) = hi;
+    *reinterpret_cast<bf16x4*>(mod.Y2 + px * 2 * Cout + Cout + co) = lo;
+  }
 }
 // v_mfma_f32_32x32x16 accumulators (k_conv_igemm): rows = channels 32 i + 8 g + 4 lhi + r, columns = pixels 32 j + l31
 template <int NI, int NJ>

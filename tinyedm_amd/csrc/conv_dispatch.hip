@@ -64,17 +64,19 @@ extern "C" int edm_conv_igemm_o(const void* X, const void* Wp, void* Y, long ldY
 // conv at the rate of the bf16 kernels / 3.  Xp: [pixels][2 C] bf16 = [hi | lo] pairs of the fp32 activation
 // (edm_f32_to_pairs), Wp3: [taps][Cout][3 C] bf16 = [w_hi | w_lo | w_hi] of the fp32 effective weight (edm_split_pack);
 // three MFMA passes hi.w_hi + hi.w_lo + lo.w_hi accumulate in fp32 (the dropped lo.w_lo term is 2^-18 of a product);
-// Y = alpha * conv + beta * R, or Y = mp_silu(conv * (lin[b,:] * gain + 1)) when lin is given -- Y, R FLOATS.
+// Y = alpha * conv + beta * R, or Y = mp_silu(conv * (lin[b,:] * gain + 1)) when lin is given -- Y, R FLOATS; Ypairs
+// (optional, Y may then be NULL): the same result as [pixels][2 Cout] bf16 pairs, ready to be the next conv's Xp.
 // C % 32 == 0 (3x3 on the static-schedule kernel: C % 64 == 0, W <= 64; anything else on k_conv_igemm).
-extern "C" int edm_split_conv(const void* Xp, const void* Wp3, float* Y, const float* R, float alpha, float beta,
+extern "C" int edm_split_conv(const void* Xp, const void* Wp3, float* Y, void* Ypairs, const float* R, float alpha, float beta,
                               const float* lin, long lin_stride, const float* gain, int B, int H, int W, int C, int Cout,
                               int taps, hipStream_t st) {
-  EDM_REQUIRE(Xp && Wp3 && Y, "split_conv: null pointer");
+  EDM_REQUIRE(Xp && Wp3 && (Y || Ypairs), "split_conv: null pointer");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 32 == 0 && Cout > 0 && Cout % 8 == 0 && (taps == 1 || taps == 9),
               "split_conv: bad args (C %% 32, Cout %% 8, taps 1 or 9)");
   EDM_REQUIRE(!lin || (gain && lin_stride >= Cout), "split_conv: the modulation epilogue needs gain and lin_stride >= Cout");
   ModEpilogue mod{};
   mod.mode = 4;
+  mod.Y2 = (bf16*)Ypairs;
   mod.lin = lin;
   mod.gain = gain;
   mod.lin_stride = lin_stride;

@@ -19,6 +19,17 @@ namespace {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+// the same four values as a (hi, lo) bf16 pair in a row [hi(C) | lo(C)] (split-bf16 operand format, see edm_f32_to_pairs)
+__device__ __forceinline__ void st4_pairs(bf16* row, int C, int c, const f32x4& v) {
+  bf16x4 hi, lo;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    hi[k] = (bf16)v[k];
+    lo[k] = (bf16)(v[k] - (float)hi[k]);
+  }
+  *reinterpret_cast<bf16x4*>(row + c) = hi;
+  *reinterpret_cast<bf16x4*>(row + C + c) = lo;
+}
 inline int cdivi(long a, long b) { return (int)((a + b - 1) / b); }
 inline int gridf(long work, int block, int cap = 256 * 16) {
   long g = (work + block - 1) / block;
@@ -335,7 +346,7 @@ __global__ __launch_bounds__(256) void k_attn_f32_g(const float* __restrict__ qk
 // ------------------------------------------------------------------------------------------------ elementwise
 // xn = x / (eps + |x| / sqrt(C)),  s = mp_silu(xn)        one wave per pixel
 __global__ __launch_bounds__(256) void k_pnorm_silu_f32(const float* __restrict__ x, float* __restrict__ xn,
-                                                          float* __restrict__ s, long P, int C) {
+                                                          float* __restrict__ s, long P, int C, int s_pairs) {
   const int lane = threadIdx.x & 63;
   for (long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6); p < P; p += (long)gridDim.x * 4) {
     const float* xr = x + p * C;
@@ -355,16 +366,22 @@ __global__ __launch_bounds__(256) void k_pnorm_silu_f32(const float* __restrict_
         a[e] = mp_silu_f(v[e]);
       }
       st4(xn + p * C + c, v);
-      st4(s + p * C + c, a);
+      if (s_pairs) st4_pairs(reinterpret_cast<bf16*>(s) + p * 2 * C, C, c, a);
+      else st4(s + p * C + c, a);
     }
   }
 }
-__global__ void k_silu_f32(const float* __restrict__ x, float* __restrict__ s, long n4) {
+__global__ void k_silu_f32(const float* __restrict__ x, float* __restrict__ s, long n4, int Cp) {   // Cp != 0: pairs out, rows of Cp
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     f32x4 v = ld4(x + i * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = mp_silu_f(v[e]);
-    st4(s + i * 4, v);
+    if (Cp) {
+      const long e0 = i * 4;
+      st4_pairs(reinterpret_cast<bf16*>(s) + (e0 / Cp) * 2 * Cp, Cp, (int)(e0 % Cp), v);
+    } else {
+      st4(s + i * 4, v);
+    }
   }
 }
 // y[b,h,w,:] = mean of the 2x2 block (H, W = output dims)
@@ -442,7 +459,7 @@ __global__ __launch_bounds__(1024) void k_skip_gate_f32(const float* __restrict_
 // cat = [inp, skip*gate[b]] ; sil = mp_silu(cat) (optional)
 __global__ void k_concat_gate_f32(const float* __restrict__ inp, const float* __restrict__ skip,
                                   const float* __restrict__ gate, float* __restrict__ cat, float* __restrict__ sil, int HW,
-                                  int Ci, int Cs, long n4) {
+                                  int Ci, int Cs, long n4, int pairs) {
   const int CLt = (Ci + Cs) >> 2, CLi = Ci >> 2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % CLt);
@@ -457,11 +474,14 @@ __global__ void k_concat_gate_f32(const float* __restrict__ inp, const float* __
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] *= gp[e];
     }
-    st4(cat + i * 4, v);
+    const int Ct = Ci + Cs;
+    if (pairs) st4_pairs(reinterpret_cast<bf16*>(cat) + pix * 2 * Ct, Ct, c4 * 4, v);
+    else st4(cat + i * 4, v);
     if (sil) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = mp_silu_f(v[e]);
-      st4(sil + i * 4, v);
+      if (pairs) st4_pairs(reinterpret_cast<bf16*>(sil) + pix * 2 * Ct, Ct, c4 * 4, v);
+      else st4(sil + i * 4, v);
     }
   }
 }
@@ -627,15 +647,15 @@ extern "C" int edm_f32_attention(const float* qkv, float* y, int B, int N, int C
   return EDM_OK;
 }
 
-extern "C" int edm_f32_pixelnorm_silu(const float* x, float* xn, float* s, long P, int C, hipStream_t st) {
+extern "C" int edm_f32_pixelnorm_silu(const float* x, float* xn, float* s, long P, int C, int s_pairs, hipStream_t st) {
   EDM_REQUIRE(x && xn && s && P > 0 && C > 0 && C % 4 == 0, "f32_pixelnorm_silu: bad args");
-  hipLaunchKernelGGL(k_pnorm_silu_f32, dim3(gridf(P, 4)), dim3(256), 0, st, x, xn, s, P, C);
+  hipLaunchKernelGGL(k_pnorm_silu_f32, dim3(gridf(P, 4)), dim3(256), 0, st, x, xn, s, P, C, s_pairs);
   EDM_CHECK_LAUNCH("f32_pixelnorm_silu");
   return EDM_OK;
 }
-extern "C" int edm_f32_silu(const float* x, float* s, long n, hipStream_t st) {
-  EDM_REQUIRE(x && s && n > 0 && n % 4 == 0, "f32_silu: bad args");
-  hipLaunchKernelGGL(k_silu_f32, dim3(gridf(n / 4, 256)), dim3(256), 0, st, x, s, n / 4);
+extern "C" int edm_f32_silu(const float* x, float* s, long n, int pairs_row, hipStream_t st) {
+  EDM_REQUIRE(x && s && n > 0 && n % 4 == 0 && (pairs_row == 0 || (pairs_row % 4 == 0 && n % pairs_row == 0)), "f32_silu: bad args");
+  hipLaunchKernelGGL(k_silu_f32, dim3(gridf(n / 4, 256)), dim3(256), 0, st, x, s, n / 4, pairs_row);
   EDM_CHECK_LAUNCH("f32_silu");
   return EDM_OK;
 }
@@ -667,12 +687,12 @@ extern "C" int edm_f32_skip_gate(const float* skip, const float* W1h, const floa
   return EDM_OK;
 }
 extern "C" int edm_f32_concat_gate(const float* inp, const float* skip, const float* gate, float* cat, float* silu_out,
-                                   int B, int HW, int Ci, int Cs, hipStream_t st) {
+                                   int B, int HW, int Ci, int Cs, int pairs, hipStream_t st) {
   EDM_REQUIRE(inp && skip && gate && cat && B > 0 && HW > 0 && Ci > 0 && Cs > 0 && Ci % 4 == 0 && Cs % 4 == 0,
               "f32_concat_gate: bad args");
   const long n4 = (long)B * HW * (Ci + Cs) / 4;
   hipLaunchKernelGGL(k_concat_gate_f32, dim3(gridf(n4, 256)), dim3(256), 0, st, inp, skip, gate, cat, silu_out, HW, Ci,
-                     Cs, n4);
+                     Cs, n4, pairs);
   EDM_CHECK_LAUNCH("f32_concat_gate");
   return EDM_OK;
 }

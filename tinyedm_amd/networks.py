@@ -983,21 +983,32 @@ class _BlockBase(nn.Module):
 _SPLIT_EVAL = [False]
 
 
-def _conv_f32(mod: "_WNBase", x: Tensor, taps: int, **kw) -> Tensor:
+def _split_ok(mod) -> bool:
+    """this conv runs on the split-bf16 back end in the current evaluation (so its input may arrive as pairs)"""
+    return bool(_SPLIT_EVAL[0]) and isinstance(mod, _WNBase) and mod.weight.shape[1] % 32 == 0 and mod.weight.shape[0] % 8 == 0
+
+
+def _conv_f32(mod: "_WNBase", x: Tensor, taps: int, pairs_out: bool = False, **kw) -> Tensor:
+    """x: fp32 NHWC, or -- split back end only -- bf16 (hi, lo) pairs written by the producer (ops.f32_pixelnorm_silu /
+    f32_silu / f32_concat_gate / split_conv with pairs=True).  pairs_out: hand the result on as pairs (split back end only)."""
     w_hat = mod.packs()[2]
-    I = w_hat.shape[1] // taps
-    if _SPLIT_EVAL[0] and x.shape[-1] % 32 == 0 and I == x.shape[-1] and w_hat.shape[0] % 8 == 0:
+    if _split_ok(mod):
         key = (mod.weight.data_ptr(), mod.weight._version, _WEIGHT_EPOCH)
         if getattr(mod, "_split_key", None) != key:
             mod._split_pack, mod._split_key = ops.split_pack(w_hat, taps), key
-        return ops.split_conv(ops.f32_to_pairs(x), mod._split_pack, taps, **kw)
+        xp = x if x.dtype == bf16 else ops.f32_to_pairs(x)
+        return ops.split_conv(xp, mod._split_pack, taps, pairs_out=pairs_out, **kw)
+    if x.dtype == bf16 or pairs_out:
+        raise RuntimeError("tinyedm_amd: split-bf16 pairs reached a conv that runs on the exact-fp32 kernel")
     return ops.f32_conv(x, w_hat, taps, **kw)
 
 
 def _res_f32(blk, xres: Tensor, s: Tensor, lin: Tensor) -> Tensor:
     """the residual branch of a block in the reference-precision evaluation path: conv3x3 -> modulation + mp_silu (fused
     epilogue; eval: no dropout) -> conv3x3 + mp_add with the skip path (networks.py:253-263 / 317-327)"""
-    a2 = _conv_f32(blk.conv_3x3_1, s, 9, lin=lin, gain=blk.gain.detach())
+    # (split back end: a2 only feeds conv2 -- it travels as pairs, written by conv1's epilogue)
+    a2 = _conv_f32(blk.conv_3x3_1, s, 9, lin=lin, gain=blk.gain.detach(),
+                   pairs_out=_split_ok(blk.conv_3x3_1) and _split_ok(blk.conv_3x3_2))
     a, b = _mp_coeffs(blk.add_factor)
     out = _conv_f32(blk.conv_3x3_2, a2, 9, residual=xres, alpha=b, beta=a)
     if isinstance(blk.attention, CosineAttention):
@@ -1055,7 +1066,7 @@ class EncoderBlock(_BlockBase):
             x = ops.f32_pool2(x)
         if isinstance(self.conv_1x1, Conv2d):
             x = _conv_f32(self.conv_1x1, x, 1)
-        xn, s = ops.f32_pixelnorm_silu(x)
+        xn, s = ops.f32_pixelnorm_silu(x, pairs=_split_ok(self.conv_3x3_1))
         return _res_f32(self, xn, s, lin)
 
 
@@ -1105,13 +1116,16 @@ class DecoderBlock(_BlockBase):
         if skip is not None:
             cf = self.cat_factor
             gate = ops.f32_skip_gate(skip, cf.layer1.packs()[2], cf.layer2.packs()[2])
-            x, s = ops.f32_concat_gate(x, skip, gate, not isinstance(self.resample, UpSample))
+            up = isinstance(self.resample, UpSample)
+            # (split back end, no upsample behind the concat: cat and mp_silu(cat) only feed convs -- pairs)
+            pairs = (not up) and isinstance(self.conv_1x1, Conv2d) and _split_ok(self.conv_1x1) and _split_ok(self.conv_3x3_1)
+            x, s = ops.f32_concat_gate(x, skip, gate, not up, pairs=pairs)
         if isinstance(self.resample, UpSample):
             x = ops.f32_up2(x)
             s = None
         xres = _conv_f32(self.conv_1x1, x, 1) if isinstance(self.conv_1x1, Conv2d) else x
         if s is None:
-            s = ops.f32_silu(x)
+            s = ops.f32_silu(x, pairs=_split_ok(self.conv_3x3_1))
         return _res_f32(self, xres, s, lin)
 
 

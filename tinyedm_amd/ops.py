@@ -1173,9 +1173,10 @@ def split_pack(w_hat, taps):
     return pk
 
 
-def split_conv(xp, pack3, taps, residual=None, alpha=1.0, beta=0.0, lin=None, gain=None):
+def split_conv(xp, pack3, taps, residual=None, alpha=1.0, beta=0.0, lin=None, gain=None, pairs_out=False):
     """fp32-accurate conv in three bf16 MFMA passes: xp (B,H,W,2C) bf16 pairs (f32_to_pairs), pack3 (taps,Cout,3C) bf16
-    (split_pack) -> (B,H,W,Cout) fp32 = alpha*conv + beta*residual, or with lin/gain mp_silu(alpha*conv*(lin*gain+1))"""
+    (split_pack) -> (B,H,W,Cout) fp32 = alpha*conv + beta*residual, or with lin/gain mp_silu(alpha*conv*(lin*gain+1));
+    pairs_out=True: the result comes back as (B,H,W,2Cout) bf16 pairs instead (it only feeds another split_conv)"""
     B, H, W, C2 = _nhwc(xp, "xp")
     C = C2 // 2
     _chk(pack3, bf16, "pack3")
@@ -1188,12 +1189,13 @@ def split_conv(xp, pack3, taps, residual=None, alpha=1.0, beta=0.0, lin=None, ga
     if lin is not None:
         ls = _lin_view(lin, B, Cout, "lin")
         _chk(gain, f32, "gain")
-    y = torch.empty(B, H, W, Cout, device=xp.device, dtype=f32)
+    y = None if pairs_out else torch.empty(B, H, W, Cout, device=xp.device, dtype=f32)
+    yp = torch.empty(B, H, W, 2 * Cout, device=xp.device, dtype=bf16) if pairs_out else None
     with _prof("split_conv3x3" if taps == 9 else "split_conv1x1", 2.0 * B * H * W * C * Cout * taps,
                4.0 * B * H * W * (C + Cout * (2 if residual is not None else 1)) + 2.0 * pack3.numel()):
-        _lib.call("edm_split_conv", _p(xp), _p(pack3), _p(y), _p(residual), float(alpha), float(beta), _p(lin), ls, _p(gain),
-                  B, H, W, C, Cout, taps, _stream())
-    return y
+        _lib.call("edm_split_conv", _p(xp), _p(pack3), _p(y), _p(yp), _p(residual), float(alpha), float(beta), _p(lin), ls,
+                  _p(gain), B, H, W, C, Cout, taps, _stream())
+    return yp if pairs_out else y
 
 
 def f32_attention(qkv, heads):
@@ -1206,17 +1208,20 @@ def f32_attention(qkv, heads):
     return y
 
 
-def f32_pixelnorm_silu(x):
+def f32_pixelnorm_silu(x, pairs=False):
+    """-> (xn fp32, s): s = mp_silu(xn) as fp32, or -- pairs=True -- as (B,H,W,2C) bf16 split pairs (split_conv's operand)"""
     B, H, W, C = _nhwc32(x, "x")
-    xn, s = torch.empty_like(x), torch.empty_like(x)
-    _lib.call("edm_f32_pixelnorm_silu", _p(x), _p(xn), _p(s), B * H * W, C, _stream())
+    xn = torch.empty_like(x)
+    s = torch.empty(B, H, W, 2 * C, device=x.device, dtype=bf16) if pairs else torch.empty_like(x)
+    _lib.call("edm_f32_pixelnorm_silu", _p(x), _p(xn), _p(s), B * H * W, C, int(bool(pairs)), _stream())
     return xn, s
 
 
-def f32_silu(x):
+def f32_silu(x, pairs=False):
     _chk(x, f32, "x")
-    s = torch.empty_like(x)
-    _lib.call("edm_f32_silu", _p(x), _p(s), x.numel(), _stream())
+    C = x.shape[-1]
+    s = torch.empty(*x.shape[:-1], 2 * C, device=x.device, dtype=bf16) if pairs else torch.empty_like(x)
+    _lib.call("edm_f32_silu", _p(x), _p(s), x.numel(), C if pairs else 0, _stream())
     return s
 
 
@@ -1246,15 +1251,20 @@ def f32_skip_gate(skip, w1h, w2h):
     return gate
 
 
-def f32_concat_gate(inp, skip, gate, want_silu):
+def f32_concat_gate(inp, skip, gate, want_silu, pairs=False):
+    """pairs=True: cat and sil come back as (B,H,W,2(Ci+Cs)) bf16 split pairs (they only feed convolutions)"""
     B, H, W, Ci = _nhwc32(inp, "inp")
     Bs, Hs, Ws, Cs = _nhwc32(skip, "skip")
     if (Bs, Hs, Ws) != (B, H, W):
         raise ValueError("f32_concat_gate: inp/skip spatial mismatch")
     _chk(gate, f32, "gate", (B, Cs))
-    cat = torch.empty(B, H, W, Ci + Cs, device=inp.device, dtype=f32)
+    if pairs:
+        cat = torch.empty(B, H, W, 2 * (Ci + Cs), device=inp.device, dtype=bf16)
+    else:
+        cat = torch.empty(B, H, W, Ci + Cs, device=inp.device, dtype=f32)
     sil = torch.empty_like(cat) if want_silu else None
-    _lib.call("edm_f32_concat_gate", _p(inp), _p(skip), _p(gate), _p(cat), _p(sil), B, H * W, Ci, Cs, _stream())
+    _lib.call("edm_f32_concat_gate", _p(inp), _p(skip), _p(gate), _p(cat), _p(sil), B, H * W, Ci, Cs, int(bool(pairs)),
+              _stream())
     return cat, sil
 
 
