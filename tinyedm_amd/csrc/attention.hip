@@ -408,22 +408,14 @@ size_t lds_bwd() { return (size_t)4 * NT * 32 * RS + (size_t)6 * NT * 32 * sizeo
 template <int NT>
 void launch_fwd(const void* qkv, void* y, int B, int N, int C, int heads, hipStream_t st) {
   auto kern = k_attn_fwd<NT>;
-  static std::atomic<bool> attr_set{false};  // (idempotent call: a race only repeats it)
-  if (!attr_set.load(std::memory_order_acquire)) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set.store(true, std::memory_order_release);
-  }
+  EDM_MAX_LDS(kern, 160 * 1024);
   hipLaunchKernelGGL(kern, dim3(B * heads), dim3(attn_threads<NT>()), lds_fwd<NT>(), st, (const bf16*)qkv, (bf16*)y, N, C, heads);
 }
 template <int NT>
 void launch_bwd(const void* qkv, const void* y, const void* gy, void* gqkv, int B, int N, int C, int heads,
                 hipStream_t st) {
   auto kern = k_attn_bwd<NT>;
-  static std::atomic<bool> attr_set{false};  // (idempotent call: a race only repeats it)
-  if (!attr_set.load(std::memory_order_acquire)) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set.store(true, std::memory_order_release);
-  }
+  EDM_MAX_LDS(kern, 160 * 1024);
   hipLaunchKernelGGL(kern, dim3(B * heads), dim3(attn_threads<NT>()), lds_bwd<NT>(), st, (const bf16*)qkv, (const bf16*)y,
                      (const bf16*)gy, (bf16*)gqkv, N, C, heads);
 }

@@ -469,11 +469,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_g(const bf16* __restrict__ qkv
 template <int D, int NT>
 void launch_fwd_g(const void* qkv, void* y, int B, int N, int C, int heads, hipStream_t st) {
   auto kern = k_attn_fwd_g<D, NT>;
-  static std::atomic<bool> attr_set{false};  // (idempotent call: a race only repeats it)
-  if (!attr_set.load(std::memory_order_acquire)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set.store(true, std::memory_order_release);
-  }
+  EDM_MAX_LDS(kern, 160 * 1024);
   const size_t lds = (size_t)TK * Geo<D>::RS + (size_t)3 * NT * 32 * sizeof(float);
   hipLaunchKernelGGL(kern, dim3(B * heads), dim3(256), lds, st, (const bf16*)qkv, (bf16*)y, N, C, heads);
 }
@@ -481,11 +477,7 @@ template <int D, int NT>
 void launch_bwd_g(const void* qkv, const void* y, const void* gy, void* gqkv, int B, int N, int C, int heads,
                   hipStream_t st) {
   auto kern = k_attn_bwd_g<D, NT>;
-  static std::atomic<bool> attr_set{false};  // (idempotent call: a race only repeats it)
-  if (!attr_set.load(std::memory_order_acquire)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set.store(true, std::memory_order_release);
-  }
+  EDM_MAX_LDS(kern, 160 * 1024);
   const size_t lds = (size_t)2 * TK * Geo<D>::RS + (size_t)6 * NT * 32 * sizeof(float);
   hipLaunchKernelGGL(kern, dim3(B * heads), dim3(256), lds, st, (const bf16*)qkv, (const bf16*)y, (const bf16*)gy,
                      (bf16*)gqkv, N, C, heads);

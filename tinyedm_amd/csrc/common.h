@@ -59,6 +59,24 @@ extern "C" const void* edm_zero_page(void);
     }                                                                                                                  \
   } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a property of (kernel, DEVICE): done once per device a process
+// drives (a bit per device id), not once per process (round 3 guarded it with one bool: fine for one process per GPU, wrong
+// for one process that launches on two).  Idempotent: a race only repeats the call.
+inline void edm_max_lds_once(const void* fn, int bytes, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.fetch_or(bit, std::memory_order_release);
+  }
+}
+#define EDM_MAX_LDS(kern, bytes)                                                   \
+  do {                                                                             \
+    static std::atomic<unsigned long long> done_{0};                               \
+    edm_max_lds_once(reinterpret_cast<const void*>(kern), (bytes), done_);         \
+  } while (0)
+
 #define SILU_DIV 0.596f
 #define NORM_EPS 1e-4f
 

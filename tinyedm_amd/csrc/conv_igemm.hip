@@ -200,11 +200,7 @@ int launch(const void* X, const void* Wp, void* Y, const void* R, float alpha, f
   const size_t lds = ((xrows * Cfg<KC>::ROWB + 15) & ~15) + 2 * BN * Cfg<KC>::ROWB;
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
   auto kern = k_conv_igemm<TAPS, KC, XL, NJ, EPI>;
-  static std::atomic<bool> attr_set{false};  // (idempotent call: a race only repeats it)
-  if (!attr_set.load(std::memory_order_acquire)) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set.store(true, std::memory_order_release);
-  }
+  EDM_MAX_LDS(kern, 160 * 1024);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, (const bf16*)X, (const bf16*)Wp, (bf16*)Y, (const bf16*)R,
                      alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n, mod);
   return 0;

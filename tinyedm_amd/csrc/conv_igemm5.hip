@@ -375,11 +375,7 @@ void launch5(const void* X, const void* Wp, void* Y, const void* R, float alpha,
   const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + BNW - 1) / BNW;
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
   auto kern = k_conv3x3_s<EPI, FRAG>;
-  static std::atomic<bool> attr_set{false};  // (idempotent call: a race only repeats it)
-  if (!attr_set.load(std::memory_order_acquire)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set.store(true, std::memory_order_release);
-  }
+  EDM_MAX_LDS(kern, 160 * 1024);
   constexpr size_t lds = (size_t)RED_BYTES > (size_t)4 * WAVE_LDS ? (size_t)RED_BYTES : (size_t)4 * WAVE_LDS;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, (const bf16*)X, (const bf16*)Wp, (bf16*)Y,
                      (const bf16*)R, (const char*)edm_zero_page(), alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n, mod);

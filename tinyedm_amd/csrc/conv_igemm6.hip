@@ -416,11 +416,7 @@ void launch6(const void* X, const void* Wp, void* Y, const void* R, float alpha,
   const size_t lds = (size_t)2 * NX * 8 * 16 * ROWB + WRING * (32 * NI * ROWB) + (EPI == 1 ? 8 * 32 * NI * 4 : 0);
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
   auto kern = k_conv3x3_v6<NX, EPI, NI, true, WB>;
-  static std::atomic<bool> attr_set{false};  // (idempotent call: a race only repeats it)
-  if (!attr_set.load(std::memory_order_acquire)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set.store(true, std::memory_order_release);
-  }
+  EDM_MAX_LDS(kern, 160 * 1024);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const bf16*)X, (const bf16*)Wp, (bf16*)Y, (const bf16*)R,
                      (const char*)edm_zero_page(), alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n, mod);
 }

@@ -214,11 +214,7 @@ void launch(const void* X, const void* dY, float* slabs, int B, int H, int W, in
   const size_t lds = 2 * (2 * KP * 64) + 2 * (2 * xrows * 64);
   const int tiles_co = (Cout + 63) / 64, tiles_ci = (Cin + 63) / 64;
   auto kern = k_conv_wgrad<TAPS, XL>;
-  static std::atomic<bool> attr_set{false};  // (idempotent call: a race only repeats it)
-  if (!attr_set.load(std::memory_order_acquire)) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set.store(true, std::memory_order_release);
-  }
+  EDM_MAX_LDS(kern, 160 * 1024);
   hipLaunchKernelGGL(kern, dim3(tiles_co * tiles_ci, S), dim3(256), lds, st, (const bf16*)X, (const bf16*)dY, slabs,
                      B, H, W, Cin, Cout, tiles_ci, L, kbeg0, kend);
 }

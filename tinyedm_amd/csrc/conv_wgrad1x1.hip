@@ -237,11 +237,7 @@ extern "C" int edm_conv_wgrad_1x1(const void* X, const void* dY, float* slabs, l
   long L = (npix + nsplit - 1) / nsplit;
   L = (L + KP - 1) / KP * KP;
   const int tiles_co = (Cout + TCO - 1) / TCO, tiles_ci = (Cin + TCI - 1) / TCI;
-  static std::atomic<bool> attr_set{false};  // (idempotent call: a race only repeats it)
-  if (!attr_set.load(std::memory_order_acquire)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad1x1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set.store(true, std::memory_order_release);
-  }
+  EDM_MAX_LDS(k_wgrad1x1, 160 * 1024);
   hipLaunchKernelGGL(k_wgrad1x1, dim3(tiles_co * tiles_ci, nsplit), dim3(512), (size_t)RING * STAGE, st, (const bf16*)X,
                      (const bf16*)dY, slabs, (const bf16*)edm_zero_page(), npix, Cin, Cout, tiles_ci, L);
   EDM_CHECK_LAUNCH("conv_wgrad_1x1");
@@ -299,11 +295,7 @@ extern "C" int edm_conv_wgrad_1x1_group(const void* items_, int n, void* table_h
     g.Cin[i] = g.Cout[i] = g.tiles_ci[i] = g.tiles[i] = g.nsplit[i] = 0;
     g.wg_end[i] = (int)total;
   }
-  static std::atomic<bool> attr_set{false};  // (idempotent call: a race only repeats it)
-  if (!attr_set.load(std::memory_order_acquire)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad1x1_group), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set.store(true, std::memory_order_release);
-  }
+  EDM_MAX_LDS(k_wgrad1x1_group, 160 * 1024);
   EDM_UPLOAD_TABLE(table_dev, table_host, &g, sizeof(W1Group), st, "conv_wgrad_1x1_group");
   hipLaunchKernelGGL(k_wgrad1x1_group, dim3((unsigned)total), dim3(512), (size_t)RING * STAGE, st, (const W1Group*)table_dev);
   EDM_CHECK_LAUNCH("conv_wgrad_1x1_group");

@@ -325,17 +325,14 @@ extern "C" int edm_conv_wgrad_v2(const void* X, const void* dY, float* slabs, in
   long L = (g.kend - g.kbeg0 + nsplit - 1) / nsplit;
   L = (L + KP - 1) / KP * KP;
   const int tiles_co = (Cout + 63) / 64, tiles_ci = (Cin + 63) / 64;
-  auto launch = [&](auto kern, size_t lds, std::atomic<bool>& attr_set) {
-    if (!attr_set.load(std::memory_order_acquire)) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set.store(true, std::memory_order_release);
-    }
+  auto launch = [&](auto kern, size_t lds, std::atomic<unsigned long long>& done) {
+    edm_max_lds_once(reinterpret_cast<const void*>(kern), 160 * 1024, done);
     hipLaunchKernelGGL(kern, dim3(tiles_co * tiles_ci, nsplit), dim3(256), lds, st, (const bf16*)X, (const bf16*)dY,
                        slabs, (const bf16*)edm_zero_page(), B, H, W, Cin, Cout, tiles_ci, L, g);
   };
   const size_t lds1 = (size_t)Ring<1>::DYRING * 2 * SUBB + (size_t)2 * Ring<1>::XSLOTS * SUBB;
   const size_t lds2 = (size_t)Ring<2>::DYRING * 2 * SUBB + (size_t)2 * Ring<2>::XSLOTS * SUBB;
-  static std::atomic<bool> set1{false}, set9{false}, set9w{false};
+  static std::atomic<unsigned long long> set1{0}, set9{0}, set9w{0};   // (a bit per device: common.h edm_max_lds_once)
   if (taps == 1) launch(k_conv_wgrad2<1, 1>, lds1, set1);
   else if (leads == 1) launch(k_conv_wgrad2<9, 1>, lds1, set9);
   else launch(k_conv_wgrad2<9, 2>, lds2, set9w);

@@ -643,7 +643,7 @@ extern "C" int edm_wgrad3_group(const edm_wgrad3_item* items, int n, void* works
   }
   const W3Group* const wgp = (const W3Group*)table_dev;
   const F3Group* const fgp = (const F3Group*)((const char*)table_dev + sizeof(W3Group));
-  static std::atomic<bool> set1{false}, set2{false}, setf{false};   // (idempotent calls: a race only repeats them)
+  static std::atomic<unsigned long long> set1{0}, set2{0};   // (a bit per device: common.h edm_max_lds_once)
   static const int abl = [] { const char* e = getenv("EDM_W3_ABLATE"); return e ? atoi(e) : 0; }();   // tools only
   if (P.leads == 1 && abl) {
     auto go = [&](auto kern) {
@@ -669,22 +669,16 @@ extern "C" int edm_wgrad3_group(const edm_wgrad3_item* items, int n, void* works
     // training step gains 0.03 ms -- the kernel waits on its LDS-DMA issue, not on the matrix pipe); EDM_W3_MFMA16=0 keeps
     // v_mfma_f32_32x32x16_bf16
     static const int mf16 = [] { const char* e = getenv("EDM_W3_MFMA16"); return e ? atoi(e) : 1; }();
-    auto go = [&](auto kern, size_t lds, std::atomic<bool>& once) {
-      if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        once = true;
-      }
+    auto go = [&](auto kern, size_t lds, std::atomic<unsigned long long>& once) {
+      edm_max_lds_once(reinterpret_cast<const void*>(kern), 160 * 1024, once);
       hipLaunchKernelGGL(kern, dim3(P.wg.nwg), dim3(256), lds, st, wgp);
     };
-    static std::atomic<bool> set1m{false}, set2m{false};
+    static std::atomic<unsigned long long> set1m{0}, set2m{0};
     if (P.leads == 1) { if (mf16) go(k_wgrad3<1, 0, true>, Ring<1>::LDS, set1m); else go(k_wgrad3<1>, Ring<1>::LDS, set1); }
     else { if (mf16) go(k_wgrad3<2, 0, true>, Ring<2>::LDS, set2m); else go(k_wgrad3<2>, Ring<2>::LDS, set2); }
   }
   EDM_CHECK_LAUNCH("wgrad3");
-  if (!setf) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3_finish), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    setf = true;
-  }
+  EDM_MAX_LDS(k_wgrad3_finish, 64 * 1024);
   hipLaunchKernelGGL(k_wgrad3_finish, dim3(P.rows_total), dim3(256), (size_t)P.max_n * 4, st, fgp);
   EDM_CHECK_LAUNCH("wgrad3_finish");
   return EDM_OK;

@@ -220,11 +220,7 @@ void launch_conv(const float* X, const float* Wh, float* Y, const float* R, floa
   const size_t lds = ((size_t)2 * KC * XR + (size_t)2 * TAPS * KC * BNP) * sizeof(float);
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
   auto kern = k_conv_f32<TAPS, KC, WM>;
-  static std::atomic<bool> attr_set{false};  // (idempotent call: a race only repeats it)
-  if (!attr_set.load(std::memory_order_acquire)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set.store(true, std::memory_order_release);
-  }
+  EDM_MAX_LDS(kern, 160 * 1024);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WM), lds, st, X, Wh, Y, R, alpha, beta, lin, lin_stride, gain, H * W,
                      Npix, H, W, Cin, I, Cout, tiles_m, tiles_n, XR);
 }

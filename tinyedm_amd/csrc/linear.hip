@@ -114,12 +114,7 @@ __global__ __launch_bounds__(256) void k_sgemm_smallk(const float* __restrict__ 
 int sgemm(const float* A, long asm_, long ask, const float* B, long bsk, long bsn, float* C, long csm, long csn, int M,
           int N, int K, float alpha, int accumulate, hipStream_t st) {
   if (K <= 512) {
-    static std::atomic<bool> attr_set{false};  // (idempotent call: a race only repeats it)
-    if (!attr_set.load(std::memory_order_acquire)) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sgemm_smallk),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set.store(true, std::memory_order_release);
-    }
+    EDM_MAX_LDS(k_sgemm_smallk, 160 * 1024);
     hipLaunchKernelGGL(k_sgemm_smallk, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), (size_t)2 * K * 33 * sizeof(float),
                        st, A, asm_, ask, B, bsk, bsn, C, csm, csn, M, N, K, alpha, accumulate);
     return 0;

@@ -533,11 +533,7 @@ extern "C" int edm_wgrad_finish_multi(const edm_finish_item* items, int n, void*
     const size_t need = (size_t)(G + 1) * nn * sizeof(float);
     if (need > lds) lds = need;
   }
-  static std::atomic<bool> attr_set{false};  // (idempotent call: a race only repeats it)
-  if (!attr_set.load(std::memory_order_acquire)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_finish_multi), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    attr_set.store(true, std::memory_order_release);
-  }
+  EDM_MAX_LDS(k_wgrad_finish_multi, 128 * 1024);
   EDM_UPLOAD_TABLE(table_dev, table_host, &g, sizeof(FinGroup), st, "wgrad_finish_multi");
   hipLaunchKernelGGL(k_wgrad_finish_multi, dim3(row), dim3(512), lds, st, (const FinGroup*)table_dev);
   EDM_CHECK_LAUNCH("wgrad_finish_multi");
@@ -565,12 +561,7 @@ extern "C" int edm_weight_prep_multi(const void* descs, const int* groups, int n
                                      int normalize_inplace, hipStream_t st) {
   EDM_REQUIRE(descs && groups && n_groups > 0 && lds_bytes > 0 && lds_bytes <= 128 * 1024, "weight_prep_multi: bad args");
   static_assert(sizeof(PrepDesc) == 64, "PrepDesc layout");
-  static std::atomic<bool> attr_set{false};  // (idempotent call: a race only repeats it)
-  if (!attr_set.load(std::memory_order_acquire)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_weight_prep_multi), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              128 * 1024);
-    attr_set.store(true, std::memory_order_release);
-  }
+  EDM_MAX_LDS(k_weight_prep_multi, 128 * 1024);
   hipLaunchKernelGGL(k_weight_prep_multi, dim3(n_groups), dim3(256), (size_t)lds_bytes, st, (const PrepDesc*)descs,
                      (const int2*)groups, normalize_inplace);
   EDM_CHECK_LAUNCH("weight_prep_multi");
@@ -593,11 +584,7 @@ extern "C" int edm_wgrad_finish(const float* slabs, int S, const float* w, float
   if (threads < 64) threads = 64;
   if (threads > 1024) threads = 1024;
   const size_t lds = (size_t)(G + 1) * n * sizeof(float);
-  static std::atomic<bool> attr_set{false};  // (idempotent call: a race only repeats it)
-  if (!attr_set.load(std::memory_order_acquire)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_finish), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    attr_set.store(true, std::memory_order_release);
-  }
+  EDM_MAX_LDS(k_wgrad_finish, 128 * 1024);
   hipLaunchKernelGGL(k_wgrad_finish, dim3(O), dim3(threads), lds, st, slabs, S, w, grad, perm, O, I, Ipad, taps, scale,
                      accumulate, G);
   EDM_CHECK_LAUNCH("wgrad_finish");
