@@ -1378,7 +1378,7 @@ class Denoiser(nn.Module):
         coalesced 1-KiB instructions.  Depends on the shape only (the resolution of every block follows from the
         architecture), cached per shape."""
         cache = self.__dict__.setdefault("_fragcache", {})
-        key = (B, H, W)
+        key = (B, H, W, ops.IGEMM_VERSION)      # (a forced kernel generation changes which layers the 8x8 kernel runs)
         if key not in cache:
             flags = {}
             h, w = H, W
