@@ -332,9 +332,11 @@ def precond_scalars(sigma: Tensor, sd: float):
 
 def denoiser_forward(P, dcfg: DenoiserCfg, noisy: Tensor, sigma: Tensor, emb: Tensor,
                      training: bool = False, bf16: bool = False,
-                     dropout_masks: Optional[Dict[str, Tensor]] = None) -> Tensor:
+                     dropout_masks: Optional[Dict[str, Tensor]] = None,
+                     record: Optional[Dict[str, Tensor]] = None) -> Tensor:
     """networks.py:577-605.  ``dropout_masks`` maps block prefix -> {0,1} keep
-    mask (B,C,H,W) so that tests can inject the HIP path's Philox masks."""
+    mask (B,C,H,W) so that tests can inject the HIP path's Philox masks.  ``record`` (a dict) receives every block's
+    output under its parameter prefix (tools/block_parity.py: per-block HIP-vs-oracle error table)."""
     q = q_bf16 if bf16 else _ident
     masks = dropout_masks or {}
     c_skip, c_out, c_in = precond_scalars(sigma, dcfg.sigma_data)
@@ -347,12 +349,16 @@ def denoiser_forward(P, dcfg: DenoiserCfg, noisy: Tensor, sigma: Tensor, emb: Te
         down, _, attn = _block_flags(t)
         x = encoder_block(P, p, x, emb, down, attn, dcfg.num_heads, dcfg.encoder_add_factor,
                           dcfg.dropout_rate, training, q, masks.get(p))
+        if record is not None:
+            record[p] = x
         skips.append(x)
     for i, (t, has_skip) in enumerate(zip(dcfg.decoder_block_types, dcfg.skip_connections)):
         p = f"denoiser.decoder_blocks.{i}."
         _, up, attn = _block_flags(t)
         x = decoder_block(P, p, x, emb, skips.pop() if has_skip else None, up, attn, dcfg.num_heads,
                           dcfg.decoder_add_factor, dcfg.dropout_rate, training, q, masks.get(p))
+        if record is not None:
+            record[p] = x
     # conv_out result is consumed in fp32 by the fused epilogue (no q on the output)
     f = F.conv2d(q(x), q(effective_weight(P["denoiser.conv_out.weight"]))) * P["denoiser.gain_out"]
     return f * c_out + noisy * c_skip
