@@ -66,38 +66,52 @@ __global__ __launch_bounds__(256) void k_sgemm(const float* __restrict__ A, long
     }
 }
 
-// Fast path for K <= 256: the whole K extent of a 32x32 output tile is staged at once (one barrier, no K loop),
-// because these GEMMs are latency-bound (a 128x256x256 problem is 17 MFLOP).
+// Fast path for K <= 512: the whole K extent of a 32x32 output tile is staged at once (one barrier, no K loop),
+// because these GEMMs are latency-bound (a 128x256x256 problem is 17 MFLOP).  Round 4: the staging loops carry no integer
+// division (the thread -> (k, row) map is fixed per operand orientation; the old `e % K`, `e / K` per element were ~1 300 of
+// the kernel's ~3 500 instructions per thread), and a thread reads its two A rows / two B columns of a k with ONE 8-byte
+// LDS read each (rows padded to 34 floats: even, so the pairs are aligned).  The sum over k runs in the same order with
+// the same fma per element as before: results are bit-identical.
 __global__ __launch_bounds__(256) void k_sgemm_smallk(const float* __restrict__ A, long asm_, long ask,
                                                         const float* __restrict__ Bm, long bsk, long bsn,
                                                         float* __restrict__ C, long csm, long csn, int M, int N, int K,
                                                         float alpha, int accumulate) {
-  constexpr int TM = 32, TN = 32, LD = 33;
+  constexpr int TM = 32, TN = 32, LD = 34;
   extern __shared__ __attribute__((aligned(16))) float sm_[];
   float (*As)[LD] = reinterpret_cast<float (*)[LD]>(sm_);
   float (*Bs)[LD] = reinterpret_cast<float (*)[LD]>(sm_ + (size_t)K * LD);
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-  // pick the thread->element map so that the unit-stride dimension of each operand is the fast one
-  for (int e = threadIdx.x; e < TM * K; e += 256) {
-    int kk, mm;
-    if (ask == 1) { kk = e % K; mm = e / K; } else { mm = e % TM; kk = e / TM; }
-    const int m = m0 + mm;
-    As[kk][mm] = (m < M) ? A[m * asm_ + kk * ask] : 0.f;
+  // the unit-stride dimension of each operand is the fast index of the thread map
+  if (ask == 1) {            // k contiguous: 64 k per pass, 4 rows per pass
+    const int tk = threadIdx.x & 63, tr = threadIdx.x >> 6;
+    for (int mm = tr; mm < TM; mm += 4) {
+      const int m = m0 + mm;
+      for (int kk = tk; kk < K; kk += 64) As[kk][mm] = (m < M) ? A[m * asm_ + kk] : 0.f;
+    }
+  } else {                   // rows contiguous (or general strides): 32 rows per pass, 8 k per pass
+    const int tr = threadIdx.x & 31, tk = threadIdx.x >> 5;
+    const int m = m0 + tr;
+    for (int kk = tk; kk < K; kk += 8) As[kk][tr] = (m < M) ? A[m * asm_ + kk * ask] : 0.f;
   }
-  for (int e = threadIdx.x; e < TN * K; e += 256) {
-    int kk, nn;
-    if (bsk == 1) { kk = e % K; nn = e / K; } else { nn = e % TN; kk = e / TN; }
-    const int n = n0 + nn;
-    Bs[kk][nn] = (n < N) ? Bm[kk * bsk + n * bsn] : 0.f;
+  if (bsk == 1) {
+    const int tk = threadIdx.x & 63, tr = threadIdx.x >> 6;
+    for (int nn = tr; nn < TN; nn += 4) {
+      const int n = n0 + nn;
+      for (int kk = tk; kk < K; kk += 64) Bs[kk][nn] = (n < N) ? Bm[kk + n * bsn] : 0.f;
+    }
+  } else {
+    const int tr = threadIdx.x & 31, tk = threadIdx.x >> 5;
+    const int n = n0 + tr;
+    for (int kk = tk; kk < K; kk += 8) Bs[kk][tr] = (n < N) ? Bm[kk * bsk + n * bsn] : 0.f;
   }
   __syncthreads();
   float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll 8
   for (int kk = 0; kk < K; ++kk) {
-    const float a0 = As[kk][ty * 2], a1 = As[kk][ty * 2 + 1];
-    const float b0 = Bs[kk][tx * 2], b1 = Bs[kk][tx * 2 + 1];
-    acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
+    const float2 a = *reinterpret_cast<const float2*>(&As[kk][ty * 2]);
+    const float2 b = *reinterpret_cast<const float2*>(&Bs[kk][tx * 2]);
+    acc[0][0] += a.x * b.x; acc[0][1] += a.x * b.y; acc[1][0] += a.y * b.x; acc[1][1] += a.y * b.y;
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -115,7 +129,7 @@ int sgemm(const float* A, long asm_, long ask, const float* B, long bsk, long bs
           int N, int K, float alpha, int accumulate, hipStream_t st) {
   if (K <= 512) {
     EDM_MAX_LDS(k_sgemm_smallk, 160 * 1024);
-    hipLaunchKernelGGL(k_sgemm_smallk, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), (size_t)2 * K * 33 * sizeof(float),
+    hipLaunchKernelGGL(k_sgemm_smallk, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), (size_t)2 * K * 34 * sizeof(float),
                        st, A, asm_, ask, B, bsk, bsn, C, csm, csn, M, N, K, alpha, accumulate);
     return 0;
   }
