@@ -127,9 +127,12 @@ int edm_conv_wgrad_1x1_nsplit_grouped(long npix, int Cin, int Cout);
  * table_host (PINNED host memory) and table_dev (device memory), each of at least edm_*_table_bytes() bytes: the call
  * fills table_host, issues ONE stream-ordered copy to table_dev (a memcpy node when the stream is being captured) and
  * launches with the device pointer.  table_host must stay valid and unmodified until that copy has executed (for a
- * captured stream: for the life of the graph), table_dev until the kernels have. */
+ * captured stream: for the life of the graph), table_dev until the kernels have.  defer_upload != 0: the call only fills
+ * table_host (any host memory) and launches; the CALLER copies table_host to table_dev before the launch can execute -- for
+ * a stream capture once, after the capture has ended, instead of a copy node that every replay would run again. */
 long edm_conv_wgrad_1x1_group_table_bytes(void);
-int edm_conv_wgrad_1x1_group(const edm_wgrad1_item* items, int n, void* table_host, void* table_dev, edm_stream_t stream);
+int edm_conv_wgrad_1x1_group(const edm_wgrad1_item* items, int n, void* table_host, void* table_dev, int defer_upload,
+                             edm_stream_t stream);
 /* third generation, 3x3 layers, a GROUP of layers per call (autograd wgrad of networks.py:35-37 + the projection of
  * networks.py:32-36's normalisation): the reduction dimension of all layers is laid end to end and cut into equal
  * ranges, one per workgroup (128x64x9 tile, one wave per SIMD); partial tiles go to `workspace`; a second launch sums
@@ -149,7 +152,7 @@ typedef struct {
 long edm_wgrad3_workspace(const edm_wgrad3_item* items, int n);
 long edm_wgrad3_table_bytes(void);
 int edm_wgrad3_group(const edm_wgrad3_item* items, int n, void* workspace, long workspace_bytes, void* table_host,
-                     void* table_dev, edm_stream_t stream);
+                     void* table_dev, int defer_upload, edm_stream_t stream);
 
 /* ---------------------------------------------------------------- weights (networks.py:17-19, 32-36, 55-59) */
 /* forced weight normalisation (in place when normalize_inplace) + effective weight w/(eps+|w|/sqrt(n))/sqrt(n),
@@ -177,7 +180,8 @@ typedef struct {
   int accumulate;
 } edm_finish_item;
 long edm_wgrad_finish_multi_table_bytes(void);
-int edm_wgrad_finish_multi(const edm_finish_item* items, int n, void* table_host, void* table_dev, edm_stream_t stream);
+int edm_wgrad_finish_multi(const edm_finish_item* items, int n, void* table_host, void* table_dev, int defer_upload,
+                           edm_stream_t stream);
 
 /* ---------------------------------------------------------------- attention (networks.py:194-202) */
 /* qkv [B*N,3C] channel order [head][q|k|v][d]; q,k,v pixel-normalised over d; softmax(qk^T/sqrt(d)) v. d = 64, N<=256 */

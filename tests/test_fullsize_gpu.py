@@ -224,3 +224,37 @@ def test_fragment_major_packs_b128():
     assert abs(res[True][1] - res[False][1]) <= 1e-6 * abs(res[False][1])
     e = rel(res[True][2], res[False][2])
     assert e <= 1e-5, e
+
+
+def test_captured_solve_sees_new_weights_when_the_plan_is_fragment_major():
+    """A captured Heun solve reads the weight packs of the plan of ITS input shape (at batch 128 the one with fragment-major
+    packs on the 8x8 layers); the refresh before a replay (solvers.py) is called without a shape and must bring THAT plan up
+    to date too: after an in-place change of an 8x8 layer's weight the replay equals the eager solve, not the old one."""
+    import tinyedm_amd as T
+    from tinyedm_amd import _runtime_env
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    if not _runtime_env.GRAPH_REPLAY_SAFE:
+        pytest.skip("hipGraph replay needs the safe runtime setting")
+    ecfg, dcfg = O.cifar10_cfg()
+    P = O.init_params(ecfg, dcfg, torch.Generator().manual_seed(1), gains_nonzero=True)
+    emb = T.Embedding(ecfg.fourier_dim, ecfg.embedding_dim, ecfg.num_classes, ecfg.add_factor)
+    den = T.Denoiser(dcfg.in_channels, dcfg.out_channels, tuple(dcfg.encoder_block_types),
+                     tuple(dcfg.decoder_block_types), tuple(dcfg.encoder_out_channels),
+                     tuple(dcfg.decoder_out_channels), tuple(dcfg.skip_connections), dcfg.dropout_rate,
+                     dcfg.sigma_data, dcfg.encoder_add_factor, dcfg.decoder_add_factor, dcfg.embedding_dim, dcfg.num_heads)
+    emb.load_state_dict({k[len("embedding."):]: v for k, v in P.items() if k.startswith("embedding.")})
+    den.load_state_dict({k[len("denoiser."):]: v for k, v in P.items() if k.startswith("denoiser.")})
+    model = T.EDM(diffuser=T.Diffuser(-1.2, 1.2), embedding=emb, denoiser=den, use_ema=False, use_uncertainty=False,
+                  steady_steps=10, rampup_steps=2, scheduler_interval="step", lr=1e-3).to(DEV).eval()
+    x0 = torch.randn(128, 3, 32, 32, generator=torch.Generator().manual_seed(3)).to(DEV)
+    solver = T.DeterministicSolver(num_steps=2)
+    with torch.no_grad():
+        x1 = solver.solve(model, x0, None, graph=True)
+        assert any(getattr(t, "_edm_frag", False) for plan in den._plans.values() for c in plan.caches for t in c[:2] if t is not None)
+        w = den.encoder_blocks[6].conv_3x3_1.weight          # an 8x8 layer: fragment-major packs at this batch
+        w.mul_(torch.linspace(0.5, 1.5, w.shape[1], device=DEV).view(1, -1, 1, 1))
+        x2 = solver.solve(model, x0, None, graph=True)
+        x2e = solver.solve(model, x0, None)
+    assert torch.equal(x2, x2e)
+    assert not torch.equal(x2, x1)

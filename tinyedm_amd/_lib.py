@@ -61,11 +61,11 @@ SIGNATURES = {
     "edm_conv_wgrad_1x1_nsplit": [L, I, I],
     "edm_conv_wgrad_1x1_nsplit_grouped": [L, I, I],
     "edm_conv_wgrad_1x1": [P, P, P, L, I, I, I, P],
-    "edm_conv_wgrad_1x1_group": [P, I, P, P, P],
+    "edm_conv_wgrad_1x1_group": [P, I, P, P, I, P],
     "edm_conv_wgrad_1x1_group_table_bytes": [],
     # conv_wgrad3.hip (items = host array of WGrad3Item)
     "edm_wgrad3_workspace": [P, I],
-    "edm_wgrad3_group": [P, I, P, L, P, P, P],
+    "edm_wgrad3_group": [P, I, P, L, P, P, I, P],
     "edm_wgrad3_table_bytes": [],
     # attention.hip
     "edm_attention_fwd": [P, P, I, I, I, I, P],
@@ -89,7 +89,7 @@ SIGNATURES = {
     "edm_weight_prep": [P, I, I, I, I, P, P, P, P, I, P],
     "edm_weight_prep_multi": [P, P, I, I, I, P],
     "edm_wgrad_finish": [P, I, P, P, P, I, I, I, I, F, I, P],
-    "edm_wgrad_finish_multi": [P, I, P, P, P],
+    "edm_wgrad_finish_multi": [P, I, P, P, I, P],
     "edm_wgrad_finish_multi_table_bytes": [],
     # eval_f32.hip (reference-precision evaluation path)
     "edm_f32_conv": [P, P, P, P, F, F, P, L, P, I, I, I, I, I, I, I, P],

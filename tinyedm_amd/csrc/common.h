@@ -49,11 +49,14 @@ extern "C" const void* edm_zero_page(void);
 // stream-ordered copy puts it into caller-provided device memory, and the kernels take a pointer: no kernel of a captured
 // step carries more than ~200 bytes of arguments.  Caller contract: `host_stage` stays valid and unmodified until the copy
 // has executed (for a captured stream: for the life of the graph), `dev` until the kernels have.
-#define EDM_UPLOAD_TABLE(dev, host_stage, src, bytes, st, name)                                                        \
+// `defer` != 0: the table is only written to host_stage (any host memory) and the CALLER copies it to `dev` before the launch
+// can execute -- for a stream capture: once, after the capture has ended, instead of a memcpy node that every replay would
+// run again (the table of a captured launch never changes between replays); ops._LaunchTables / ops.capture_end do that.
+#define EDM_UPLOAD_TABLE(dev, host_stage, src, bytes, st, name, defer)                                                 \
   do {                                                                                                                 \
-    EDM_REQUIRE((dev) && (host_stage), name ": the launch table needs a pinned host staging buffer and a device buffer"); \
+    EDM_REQUIRE((dev) && (host_stage), name ": the launch table needs a host staging buffer and a device buffer");     \
     memcpy((host_stage), (src), (bytes));                                                                              \
-    if (hipMemcpyAsync((dev), (host_stage), (bytes), hipMemcpyHostToDevice, (st)) != hipSuccess) {                      \
+    if (!(defer) && hipMemcpyAsync((dev), (host_stage), (bytes), hipMemcpyHostToDevice, (st)) != hipSuccess) {         \
       edm_set_error("%s: uploading the launch table failed: %s", name, hipGetErrorString(hipGetLastError()));         \
       return EDM_ERR_LAUNCH;                                                                                           \
     }                                                                                                                  \

@@ -255,7 +255,7 @@ struct edm_wgrad1_item_ {
 };
 extern "C" long edm_conv_wgrad_1x1_group_table_bytes(void) { return (long)sizeof(W1Group); }
 
-extern "C" int edm_conv_wgrad_1x1_group(const void* items_, int n, void* table_host, void* table_dev, hipStream_t st) {
+extern "C" int edm_conv_wgrad_1x1_group(const void* items_, int n, void* table_host, void* table_dev, int defer_upload, hipStream_t st) {
   const edm_wgrad1_item_* items = (const edm_wgrad1_item_*)items_;
   EDM_REQUIRE(items && n > 0 && n <= W1_MAX, "conv_wgrad_1x1_group: 1..%d layers per group", W1_MAX);
   EDM_ZERO_PAGE(zero_page_, "conv_wgrad_1x1_group");
@@ -296,7 +296,7 @@ extern "C" int edm_conv_wgrad_1x1_group(const void* items_, int n, void* table_h
     g.wg_end[i] = (int)total;
   }
   EDM_MAX_LDS(k_wgrad1x1_group, 160 * 1024);
-  EDM_UPLOAD_TABLE(table_dev, table_host, &g, sizeof(W1Group), st, "conv_wgrad_1x1_group");
+  EDM_UPLOAD_TABLE(table_dev, table_host, &g, sizeof(W1Group), st, "conv_wgrad_1x1_group", defer_upload);
   hipLaunchKernelGGL(k_wgrad1x1_group, dim3((unsigned)total), dim3(512), (size_t)RING * STAGE, st, (const W1Group*)table_dev);
   EDM_CHECK_LAUNCH("conv_wgrad_1x1_group");
   return EDM_OK;

@@ -622,7 +622,7 @@ extern "C" long edm_wgrad3_workspace(const edm_wgrad3_item* items, int n) {
 extern "C" long edm_wgrad3_table_bytes(void) { return (long)(sizeof(W3Group) + sizeof(F3Group)); }
 
 extern "C" int edm_wgrad3_group(const edm_wgrad3_item* items, int n, void* workspace, long workspace_bytes,
-                                void* table_host, void* table_dev, hipStream_t st) {
+                                void* table_host, void* table_dev, int defer_upload, hipStream_t st) {
   Plan P;
   const int rc = make_plan(items, n, P);
   if (rc != EDM_OK) return rc;
@@ -639,7 +639,7 @@ extern "C" int edm_wgrad3_group(const edm_wgrad3_item* items, int n, void* works
     char stage[sizeof(W3Group) + sizeof(F3Group)];
     memcpy(stage, &P.wg, sizeof(W3Group));
     memcpy(stage + sizeof(W3Group), &P.fg, sizeof(F3Group));
-    EDM_UPLOAD_TABLE(table_dev, table_host, stage, sizeof(stage), st, "wgrad3");
+    EDM_UPLOAD_TABLE(table_dev, table_host, stage, sizeof(stage), st, "wgrad3", defer_upload);
   }
   const W3Group* const wgp = (const W3Group*)table_dev;
   const F3Group* const fgp = (const F3Group*)((const char*)table_dev + sizeof(W3Group));

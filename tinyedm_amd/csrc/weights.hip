@@ -513,7 +513,7 @@ typedef struct {
 // Reduce + project up to 40 weight gradients in one launch (`items` is HOST memory, read during the call).
 extern "C" long edm_wgrad_finish_multi_table_bytes(void) { return (long)sizeof(FinGroup); }
 
-extern "C" int edm_wgrad_finish_multi(const edm_finish_item* items, int n, void* table_host, void* table_dev, hipStream_t st) {
+extern "C" int edm_wgrad_finish_multi(const edm_finish_item* items, int n, void* table_host, void* table_dev, int defer_upload, hipStream_t st) {
   EDM_REQUIRE(items && n > 0 && n <= MAXF, "wgrad_finish_multi: need 1..%d tensors, got %d", MAXF, n);
   FinGroup g;
   g.n = n;
@@ -534,7 +534,7 @@ extern "C" int edm_wgrad_finish_multi(const edm_finish_item* items, int n, void*
     if (need > lds) lds = need;
   }
   EDM_MAX_LDS(k_wgrad_finish_multi, 128 * 1024);
-  EDM_UPLOAD_TABLE(table_dev, table_host, &g, sizeof(FinGroup), st, "wgrad_finish_multi");
+  EDM_UPLOAD_TABLE(table_dev, table_host, &g, sizeof(FinGroup), st, "wgrad_finish_multi", defer_upload);
   hipLaunchKernelGGL(k_wgrad_finish_multi, dim3(row), dim3(512), lds, st, (const FinGroup*)table_dev);
   EDM_CHECK_LAUNCH("wgrad_finish_multi");
   return EDM_OK;

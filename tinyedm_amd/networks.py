@@ -1408,9 +1408,16 @@ class Denoiser(nn.Module):
         captured step or solve holds the addresses of the plan it was captured with."""
         mods = [m for m in self.modules() if isinstance(m, _WNBase)]
         frag = self._frag_flags(*shape) if (shape is not None and FRAG_PACKS) else {}
-        key = (tuple(m.weight.data_ptr() for m in mods), tuple(m._want for m in mods),
-               tuple((k, v) for k, v in enumerate(frag.get(m) for m in mods) if v))
+        base = (tuple(m.weight.data_ptr() for m in mods), tuple(m._want for m in mods))
+        key = base + (tuple((k, v) for k, v in enumerate(frag.get(m) for m in mods) if v),)
         plans = self.__dict__.setdefault("_plans", {})
+        if shape is None and not self.training:
+            # no shape given (the sampler's refresh before a graph replay, the fp32 evaluation route): every plan of these
+            # weights is brought up to date -- a captured solve reads the packs of the plan of ITS input shape (each
+            # run() is a no-op unless the master weights changed since that plan's last run)
+            for k, plan in plans.items():
+                if k[:2] == base and k != key:
+                    plan.run(False)
         plan = plans.get(key)
         if plan is None:
             plan = plans[key] = _PrepPlan(mods, frag)

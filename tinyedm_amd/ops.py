@@ -100,24 +100,34 @@ def zeros_f32(shape, device):
 def capture_begin():
     """call right before a stream capture starts (and capture_end() right after it ends)"""
     _zero_pool.buf = None
+    _tables.begin()
 
 
-capture_end = capture_begin
+def capture_end():
+    _zero_pool.buf = None
+    _tables.end()
 
 
 class _LaunchTables:
     """Staging for the launch tables of the grouped kernels (edm_wgrad3_group, edm_conv_wgrad_1x1_group,
-    edm_wgrad_finish_multi; include/tinyedm_hip.h "LAUNCH TABLES"): the C side writes a table into PINNED host memory and
-    copies it, stream-ordered, into device memory that the kernels read -- nothing larger than a few hundred bytes travels
-    as a by-value kernel argument.
-    Eager steps take (host, device) slot pairs from a ring; a slot is reused only after the event recorded behind its last
-    use has completed.  While a stream is being CAPTURED the copy becomes a memcpy node that every replay executes again
-    from the same host address, so those slots come from a bump-allocated pinned pool that is never reused or freed
-    (allocated up front: pinning memory is not a capturable call)."""
+    edm_wgrad_finish_multi; include/tinyedm_hip.h "LAUNCH TABLES"): the C side writes a table into host memory and it is
+    copied into device memory that the kernels read -- nothing larger than a few hundred bytes travels as a by-value
+    kernel argument.
+    * Eager steps: (pinned host, device) slot pairs from a ring, one stream-ordered copy per table issued by the C side; a
+      slot is reused only after the event recorded behind its last use has completed.
+    * Between ops.capture_begin() and ops.capture_end() (graph.CapturedTrainStep): the table of a captured launch never
+      changes between replays, so it is uploaded ONCE -- the C side only fills a host buffer (defer_upload), the device
+      slot comes from a pool allocated up front, and capture_end() copies all of them before the first replay can run
+      (no memcpy nodes in the graph: nine 4-us copies per replayed step otherwise).
+    * A capture made WITHOUT those hooks still works: the copy becomes a memcpy node that every replay executes again from
+      the same host address, so those slots come from a bump-allocated pinned pool that is never reused or freed
+      (allocated up front: pinning memory is not a capturable call)."""
     RING, POOL = 64, 512
 
     def __init__(self):
         self.dev = {}
+        self.deferring = False
+        self.pending = []           # (device tensor, host tensor) pairs to upload at capture_end()
 
     def _state(self, device):
         key = torch.device(device).index
@@ -132,20 +142,27 @@ class _LaunchTables:
                 "nb": nb, "i": 0, "events": [None] * self.RING,
                 "host": torch.empty(self.RING, nb, dtype=torch.uint8).pin_memory(),
                 "devb": torch.empty(self.RING, nb, dtype=torch.uint8, device=d),
-                "pool": torch.empty(self.POOL, nb, dtype=torch.uint8).pin_memory(), "pool_i": 0, "pool_dev": []}
+                "pool": torch.empty(self.POOL, nb, dtype=torch.uint8).pin_memory(), "pool_i": 0,
+                # device slots for captured launches, allocated HERE (eagerly, ordinary memory): a buffer allocated inside a
+                # capture belongs to the graph's pool and a write to it from outside the graph (the deferred upload) did
+                # not reach what the replayed kernels read -- the first replay hung on a garbage table
+                "pool_devb": torch.empty(self.POOL, nb, dtype=torch.uint8, device=d)}
         return st
 
     def take(self, device):
-        """-> (host pointer, device pointer, release()): call release() right after the launch that uses the table"""
+        """-> (host pointer, device pointer, defer_upload, release()): call release() right after the launch"""
         st = self._state(device)
         if torch.cuda.is_current_stream_capturing():
             k = st["pool_i"]
             if k >= self.POOL:
-                raise RuntimeError("tinyedm_amd: out of pinned launch-table slots for captured graphs (ops._LaunchTables.POOL)")
-            st["pool_i"] = k + 1
-            dev = torch.empty(st["nb"], dtype=torch.uint8, device=st["devb"].device)   # from the capturing graph's pool
-            st["pool_dev"].append(dev)
-            return st["pool"][k].data_ptr(), dev.data_ptr(), (lambda: None)
+                raise RuntimeError("tinyedm_amd: out of launch-table slots for captured graphs (ops._LaunchTables.POOL)")
+            st["pool_i"] = k + 1                    # never reused: the graph keeps reading it
+            dev = st["pool_devb"][k]
+            if self.deferring:
+                host = torch.empty(st["nb"], dtype=torch.uint8)
+                self.pending.append((dev, host))
+                return host.data_ptr(), dev.data_ptr(), 1, (lambda: None)
+            return st["pool"][k].data_ptr(), dev.data_ptr(), 0, (lambda: None)
         k = st["i"] % self.RING
         st["i"] += 1
         if st["events"][k] is not None:
@@ -155,7 +172,18 @@ class _LaunchTables:
             ev = torch.cuda.Event()
             ev.record()
             st["events"][k] = ev
-        return st["host"][k].data_ptr(), st["devb"][k].data_ptr(), release
+        return st["host"][k].data_ptr(), st["devb"][k].data_ptr(), 0, release
+
+    def begin(self):
+        self.deferring, self.pending = True, []
+
+    def end(self):
+        """upload the tables of the capture that just ended (their launches have only been recorded so far)"""
+        pend, self.pending, self.deferring = self.pending, [], False
+        for dev, host in pend:
+            dev.copy_(host)
+        if pend:
+            torch.cuda.synchronize(pend[0][0].device)
 
 
 _tables = _LaunchTables()
@@ -810,9 +838,9 @@ def conv_wgrad_1x1_group(pairs):
         out.append(slabs)
         flops += 2.0 * npix * Cin * Cout
         nbytes += 2.0 * npix * (Cin + Cout) + 4.0 * slabs.numel()
-    th, td, release = _tables.take(pairs[0][0].device)
+    th, td, defer, release = _tables.take(pairs[0][0].device)
     with _prof("conv1x1_wgrad", flops, nbytes):
-        _lib.call("edm_conv_wgrad_1x1_group", ctypes.byref(arr), n, ctypes.c_void_p(th), ctypes.c_void_p(td), _stream())
+        _lib.call("edm_conv_wgrad_1x1_group", ctypes.byref(arr), n, ctypes.c_void_p(th), ctypes.c_void_p(td), defer, _stream())
     release()
     return out
 
@@ -861,9 +889,10 @@ def wgrad3_group(items):
     if nb <= 0:
         raise _lib.HipKernelError(f"edm_wgrad3_workspace failed: {_lib.lib().edm_last_error().decode()}")
     work = torch.empty(nb // 4, device=items[0][0].device, dtype=f32)
-    th, td, release = _tables.take(items[0][0].device)
+    th, td, defer, release = _tables.take(items[0][0].device)
     with _prof("conv3x3_wgrad", flops, nbytes):
-        _lib.call("edm_wgrad3_group", ctypes.byref(arr), n, _p(work), nb, ctypes.c_void_p(th), ctypes.c_void_p(td), _stream())
+        _lib.call("edm_wgrad3_group", ctypes.byref(arr), n, _p(work), nb, ctypes.c_void_p(th), ctypes.c_void_p(td), defer,
+                  _stream())
     release()
     return work
 
@@ -932,8 +961,9 @@ def wgrad_finish_multi(items):
                 _chk(perm, torch.int32, "perm", (O,))
             arr[k] = _lib.FinishItem(slabs.data_ptr(), w.data_ptr(), grad.data_ptr(), None if perm is None else perm.data_ptr(),
                                      S, O, I, Ipad, taps, float(scale), int(bool(accumulate)))
-        th, td, release = _tables.take(chunk[0][0].device)
-        _lib.call("edm_wgrad_finish_multi", ctypes.byref(arr), len(chunk), ctypes.c_void_p(th), ctypes.c_void_p(td), _stream())
+        th, td, defer, release = _tables.take(chunk[0][0].device)
+        _lib.call("edm_wgrad_finish_multi", ctypes.byref(arr), len(chunk), ctypes.c_void_p(th), ctypes.c_void_p(td), defer,
+                  _stream())
         release()
 
 
