@@ -324,6 +324,11 @@ int edm_split_conv(const void* Xp, const void* Wp3, float* Y, void* Ypairs, cons
 /* cosine attention (networks.py:194-202) on the qkv conv's own output order: channel head*3d + 3*dd + {q,k,v};
  * y [B*N][C] with channel head*d + dd.  head_dim in {32, 64, 128, 144, 192}; any number of tokens (key tiles of 64). */
 int edm_f32_attention(const float* qkv, float* y, int B, int N, int C, int heads, edm_stream_t stream);
+/* the same attention for the split-bf16 ("f32x3") evaluation path: every matrix product in three bf16 MFMA passes over
+ * (hi, lo) operand pairs (fp32-accurate to 2^-17 per operand, as edm_split_conv), normalisation / softmax / accumulation in
+ * fp32.  y (fp32 [B*N][C]) and / or ypairs (bf16 [B*N][2C] = [hi | lo], the out conv's operand format) -- either may be
+ * NULL.  head_dim 64 and N <= 256 tokens; -3 otherwise (callers fall back to edm_f32_attention). */
+int edm_split_attention(const float* qkv, float* y, void* ypairs, int B, int N, int C, int heads, edm_stream_t stream);
 /* (s_pairs / pairs_row / pairs != 0 in the three entry points below: the mp_silu / concat outputs are written as split-bf16
  * PAIRS -- rows [hi(C) | lo(C)] of bf16 in the same bytes -- ready to be edm_split_conv's Xp) */
 int edm_f32_pixelnorm_silu(const float* x, float* xn, float* s, long P, int C, int s_pairs, edm_stream_t stream);

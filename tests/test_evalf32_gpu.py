@@ -267,6 +267,35 @@ def test_split_conv_modulation_epilogue(ops):
     assert rel(y, yx) <= 1e-5
 
 
+@pytest.mark.parametrize("B,H,W,heads", [(2, 8, 8, 4), (3, 16, 16, 4), (2, 7, 7, 2), (1, 14, 14, 4), (2, 11, 11, 1)])
+def test_split_attention_vs_fp64(ops, B, H, W, heads):
+    """the split-bf16 attention (three MFMA passes over hi/lo pairs; head_dim 64, <= 256 tokens: the CIFAR-10 / ImageNet-64
+    16x16 and 8x8 layers, MNIST's ragged 14x14 and 7x7) against the reference's arithmetic (networks.py:194-202) in fp64;
+    the pairs output reassembles to the same values"""
+    hd = 64
+    g = torch.Generator().manual_seed(B + H + heads)
+    C = heads * hd
+    qkv = torch.randn(B, 3 * C, H, W, generator=g) * 1.7
+    t = qkv.double().view(B, heads, -1, 3, H * W)
+    t = t / (1e-4 + t.norm(dim=2, keepdim=True) / math.sqrt(hd))
+    q, k, v = t.unbind(3)
+    attn = torch.softmax(torch.einsum("nhcq,nhck->nhqk", q, k / math.sqrt(hd)), dim=3)
+    ref = torch.einsum("nhqk,nhck->nhcq", attn, v).reshape(B, C, H, W)
+    x = nhwc(qkv)
+    assert ops.split_attention_ok(C, heads, H * W)
+    y = ops.split_attention(x, heads)
+    e = rel(nchw(y), ref)
+    record(f"evalf32/split_attention[{H}x{W} h{heads}]", e, 2e-5)
+    assert e <= 2e-5, e
+    yp = ops.split_attention(x, heads, pairs=True)
+    assert yp.shape == (B, H, W, 2 * C) and yp.dtype == torch.bfloat16
+    back = yp[..., :C].float() + yp[..., C:].float()
+    assert rel(back, y) <= 2e-5
+    # and it is what the exact-fp32 kernel computes, to the same limit
+    assert rel(y, ops.f32_attention(x, heads)) <= 2e-5
+    assert not ops.split_attention_ok(2 * 144, 2, 64) and not ops.split_attention_ok(64, 1, 400)
+
+
 def test_cifar10_forward_and_trajectory_f32x3():
     """set_eval_dtype("f32x3"): the 35.6 M-parameter net through the split-bf16 convs against the FP32 oracle (forward,
     limit 1e-4 like the exact path) and the 32-step Heun trajectory against the exact-fp32 path of this library from the

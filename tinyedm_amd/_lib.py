@@ -94,6 +94,7 @@ SIGNATURES = {
     # eval_f32.hip (reference-precision evaluation path)
     "edm_f32_conv": [P, P, P, P, F, F, P, L, P, I, I, I, I, I, I, I, P],
     "edm_f32_attention": [P, P, I, I, I, I, P],
+    "edm_split_attention": [P, P, P, I, I, I, I, P],
     "edm_f32_to_pairs": [P, P, L, I, P],
     "edm_split_pack": [P, P, I, I, I, I, P],
     "edm_split_conv": [P, P, P, P, P, F, F, P, L, P, I, I, I, I, I, I, P],

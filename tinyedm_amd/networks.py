@@ -721,7 +721,13 @@ class CosineAttention(nn.Module):
     def forward_f32(self, x: Tensor) -> Tensor:
         """reference-precision evaluation (NHWC fp32 in / out): qkv conv in the master row order, exact-fp32 attention"""
         qkv = _conv_f32(self.qkv_conv, x, 1)
-        y = ops.f32_attention(qkv, self.num_heads)
+        B, H, W, _ = qkv.shape
+        if _split_ok(self.out_conv) and ops.split_attention_ok(self.embedding_dim, self.num_heads, H * W):
+            # split back end: the attention runs on the bf16 matrix cores too (three passes over hi/lo pairs) and hands its
+            # output to the out conv as pairs
+            y = ops.split_attention(qkv, self.num_heads, pairs=True)
+        else:
+            y = ops.f32_attention(qkv, self.num_heads)
         a, b = _mp_coeffs(0.5)
         return _conv_f32(self.out_conv, y, 1, residual=x, alpha=b, beta=a)
 

@@ -1238,6 +1238,25 @@ def f32_attention(qkv, heads):
     return y
 
 
+def split_attention_ok(C, heads, N):
+    """shapes edm_split_attention covers (attention_split.hip): head_dim 64, at most 256 tokens"""
+    return C % heads == 0 and C // heads == 64 and N <= 256
+
+
+def split_attention(qkv, heads, pairs=False):
+    """fp32-accurate attention on the bf16 matrix cores (three MFMA passes over hi/lo pairs): qkv (B,H,W,3C) fp32 in the qkv
+    conv's own channel order -> (B,H,W,C) fp32, or -- pairs=True -- (B,H,W,2C) bf16 [hi | lo] pairs for the out conv"""
+    B, H, W, C3 = _nhwc32(qkv, "qkv")
+    C = C3 // 3
+    N = H * W
+    if not split_attention_ok(C, heads, N):
+        raise ValueError(f"split_attention: head_dim {C // heads}, {N} tokens not covered (head_dim 64, <= 256 tokens)")
+    y = torch.empty(B, H, W, 2 * C, device=qkv.device, dtype=bf16) if pairs else torch.empty(B, H, W, C, device=qkv.device, dtype=f32)
+    with _prof("split_attention", 3 * 4.0 * B * N * N * C, 4.0 * B * N * 4 * C):
+        _lib.call("edm_split_attention", _p(qkv), None if pairs else _p(y), _p(y) if pairs else None, B, N, C, heads, _stream())
+    return y
+
+
 def f32_pixelnorm_silu(x, pairs=False):
     """-> (xn fp32, s): s = mp_silu(xn) as fp32, or -- pairs=True -- as (B,H,W,2C) bf16 split pairs (split_conv's operand)"""
     B, H, W, C = _nhwc32(x, "x")
