@@ -110,6 +110,53 @@ __global__ __launch_bounds__(THREADS) void k_ring(const char* __restrict__ src, 
   }
 }
 
+// The access shape of the 1x1 kernels: the source is [rows][ROWB bytes] (ROWB = 2 * channels); a stage is 64 rows; one
+// LDS-DMA instruction fetches SEG bytes of each of 1024 / SEG rows (SEG = 64: the [64 rows][32 ch] sub-images of
+// k_wgrad1x1_group / the conv kernels' slabs; 128, 256: wider segments) -- every byte is still loaded exactly once.
+template <int ROWB, int SEG, int R>
+__global__ __launch_bounds__(512) void k_strided(const char* __restrict__ src, char* __restrict__ dst, long nstages) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = 64 * ROWB;                 // bytes per stage
+  constexpr int NINSTR = STAGE / 1024;             // DMA instructions per stage (all waves together)
+  constexpr int PER = NINSTR / 8;                  // per wave
+  constexpr int RPI = 1024 / SEG;                  // rows per instruction
+  constexpr int SEGS = ROWB / SEG;                 // segments per row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long first = blockIdx.x, step = gridDim.x;
+  const long mine = first < nstages ? (nstages - first + step - 1) / step : 0;
+  auto issue = [&](long k, int slot) {
+    const char* s = src + (first + k * step) * STAGE;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int j = wave + 8 * i;                  // instruction j: segment column j % SEGS, row group j / SEGS
+      const int seg = j % SEGS, rg = j / SEGS;
+      const int row = rg * RPI + lane / (SEG / 16), piece = lane % (SEG / 16);
+      __builtin_amdgcn_global_load_lds((gptr_t)(s + (long)row * ROWB + seg * SEG + piece * 16), (lptr_t)(smem + slot * STAGE + j * 1024), 16, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int r = 0; r < R - 1; ++r)
+    if (r < mine) issue(r, r);
+  for (long k = 0; k < mine; ++k) {
+    const int slot = (int)(k % R);
+    if (k + R - 1 < mine) {
+      issue(k + R - 1, (int)((k + R - 1) % R));
+      wait_vmcnt<(R - 1) * PER>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __syncthreads();
+    char* d = dst + (first + k * step) * STAGE;
+#pragma unroll
+    for (int p = 0; p < PER; ++p) {
+      const int t2 = (tid + 64) % 512;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(smem + slot * STAGE + (p * 512 + t2) * 16);
+      *reinterpret_cast<u32x4*>(d + (p * 512 + t2) * 16) = v;
+    }
+    __syncthreads();
+  }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 template <class F>
@@ -154,5 +201,17 @@ int main() {
   RING(256, 2, 8, true, 4) RING(256, 1, 8, true, 8)
   RING(256, 2, 3, false, 2) RING(256, 2, 3, false, 4) RING(256, 4, 3, false, 2) RING(256, 4, 4, false, 4) RING(512, 2, 3, false, 2)
   RING(256, 2, 4, false, 8)
+#define STR(ROWB, SEG, R)                                                                                              \
+  {                                                                                                                    \
+    constexpr int STAGE = 64 * ROWB;                                                                                   \
+    auto kern = k_strided<ROWB, SEG, R>;                                                                               \
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                \
+    char nm[96];                                                                                                       \
+    snprintf(nm, 96, "lds-dma rows of %d B, %d-B segments, ring %d", ROWB, SEG, R);                                    \
+    report(nm, timeit([&](int i) { hipLaunchKernelGGL(kern, dim3(256), dim3(512), (size_t)R * STAGE, 0, src[i % 3], dst[i % 3], bytes / STAGE); }, reps)); \
+  }
+  STR(512, 64, 3) STR(512, 128, 3) STR(512, 256, 3) STR(512, 512, 3)
+  STR(768, 64, 3) STR(768, 128, 3) STR(768, 256, 3)
+  STR(1024, 64, 2) STR(1024, 128, 2) STR(1024, 256, 2) STR(1024, 1024, 2)
   return 0;
 }
