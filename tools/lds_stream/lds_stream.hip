@@ -157,6 +157,47 @@ __global__ __launch_bounds__(512) void k_strided(const char* __restrict__ src, c
   }
 }
 
+// The PHASE shape of a 1x1 conv workgroup: read RD stages of 16 KB through the ring (the K loop), THEN write WR KB (the
+// epilogue) -- one tile per workgroup (grid = tiles), or persistent workgroups that keep the next tile's loads in flight
+// under the stores (PERSIST).  Reads 2/3, writes 1/3 of the bytes, as the 512->256 layers.
+template <int RD, int WRK, int R, bool PERSIST>
+__global__ __launch_bounds__(512) void k_phased(const char* __restrict__ src, char* __restrict__ dst, long ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = 16 * 1024, PER = 2;
+  const int tid = threadIdx.x;
+  const long first = blockIdx.x, step = PERSIST ? gridDim.x : ntiles;
+  const long mine = PERSIST ? (first < ntiles ? (ntiles - first + step - 1) / step : 0) : 1;
+  const long nst = mine * RD;                       // stages of this workgroup, tile after tile
+  auto issue = [&](long q) {
+    const long tile = first + (q / RD) * step;
+    const char* s = src + (tile * RD + q % RD) * STAGE;
+#pragma unroll
+    for (int p = 0; p < PER; ++p)
+      __builtin_amdgcn_global_load_lds((gptr_t)(s + (p * 512 + tid) * 16), (lptr_t)(smem + (q % R) * STAGE + p * 8192), 16, 0, 0);
+  };
+  u32x4 keep = {0, 0, 0, 0};
+  for (int r = 0; r < R - 1; ++r)
+    if (r < nst) issue(r);
+  for (long q = 0; q < nst; ++q) {
+    if (q + R - 1 < nst) {
+      issue(q + R - 1);
+      wait_vmcnt<(R - 1) * PER>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __syncthreads();
+    const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (q % R) * STAGE + ((tid + 64) % 512) * 16);
+    keep[0] ^= v[0]; keep[1] ^= v[1]; keep[2] ^= v[2]; keep[3] ^= v[3];
+    __syncthreads();
+    if (q % RD == RD - 1) {                         // the tile's K loop is over: its outputs
+      const long tile = first + (q / RD) * step;
+      char* d = dst + tile * (WRK * 1024);
+#pragma unroll
+      for (int p = 0; p < WRK * 1024 / (512 * 16); ++p) *reinterpret_cast<u32x4*>(d + (p * 512 + tid) * 16) = keep;
+    }
+  }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 template <class F>
@@ -213,5 +254,18 @@ int main() {
   STR(512, 64, 3) STR(512, 128, 3) STR(512, 256, 3) STR(512, 512, 3)
   STR(768, 64, 3) STR(768, 128, 3) STR(768, 256, 3)
   STR(1024, 64, 2) STR(1024, 128, 2) STR(1024, 256, 2) STR(1024, 1024, 2)
+#define PHS(RD, WRK, R, PERSIST, GRIDMUL)                                                                               \
+  {                                                                                                                    \
+    const long ntiles = bytes / (RD * 16 * 1024);                                                                      \
+    auto kern = k_phased<RD, WRK, R, PERSIST>;                                                                         \
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                \
+    char nm[128];                                                                                                      \
+    snprintf(nm, 128, "phased: read %d KB then write %d KB per tile, ring %d, %s", RD * 16, WRK, R,                    \
+             PERSIST ? "persistent (loads run under the stores)" : "one tile per workgroup");                          \
+    const double ms = timeit([&](int i) { hipLaunchKernelGGL(kern, dim3(PERSIST ? 256 * GRIDMUL : (unsigned)ntiles), dim3(512), (size_t)R * 16 * 1024, 0, src[i % 3], dst[i % 3], ntiles); }, reps); \
+    printf("%-100s %8.3f ms  %6.2f TB/s (read + write)\n", nm, ms, (bytes * (1.0 + (double)WRK / (RD * 16))) / ms / 1e9); fflush(stdout); \
+  }
+  PHS(16, 128, 3, false, 1) PHS(16, 128, 4, false, 1) PHS(16, 128, 3, true, 1) PHS(16, 128, 4, true, 1) PHS(16, 128, 4, true, 2)
+  PHS(8, 128, 3, false, 1) PHS(8, 128, 4, true, 1)
   return 0;
 }
