@@ -1075,7 +1075,9 @@ extern "C" int edm_conv_out_fwd(const void* x, const float* w_hat, const float* 
               "conv_out_fwd: bad args (Co<=8 required)");
   long npix = (long)B * HW;
   EDM_REQUIRE(npix < (1L << 31), "conv_out_fwd: too many pixels");
-  hipLaunchKernelGGL(k_conv_out_fwd<32>, dim3(grid_for(npix, 8)), dim3(256), 0, st, (const bf16*)x, w_hat, gain_out,
+  // 8 lanes per pixel (8 pixels per wave trip, four 16-byte loads per lane in flight, 9 shuffles per 8 pixels): 26.5 us at the
+  // CIFAR-10 size against 44.8 with 32 lanes per pixel (one load per lane, 15 shuffles per 2 pixels), 32.1 with 16, 29.2 with 4
+  hipLaunchKernelGGL(k_conv_out_fwd<8>, dim3(grid_for(npix, 32)), dim3(256), 0, st, (const bf16*)x, w_hat, gain_out,
                      noisy, sigma, sigma_stride, sigma_data, D, Fraw, HW, C, Co, npix);
   EDM_CHECK_LAUNCH("conv_out_fwd");
   return EDM_OK;
@@ -1086,23 +1088,23 @@ extern "C" int edm_conv_out_fwd(const void* x, const float* w_hat, const float* 
 __global__ void k_conv_out_bwd_x(const float* __restrict__ dD, const float* __restrict__ wh,
                                  const float* __restrict__ gain_out, const float* __restrict__ sigma, int sstride,
                                  float sd, bf16* __restrict__ gx, int HW, int C, int Co, long n8) {
-  const int CL = C >> 3;
+  // (32-bit index arithmetic: n8 < 2^31 is host-checked; the 64-bit i / CL, p / HW, p % HW of the first form were ~300
+  // instructions per 16 output bytes)
+  const unsigned CL = (unsigned)C >> 3, uHW = (unsigned)HW;
   const float go = *gain_out;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
-    int c8 = (int)(i % CL);
-    long p = i / CL;
-    long b = p / HW;
-    int hw = (int)(p % HW);
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)n8; i += gridDim.x * blockDim.x) {
+    const unsigned p = i / CL, c8 = i - p * CL;
+    const unsigned b = p / uHW, hw = p - b * uHW;
     float s = sigma[b * sstride];
     float cout = s * sd * rsqrtf(s * s + sd * sd) * go;
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int o = 0; o < Co; ++o) {
-      float df = dD[(b * Co + o) * HW + hw] * cout;
+      float df = dD[((long)b * Co + o) * HW + hw] * cout;
       const float* wp = wh + (long)o * C + c8 * 8;
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] += df * wp[j];
     }
-    store8(gx + i * 8, v);
+    store8(gx + (long)i * 8, v);
   }
 }
 //   gwh[o,c] += sum_p dF[p,o]*x[p,c] ;  ggain += sum dD*c_out*F
@@ -1124,19 +1126,51 @@ __global__ void k_conv_out_bwd_w(const bf16* __restrict__ x, const float* __rest
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[o][j] = 0.f;
   float gg = 0.f;
-  for (long p = p0 + ps; p < p1; p += PS) {
-    const long b = p / HW;
-    const int hw = (int)(p % HW);
-    const float s = sigma[b * sstride];
-    const float cout = s * sd * rsqrtf(s * s + sd * sd);
-    float v[8];
-    load8(x + p * C + c8 * 8, v);
+  // (sample index, pixel-in-sample and the sample's c_out advance incrementally -- npix < 2^31 host-checked -- instead of a 64-bit division and a dependent sigma load per pixel; the next pixel's operands are loaded
+  // before this one's are consumed: the trip was one exposed load -> use chain per pixel)
+  int p = (int)p0 + ps;
+  const int pend = (int)p1;
+  int b = p / HW, hw = p - b * HW;
+  float cout = 0.f;
+  {
+    const float s = sigma[(p < pend ? b : 0) * sstride];
+    cout = s * sd * rsqrtf(s * s + sd * sd);
+  }
+  float vn[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dn[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto fetch = [&](int pp, int bb, int hh) {
+    load8(x + (long)pp * C + c8 * 8, vn);
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+      if (o < Co) {
+        const long idx = ((long)bb * Co + o) * HW + hh;
+        dn[o] = dD[idx];
+        if (c8 == 0) fn[o] = Fraw[idx];
+      }
+  };
+  if (p < pend) fetch(p, b, hw);
+  while (p < pend) {
+    float v[8], dd[8], ff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] = vn[j]; dd[j] = dn[j]; ff[j] = fn[j]; }
+    const float cur = cout;
+    p += PS;
+    hw += PS;
+    if (hw >= HW) {
+      do {
+        hw -= HW;
+        ++b;
+      } while (hw >= HW);
+      if (p < pend) {
+        const float s = sigma[b * sstride];
+        cout = s * sd * rsqrtf(s * s + sd * sd);
+      }
+    }
+    if (p < pend) fetch(p, b, hw);
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
       if (o < Co) {
-        const long idx = (b * Co + o) * HW + hw;
-        float d = dD[idx] * cout;
-        if (c8 == 0) gg += d * Fraw[idx];
+        float d = dd[o] * cur;
+        if (c8 == 0) gg += d * ff[o];
         d *= go;
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[o][j] += d * v[j];
@@ -1164,6 +1198,7 @@ extern "C" int edm_conv_out_bwd(const void* x, const float* w_hat, const float* 
   EDM_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && Co >= 1 && Co <= 8 && (sigma_stride == 0 || sigma_stride == 1),
               "conv_out_bwd: bad args");
   long npix = (long)B * HW, n8 = npix * C / 8;
+  EDM_REQUIRE(n8 < (1L << 31), "conv_out_bwd: too many elements (32-bit index arithmetic)");
   hipLaunchKernelGGL(k_conv_out_bwd_x, dim3(grid_for(n8, 256)), dim3(256), 0, st, dD, w_hat, gain_out, sigma,
                      sigma_stride, sigma_data, (bf16*)gx, HW, C, Co, n8);
   EDM_CHECK_LAUNCH("conv_out_bwd_x");
@@ -1172,7 +1207,8 @@ extern "C" int edm_conv_out_bwd(const void* x, const float* w_hat, const float* 
     EDM_REQUIRE(CL <= 256, "conv_out_bwd: C=%d too large", C);
     int block = (256 / CL) * CL, PS = block / CL;
     while (PS > 1 && (size_t)PS * Co * C * sizeof(float) > 48 * 1024) { --PS; block = PS * CL; }
-    const int PIXW = 256;   // r01 sweep at the CIFAR-10 size (us): 1024 -> 167, 512 -> 93, 256 -> 72, 128 -> 80, 32 -> 841
+    const int PIXW = 256;   // sweep at the CIFAR-10 size, x + w kernels (us), round 4: 128 -> 89, 256 -> 73, 512 -> 80, 1024 -> 115
+                            // (512 / 1024 threads per workgroup: no better)
     hipLaunchKernelGGL(k_conv_out_bwd_w, dim3(cdiv(npix, PIXW)), dim3(block), (size_t)PS * Co * C * sizeof(float), st,
                        (const bf16*)x, dD, Fraw, gain_out, sigma, sigma_stride, sigma_data, gw_hat, ggain, HW, C, Co,
                        npix, PIXW);
