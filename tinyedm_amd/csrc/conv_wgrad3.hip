@@ -474,6 +474,18 @@ __global__ __launch_bounds__(256) void k_wgrad3_finish(const F3Group* __restrict
   const float* __restrict__ row = g.L[li].w + (long)mo * n;
   const int tco = r / TCO, rl = r - tco * TCO;
   const float scale = g.L[li].scale;
+  // the row of the master weight (projection below): loaded NOW, while the partial tiles are in flight -- the kernel is a
+  // chain of memory round trips per workgroup (partials -> row -> block sums -> store) and this takes one of them out
+  constexpr int WPF = 28;                       // covers n <= 7168 (Cin <= 796) with 256 threads; longer rows load late
+  const bool pf = n <= WPF * 256;
+  float wpre[WPF];
+  if (pf) {
+#pragma unroll
+    for (int k = 0; k < WPF; ++k) {
+      const int e = threadIdx.x + k * 256;
+      wpre[k] = e < n ? row[e] : 0.f;
+    }
+  }
   // work items: (ci tile, tap, float4 of the 64 ci) -> 16 per (tile, tap)
   const int items = tiles_ci * 9 * 16;
   for (int idx = threadIdx.x; idx < items; idx += blockDim.x) {
@@ -498,10 +510,21 @@ __global__ __launch_bounds__(256) void k_wgrad3_finish(const F3Group* __restrict
   }
   __syncthreads();
   float dot = 0.f, ss = 0.f;
-  for (int e = threadIdx.x; e < n; e += blockDim.x) {
-    const float wv = row[e];
-    dot += gsm[e] * wv;
-    ss += wv * wv;
+  if (pf) {
+#pragma unroll
+    for (int k = 0; k < WPF; ++k) {
+      const int e = threadIdx.x + k * 256;
+      if (e < n) {
+        dot += gsm[e] * wpre[k];
+        ss += wpre[k] * wpre[k];
+      }
+    }
+  } else {
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+      const float wv = row[e];
+      dot += gsm[e] * wv;
+      ss += wv * wv;
+    }
   }
   dot = block_sum_f(dot, red);
   ss = block_sum_f(ss, red);
@@ -512,9 +535,20 @@ __global__ __launch_bounds__(256) void k_wgrad3_finish(const F3Group* __restrict
   const float c1 = rn > 0.f ? dot / (d * rn * sqn) : 0.f;
   float* __restrict__ outp = g.L[li].grad + (long)mo * n;
   const int accumulate = g.L[li].accumulate;
-  for (int e = threadIdx.x; e < n; e += blockDim.x) {
-    const float v = c0 * (gsm[e] - row[e] * c1);
-    outp[e] = accumulate ? outp[e] + v : v;
+  if (pf) {
+#pragma unroll
+    for (int k = 0; k < WPF; ++k) {
+      const int e = threadIdx.x + k * 256;
+      if (e < n) {
+        const float v = c0 * (gsm[e] - wpre[k] * c1);
+        outp[e] = accumulate ? outp[e] + v : v;
+      }
+    }
+  } else {
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+      const float v = c0 * (gsm[e] - row[e] * c1);
+      outp[e] = accumulate ? outp[e] + v : v;
+    }
   }
 }
 
