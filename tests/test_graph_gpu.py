@@ -275,3 +275,22 @@ def test_copy_free_concat_matches_the_standalone_concat_kernels():
     assert torch.equal(res[True][0], res[False][0])
     assert abs(res[True][1] - res[False][1]) <= 1e-6 * abs(res[False][1])
     assert rel(res[True][2], res[False][2]) <= 1e-5, rel(res[True][2], res[False][2])
+
+
+def test_captured_launch_table_pool_grows_outside_capture():
+    """ops._LaunchTables: the device slots of captured launches are never reused (a graph keeps reading its tables), so a
+    process that captures again and again must not run out -- capture_begin() reserves room for the next capture by adding
+    a chunk of slots (outside the capture: memory allocated inside one belongs to the graph's pool)"""
+    from tinyedm_amd import ops
+    t = ops._tables
+    st = t._state(torch.cuda.current_device())
+    before_chunks, before_i = len(st["pool_devb"]), st["pool_i"]
+    try:
+        st["pool_i"] = len(st["pool_devb"]) * t.POOL - 3          # three slots left
+        ops.capture_begin()
+        assert len(st["pool_devb"]) == before_chunks + 1
+        assert len(st["pool_devb"]) * t.POOL - st["pool_i"] >= 64
+        assert st["pool_devb"][-1].device.type == "cuda" and st["pool_devb"][-1].shape == (t.POOL, st["nb"])
+    finally:
+        ops.capture_end()
+        st["pool_i"] = max(before_i, 0)

@@ -146,18 +146,26 @@ class _LaunchTables:
                 # device slots for captured launches, allocated HERE (eagerly, ordinary memory): a buffer allocated inside a
                 # capture belongs to the graph's pool and a write to it from outside the graph (the deferred upload) did
                 # not reach what the replayed kernels read -- the first replay hung on a garbage table
-                "pool_devb": torch.empty(self.POOL, nb, dtype=torch.uint8, device=d)}
+                "pool_devb": [torch.empty(self.POOL, nb, dtype=torch.uint8, device=d)]}
         return st
+
+    def _reserve(self, st, want):
+        """make sure `want` more captured launches find a device slot -- called OUTSIDE capture (capture_begin): a long-lived
+        process that captures again and again (new batch shapes, new models) grows the pool instead of running out"""
+        while len(st["pool_devb"]) * self.POOL - st["pool_i"] < want:
+            st["pool_devb"].append(torch.empty(self.POOL, st["nb"], dtype=torch.uint8, device=st["devb"].device))
 
     def take(self, device):
         """-> (host pointer, device pointer, defer_upload, release()): call release() right after the launch"""
         st = self._state(device)
         if torch.cuda.is_current_stream_capturing():
             k = st["pool_i"]
-            if k >= self.POOL:
-                raise RuntimeError("tinyedm_amd: out of launch-table slots for captured graphs (ops._LaunchTables.POOL)")
+            if k >= len(st["pool_devb"]) * self.POOL or (not self.deferring and k >= self.POOL):
+                raise RuntimeError("tinyedm_amd: out of launch-table slots for captured graphs (ops._LaunchTables: captures "
+                                   "made between ops.capture_begin() / capture_end() grow the pool; bare captures share "
+                                   f"{self.POOL} pinned slots per process)")
             st["pool_i"] = k + 1                    # never reused: the graph keeps reading it
-            dev = st["pool_devb"][k]
+            dev = st["pool_devb"][k // self.POOL][k % self.POOL]
             if self.deferring:
                 host = torch.empty(st["nb"], dtype=torch.uint8)
                 self.pending.append((dev, host))
@@ -176,6 +184,8 @@ class _LaunchTables:
 
     def begin(self):
         self.deferring, self.pending = True, []
+        if torch.cuda.is_available():
+            self._reserve(self._state(torch.cuda.current_device()), 64)     # (a captured training step takes 9)
 
     def end(self):
         """upload the tables of the capture that just ended (their launches have only been recorded so far)"""
