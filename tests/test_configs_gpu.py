@@ -88,10 +88,19 @@ def eval_parity(ecfg, dcfg, shape, seed, tol):
         den.set_eval_dtype("f32")
         with torch.no_grad():
             D32 = den(noisy.to(DEV), sigma.to(DEV), e)
+        # ... and the split-bf16 form of it, the default of the sampling entry points (three MFMA passes per product; the
+        # attention too where head_dim is 64 and the map has <= 256 tokens, the exact-fp32 kernels elsewhere)
+        den.set_eval_dtype("f32x3")
+        with torch.no_grad():
+            D3 = den(noisy.to(DEV), sigma.to(DEV), e)
         den.set_eval_dtype("bf16")
-        r32 = rel(D32.cpu() - base, O.edm_forward(P, ecfg, dcfg, noisy, sigma, labels, bf16=False) - base)
+        D_or32 = O.edm_forward(P, ecfg, dcfg, noisy, sigma, labels, bf16=False)
+        r32 = rel(D32.cpu() - base, D_or32 - base)
         record(f"configs/eval_forward_f32_path_vs_fp32_oracle[{tuple(shape)} emb{ecfg.embedding_dim}]", r32, 1e-4)
         assert r32 <= 1e-4, f"fp32 eval forward rel {r32:.3e}"
+        r3 = rel(D3.cpu() - base, D_or32 - base)
+        record(f"configs/eval_forward_f32x3_path_vs_fp32_oracle[{tuple(shape)} emb{ecfg.embedding_dim}]", r3, 1e-4)
+        assert r3 <= 1e-4, f"split-bf16 eval forward rel {r3:.3e}"
     return P, emb, den, (noisy, sigma, labels)
 
 
