@@ -63,8 +63,12 @@ __device__ __forceinline__ void lgkm_wait() {
 __device__ unsigned long long* g_v6_timeline = nullptr;
 #define V6_STAMP(slot)                                                                                          \
   if (g_v6_timeline && threadIdx.x == 0) g_v6_timeline[(long)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime()
+// the SHADER clock (s_memtime) at the same point: (d memtime) / (d memrealtime) x 100 MHz is the clock the chip holds there
+#define V6_CLK(slot)                                                                                            \
+  if (g_v6_timeline && threadIdx.x == 0) g_v6_timeline[(long)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime()
 #else
 #define V6_STAMP(slot)
+#define V6_CLK(slot)
 #endif
 
 template <int NX, int EPI = 0, int NI = 4, bool WPTR64 = true, int WB = 0, bool LATE_DMA = false>
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
       }
       __builtin_amdgcn_s_barrier();
 #ifdef EDM_V6_TIMELINE
-      if (u == 0 && chunk2 == 0) { V6_STAMP(1); }
+      if (u == 0 && chunk2 == 0) { V6_STAMP(1); V6_CLK(6); }
 #endif
       // ---- this step's DMAs: weight tile t+D into the ring slot read at step t-1, and (tap 0) the next slab.  An LDS-DMA
       // instruction holds the issuing wave for 60-180 cycles and the two waves of a SIMD leave the barrier together.
@@ -369,6 +373,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // asm MFMA results -> first read by ordinary code
   __builtin_amdgcn_s_barrier();  // every wave is done with the slab / weight ring
   V6_STAMP(2);
+  V6_CLK(7);
   if constexpr (EPI == 1) {
     const bool wave_rows = mod.HW % (32 * NJ) == 0;   // a wave's 64 pixels lie in one sample
     store_tile_transposed16<NI, NJ, EPI>(acc, smem + wave * (32 * (NI * 64 + 16)), Y, R, alpha, beta,

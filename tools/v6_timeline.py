@@ -61,6 +61,12 @@ for name, v in ph.items():
 if gaps:
     g = np.array(gaps)
     print(f"CU idle between a workgroup's last store and the next workgroup's start: median {np.median(g):.1f} us (p10 {np.percentile(g, 10):.1f}, p90 {np.percentile(g, 90):.1f})")
+clk = (t[:, 7] - t[:, 6]) / np.maximum(t[:, 2] - t[:, 1], 1) * 100.0       # MHz: shader-clock ticks per 10-ns tick
+steps = Cin // 32 * 9
+mf = steps * 32 * 2 * 16        # MFMA cycles of a SIMD's two waves over the main loop (32 per step and wave, 16 cycles each)
+print(f"shader clock inside the main loop (s_memtime / s_memrealtime): median {np.median(clk):.0f} MHz (p10 {np.percentile(clk, 10):.0f}, "
+      f"p90 {np.percentile(clk, 90):.0f}); the loop's {mf} MFMA cycles per SIMD would take {mf / np.median(clk):.1f} us at that clock: "
+      f"matrix-pipe occupancy {mf / np.median(clk) / np.median((t[:, 2] - t[:, 1]) / 100.0) * 100:.0f} %")
 end = us(t[:, 4])
 print(f"workgroup end times: p10 {np.percentile(end, 10):.1f}  median {np.median(end):.1f}  p90 {np.percentile(end, 90):.1f}  max {end.max():.1f} us")
 last = np.array([us(t[i, 4]) for i in seen.values()])
