@@ -93,6 +93,7 @@ def host_cores():
 TRAIN_GFLOP_PER_IMG = 81.0
 FWD_GFLOP_PER_IMG = 27.0
 MFMA_PEAK_TFLOPS = 2500.0      # bf16 dense, MI355X_MICROARCH.md chip table
+SUSTAINED_MFMA_TFLOPS = 1660.0  # measured: bare v_mfma_f32_16x16x32_bf16 + ds_read loop, all CUs, power-limited clock (tools/mfma_shape)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -583,6 +584,12 @@ def main():
                 "launches_per_step": conv["launches"],
                 "avg_launch_ms": round(conv["ms"] / max(1, conv["launches"]), 4),
                 "algorithmic_gflop_per_step": round(conv["gflop"], 1),
+                # what the matrix pipe SUSTAINS on this power-limited part (not the contract's `peak`, kept above): a bare
+                # MFMA + LDS loop of the same instruction on all 256 CUs holds 1.80 GHz x 88 % = 1 660 TFLOP/s
+                # (tools/mfma_shape); inside this kernel's main loop the chip runs 1.845 GHz with the pipe 81 % busy
+                # (tools/v6_timeline.py, profiles/r04_v6_timeline_clock.txt) -- clock x occupancy is what the power cap fixes
+                "sustained_mfma_tflops": SUSTAINED_MFMA_TFLOPS,
+                "frac_of_sustained": round(achieved / SUSTAINED_MFMA_TFLOPS, 4),
                 "whole_step_mfma_frac": round(ips / world * TRAIN_GFLOP_PER_IMG / 1e3 / MFMA_PEAK_TFLOPS, 4),
                 "whole_step_hbm_frac": round(ips / world * 108.6e6 / 1e9 / HBM_PEAK_GBS, 4),
                 # BASELINE.json's literal "HBM-bound 3x3-conv roofline": 3x3-conv activation bytes only (59.7 MB per
