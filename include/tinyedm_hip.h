@@ -189,6 +189,15 @@ int edm_attention_fwd(const void* qkv, void* y, int B, int N, int C, int heads, 
 int edm_attention_bwd(const void* qkv, const void* y, const void* gy, void* gqkv, int B, int N, int C, int heads,
                       edm_stream_t stream);
 
+/* CosineAttention with the qkv projection inside the attention kernel (csrc/attention_fused.hip, round 5; replaces
+ * networks.py:193-202 = qkv_conv -> view -> pixel_norm -> scaled_dot_product_attention as ONE launch; the qkv tensor never
+ * exists in HBM).  x [B*N, C] bf16 tokens, Wqkv [3C, C] bf16 = the qkv conv's forward pack (rows in [head][q|k|v][d] order),
+ * y [B*N, C] bf16, stat [B, heads, N] fp32 (softmax normaliser, kept for the backward; may be NULL in evaluation).
+ * Covered: C = 256, 4 heads (head_dim 64), 33..256 tokens (edm_attention_qkv_supported); heads_per_wg 0 = default. */
+int edm_attention_qkv_supported(int N, int C, int heads);
+int edm_attention_qkv_fwd(const void* x, const void* Wqkv, void* y, void* stat, int B, int N, int C, int heads,
+                          int heads_per_wg, edm_stream_t stream);
+
 /* ---------------------------------------------------------------- per-pixel / elementwise */
 /* pixel_norm over C + mp_silu (networks.py:9-14, 83-84, 249-252); dsave[p] = eps + |x_p|/sqrt(C) */
 int edm_pixelnorm_silu_fwd(const void* x, void* xn, void* a, float* dsave, long P, int C, edm_stream_t stream);

@@ -44,9 +44,9 @@ class Probed(CapturedTrainStep):
                 self.hist.index_copy_(0, self.ctr, torch.stack([loss.float().reshape(()), gb, gn, wb, mb, eb])[None])
                 self.ctr += 1
         finally:
-            ops.capture_end()
+            token = ops.capture_end()
             self._restore(snap)
-        return graph, sx, sy, loss
+        return graph, sx, sy, loss, token
 
 
 dev = torch.device("cuda:0")

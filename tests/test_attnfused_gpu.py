@@ -1,0 +1,80 @@
+"""CosineAttention with the projections inside the attention kernels (csrc/attention_fused.hip, round 5) against the
+reference's algorithm (networks.py:191-207) restated with the same bf16 rounding points as oracle/edm_oracle.py
+`cosine_attention`: qkv conv output rounded, pixel norm rounded, softmax probabilities rounded, y rounded.
+Operands are bf16-representable, so the only differences left are summation order and where the probabilities are rounded
+(the kernel rounds them before the normalisation, like attention.hip)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import edm_oracle as O
+from test_kernels_gpu import DEV, _qkv_perm, close_bf16, nchw, nhwc, q, rel
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tinyedm_amd import ops as _ops
+    return _ops
+
+
+def _reference(x, w_qkv_hat, heads, gy=None):
+    """x (B,C,H,W) fp32 bf16-representable, w_qkv_hat (3C, C) effective weight (bf16-representable), reference channel order.
+    -> y (B,C,H,W) [, dx, dw through autograd when gy is given]"""
+    B, C, H, W = x.shape
+    d = C // heads
+    N = H * W
+    qkv = O.q_bf16(torch.einsum("oc,bchw->bohw", w_qkv_hat, x))
+    t = O.q_bf16(O.rms_div(qkv.view(B, heads, d, 3, N), [2]))
+    qq, kk, vv = t.unbind(3)
+    s = torch.einsum("bhdi,bhdj->bhij", qq, kk) / math.sqrt(d)
+    p = O.q_bf16(torch.softmax(s, dim=-1))
+    return torch.einsum("bhij,bhdj->bhdi", p, vv).reshape(B, C, H, W)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 16, 16), (3, 8, 8), (9, 8, 8), (1, 14, 14), (2, 7, 7), (2, 6, 11), (17, 16, 16)])
+@pytest.mark.parametrize("hp", [0, 1, 2, 4])
+def test_attention_qkv_fwd(ops, B, H, W, hp):
+    heads, C = 4, 256
+    if not ops._lib.call("edm_attention_qkv_supported", H * W, C, heads):
+        pytest.skip("shape not covered by the fused kernel")
+    g = torch.Generator().manual_seed(B * 100 + H + W)
+    x = q(torch.randn(B, C, H, W, generator=g))
+    w = q(torch.randn(3 * C, C, generator=g) / math.sqrt(C))          # effective weight, reference row order
+    y_ref = _reference(x.double(), w.double(), heads)
+    perm = _qkv_perm(C, heads)
+    wf = w[perm].view(1, 3 * C, C).contiguous().to(torch.bfloat16).to(DEV)
+    old = ops.ATTN_HP
+    ops.ATTN_HP = hp
+    try:
+        y, stat = ops.attention_qkv_fwd(nhwc(x), wf, heads)
+    finally:
+        ops.ATTN_HP = old
+    close_bf16(nchw(y), y_ref, l2=6e-3, mx=3e-2)
+    # the unfused pair (1x1 conv kernel + attention.hip) computes the same thing: agree to bf16 rounding of y
+    qkv = ops.conv_igemm(nhwc(x), wf, 1)
+    y2 = ops.attention_fwd(qkv, heads)
+    assert rel(nchw(y), nchw(y2)) < 6e-3
+    # stat = 1 / sum_j exp(s_ij - 8): positive, finite
+    assert torch.isfinite(stat).all() and (stat > 0).all()
+
+
+def test_attention_qkv_fwd_extreme_logits(ops):
+    """the streamed softmax has no running maximum: it rests on |q.k| / sqrt(d) <= 8 for pixel-normalised q, k.  Saturate
+    it: every token identical (all logits = +8) and sign-flipped halves (logits -8 and +8 in one row)."""
+    heads, C, B, H, W = 4, 256, 2, 16, 16
+    g = torch.Generator().manual_seed(5)
+    base = q(torch.randn(1, C, 1, 1, generator=g))
+    x = base.expand(B, C, H, W).clone()
+    x[:, :, H // 2:] = -x[:, :, H // 2:]                              # half the tokens are the negation of the other half
+    w = q(torch.randn(3 * C, C, generator=g) / math.sqrt(C))
+    y_ref = _reference(x.double(), w.double(), heads)
+    perm = _qkv_perm(C, heads)
+    wf = w[perm].view(1, 3 * C, C).contiguous().to(torch.bfloat16).to(DEV)
+    y, stat = ops.attention_qkv_fwd(nhwc(x), wf, heads)
+    assert torch.isfinite(stat).all()
+    close_bf16(nchw(y), y_ref, l2=6e-3, mx=3e-2)

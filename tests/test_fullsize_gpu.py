@@ -258,3 +258,109 @@ def test_captured_solve_sees_new_weights_when_the_plan_is_fragment_major():
         x2e = solver.solve(model, x0, None)
     assert torch.equal(x2, x2e)
     assert not torch.equal(x2, x1)
+
+
+def _cifar_model(T, seed=1):
+    ecfg, dcfg = O.cifar10_cfg()
+    P = O.init_params(ecfg, dcfg, torch.Generator().manual_seed(seed), gains_nonzero=True)
+    emb = T.Embedding(ecfg.fourier_dim, ecfg.embedding_dim, ecfg.num_classes, ecfg.add_factor)
+    den = T.Denoiser(dcfg.in_channels, dcfg.out_channels, tuple(dcfg.encoder_block_types),
+                     tuple(dcfg.decoder_block_types), tuple(dcfg.encoder_out_channels),
+                     tuple(dcfg.decoder_out_channels), tuple(dcfg.skip_connections), dcfg.dropout_rate,
+                     dcfg.sigma_data, dcfg.encoder_add_factor, dcfg.decoder_add_factor, dcfg.embedding_dim, dcfg.num_heads)
+    emb.load_state_dict({k[len("embedding."):]: v for k, v in P.items() if k.startswith("embedding.")})
+    den.load_state_dict({k[len("denoiser."):]: v for k, v in P.items() if k.startswith("denoiser.")})
+    model = T.EDM(diffuser=T.Diffuser(-1.2, 1.2), embedding=emb, denoiser=den, use_ema=False, use_uncertainty=False,
+                  steady_steps=10, rampup_steps=2, scheduler_interval="step", lr=1e-3).to(DEV)
+    return model, den
+
+
+def test_captured_f32x3_solve_sees_new_weights():
+    """the split-bf16 weight packs of the "f32x3" evaluation are persistent plan buffers rewritten in
+    place by the refresh before a replay -- after an in-place weight change (and after an eager f32x3 forward in between,
+    which used to re-allocate the pack under the live graph) the replayed solve equals the eager one."""
+    import tinyedm_amd as T
+    from tinyedm_amd import _runtime_env
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    if not _runtime_env.GRAPH_REPLAY_SAFE:
+        pytest.skip("hipGraph replay needs the safe runtime setting")
+    model, den = _cifar_model(T)
+    model.eval()
+    den.set_eval_dtype("f32x3")
+    x0 = torch.randn(16, 3, 32, 32, generator=torch.Generator().manual_seed(3)).to(DEV)
+    solver = T.DeterministicSolver(num_steps=2)
+    with torch.no_grad():
+        x1 = solver.solve(model, x0, None, graph=True)
+        conv = den.encoder_blocks[2].conv_3x3_1
+        addr = conv._split_pack.data_ptr()
+        w = conv.weight
+        w.mul_(torch.linspace(0.5, 1.5, w.shape[1], device=DEV).view(1, -1, 1, 1))
+        w2 = den.decoder_blocks[2].attention.qkv_conv.weight
+        w2.mul_(torch.linspace(1.5, 0.5, w2.shape[1], device=DEV).view(1, -1, 1, 1))
+        x2e = solver.solve(model, x0, None)                 # an eager f32x3 pass between capture and replay
+        assert conv._split_pack.data_ptr() == addr          # rewritten in place, not re-allocated
+        x2 = solver.solve(model, x0, None, graph=True)
+    assert torch.equal(x2, x2e)
+    assert not torch.equal(x2, x1)
+    den.set_eval_dtype("bf16")
+
+
+def test_eval_dtype_toggle_leaves_the_training_plan_alone():
+    """a sampling callback that switches the evaluation precision for a while must not change the
+    training plan's key (set_eval_dtype used to append "hat" to every module's _want for good: a second full plan, and fp32
+    effective weights written by every later training step), and repeated toggles / shapes keep the number of plans bounded."""
+    import tinyedm_amd as T
+    from tinyedm_amd.callbacks import _eval_dtype
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    model, den = _cifar_model(T)
+    g = torch.Generator().manual_seed(5)
+    x = (0.5 * torch.randn(8, 3, 32, 32, generator=g)).to(DEV)
+    sigma = torch.ones(8, device=DEV)
+    model.train()
+    model.training_step((x, None), 0).backward()
+    train_keys = set(den._plans)
+    wants = {m: tuple(m._want) for m in den.modules() if hasattr(m, "_want")}
+    for _ in range(3):
+        for dt in ("f32x3", "f32"):
+            model.eval()
+            with _eval_dtype(model, dt), torch.no_grad():
+                model(x, sigma, None)
+            model.train()
+            model.training_step((x, None), 0).backward()
+    assert all(tuple(m._want) == w for m, w in wants.items())
+    assert train_keys <= set(den._plans)                         # the training plan is still there, under the same key
+    (tk,) = train_keys
+    assert all("hat" not in w or "hat" in m._want for m, w in zip(den._plans[tk].mods, den._plans[tk].wants))
+    assert len(den._plans) == 3                                  # training, f32x3 evaluation, f32 evaluation
+    model.eval()
+    with torch.no_grad():
+        for b in range(1, 12):                                   # many shapes: the plan count stays bounded
+            model(x[:1].expand(b, -1, -1, -1).contiguous(), sigma[:1].expand(b).contiguous(), None)
+    assert len(den._plans) <= den.MAX_PLANS + 1
+    torch.cuda.synchronize()
+
+
+def test_standalone_module_call_after_a_fragment_major_forward():
+    """a Denoiser forward at batch 128 leaves FRAGMENT-MAJOR packs in the 8x8 convs' caches (eval mode keeps
+    caches); the reference-style standalone module call on another shape must still work (plain packs) and must not disturb
+    the plan's buffers."""
+    import tinyedm_amd as T
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    model, den = _cifar_model(T)
+    model.eval()
+    g = torch.Generator().manual_seed(5)
+    x = (0.5 * torch.randn(128, 3, 32, 32, generator=g)).to(DEV)
+    sigma = torch.ones(128, device=DEV)
+    with torch.no_grad():
+        D1 = model(x, sigma, None).clone()
+        conv = den.encoder_blocks[6].conv_3x3_1
+        assert getattr(conv._cache[0], "_edm_frag", False)
+        xin = torch.randn(2, conv.in_channels, 8, 8, generator=g).to(DEV)
+        y = conv(xin)                                            # NCHW module API, a shape k_conv3x3_s does not run
+        ref = O.wn_conv(xin.cpu().float(), conv.weight.detach().cpu().float())
+        assert rel(y.cpu().float(), ref) < 1e-2
+        D2 = model(x, sigma, None)
+    assert torch.equal(D1, D2)

@@ -294,3 +294,45 @@ def test_captured_launch_table_pool_grows_outside_capture():
     finally:
         ops.capture_end()
         st["pool_i"] = max(before_i, 0)
+
+
+def test_launch_table_slots_are_released_and_bare_captures_have_their_own_index():
+    """ADVICE r4 (low) + round-4 review: (1) deferred captures (capture_begin / capture_end) and bare captures draw from
+    separate indices -- many deferred captures no longer exhaust the pinned pool of the bare path; (2) capture_end() returns
+    the slots the capture took and release_capture() makes them reusable: a process that re-captures does not grow."""
+    from tinyedm_amd import ops
+    t = ops._tables
+    dev = torch.cuda.current_device()
+    st = t._state(dev)
+    bare0, pool0, free0 = st["bare_i"], st["pool_i"], list(st["free"])
+    s = torch.cuda.Stream()
+    toks = []
+    for _ in range(3):
+        ops.capture_begin()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            _ = torch.ones(4, device="cuda") + 1
+            got = [t.take(dev) for _ in range(5)]
+        assert all(x[2] == 1 for x in got)                       # deferred upload
+        toks.append(ops.capture_end())
+        del g
+    assert st["bare_i"] == bare0                                 # the bare pool was not touched
+    used = st["pool_i"] - pool0 + (len(free0) - len(st["free"]))
+    assert used == 15
+    for tok in toks:
+        ops.release_capture(tok)
+    mark = st["pool_i"]
+    ops.capture_begin()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        _ = torch.ones(4, device="cuda") + 1
+        for _ in range(15):
+            t.take(dev)
+    tok = ops.capture_end()
+    assert st["pool_i"] == mark                                  # all fifteen came from the free list
+    ops.release_capture(tok)
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=s):                         # a bare capture: pinned slot + memcpy node path
+        _ = torch.ones(4, device="cuda") + 1
+        h, d, defer, _rel = t.take(dev)
+    assert defer == 0 and st["bare_i"] == bare0 + 1

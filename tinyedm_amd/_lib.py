@@ -70,6 +70,9 @@ SIGNATURES = {
     # attention.hip
     "edm_attention_fwd": [P, P, I, I, I, I, P],
     "edm_attention_bwd": [P, P, P, P, I, I, I, I, P],
+    # attention_fused.hip
+    "edm_attention_qkv_supported": [I, I, I],
+    "edm_attention_qkv_fwd": [P, P, P, P, I, I, I, I, I, P],
     # linear.hip
     "edm_linear_fwd": [P, P, P, I, I, I, P],
     "edm_linear_dgrad": [P, P, P, I, I, I, I, P],
@@ -121,7 +124,7 @@ DIAG_SIGNATURES = {
 _RET = {"edm_last_error": ctypes.c_char_p, "edm_wgrad3_workspace": ctypes.c_long, "edm_wgrad3_table_bytes": ctypes.c_long,
         "edm_conv_wgrad_1x1_group_table_bytes": ctypes.c_long, "edm_wgrad_finish_multi_table_bytes": ctypes.c_long}
 _NO_STATUS = {"edm_version", "edm_graph_replay_safe", "edm_last_error", "edm_conv_wgrad_nsplit", "edm_conv_wgrad_1x1_nsplit", "edm_conv_wgrad_1x1_nsplit_grouped", "edm_wgrad3_workspace", "edm_wgrad3_table_bytes",
-              "edm_conv_wgrad_1x1_group_table_bytes", "edm_wgrad_finish_multi_table_bytes"}
+              "edm_conv_wgrad_1x1_group_table_bytes", "edm_wgrad_finish_multi_table_bytes", "edm_attention_qkv_supported"}
 
 _lib = None
 

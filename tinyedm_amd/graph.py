@@ -69,6 +69,7 @@ class CapturedTrainStep:
     including the host-side counters (Philox step, Adam step, EMA step, weight epoch)."""
 
     WARMUP = 2
+    MAX_GRAPHS = 4      # captured batch shapes kept (least recently used beyond that are released)
 
     def __init__(self, model, optimizer, grad_scale: float = 1.0, reducer=None):
         self.model = model
@@ -91,6 +92,7 @@ class CapturedTrainStep:
         # stream into the capture (unjoined at capture end)
         self.stream = torch.cuda.Stream(self.base.arena.theta.device)
         self._graphs = {}
+        self._seen = {}
         self._calls = 0
         # True once a capture failed on ANY rank of a multi-rank job: every rank then runs the eager step from here on
         # (ranks replaying captured collectives beside a rank that issues none would hang)
@@ -178,14 +180,22 @@ class CapturedTrainStep:
         networks.rng.dyn = self.params.dev
         try:
             ent = self._graphs.get(key)
-            if ent is None and not self.fallback and self._calls >= self.WARMUP:
+            seen = self._seen.get(key, 0)
+            self._seen[key] = seen + 1
+            # (a batch shape is captured on its SECOND visit: its first step runs eagerly so that the plans / scratch of that
+            # shape are allocated outside the capture -- e.g. the ragged last batch of an epoch)
+            if ent is None and not self.fallback and self._calls >= self.WARMUP and seen >= 1:
                 ent = self._capture_agreed(batch)
                 if ent is not None:
+                    while len(self._graphs) >= self.MAX_GRAPHS:      # (dict order = least recently used first)
+                        self._drop(next(iter(self._graphs)))
                     self._graphs[key] = ent
+            elif ent is not None:
+                self._graphs[key] = self._graphs.pop(key)            # most recently used last
             if ent is None:
                 loss = self._eager(batch)          # allocator / plan / stream warm-up before capturing; the fallback
             else:
-                graph, sx, sy, loss = ent
+                graph, sx, sy, loss, _tok = ent
                 sx.copy_(x, non_blocking=True)
                 if sy is not None:
                     sy.copy_(y, non_blocking=True)
@@ -212,6 +222,7 @@ class CapturedTrainStep:
             time.sleep(0.5)
             mode = "thread_local"
         ops.capture_begin()
+        failed = False
         graph = torch.cuda.CUDAGraph()
         # the step is captured as ONE chain: a weight-gradient side branch replays slower than the chain (CIFAR-10:
         # 15.5 vs 15.1 ms) -- hipGraph schedules the branch less favourably than the host's enqueue order does
@@ -227,9 +238,30 @@ class CapturedTrainStep:
         except BaseException:
             if self.reducer is not None:
                 self.reducer.reset()        # pending counts / fired set of the aborted pass
+            failed = True
             raise
         finally:
             networks.WGRAD_STREAM = side
-            ops.capture_end()
+            token = ops.capture_end()
+            if failed:
+                ops.release_capture(token)  # no graph came of it: its launch-table slots are free again
             self._restore(snap)
-        return graph, sx, sy, loss
+        return graph, sx, sy, loss, token
+
+    def _drop(self, key):
+        ent = self._graphs.pop(key, None)
+        if ent is not None:
+            torch.cuda.synchronize()            # no replay of it may still be running when its slots are reused
+            ops.release_capture(ent[4])
+
+    def release(self):
+        """drop every captured graph (their launch-table slots go back to the pool): call when the step object is retired"""
+        for key in list(self._graphs):
+            self._drop(key)
+
+    def __del__(self):
+        try:
+            for ent in self._graphs.values():
+                ops.release_capture(ent[4])
+        except Exception:       # noqa: BLE001  (interpreter shutdown)
+            pass

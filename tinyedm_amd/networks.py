@@ -52,6 +52,7 @@ def manual_seed(seed: int) -> None:
 _WEIGHT_EPOCH = 0
 
 
+_IN_DENOISER = [False]  # a Denoiser forward is running (its plan chose the pack layouts for ITS input shape)
 FORWARD_EPOCH = 0       # grad-enabled Denoiser forwards so far (FusedAdam.zero_grad: "was a gradient written since step()?")
 
 
@@ -77,6 +78,9 @@ class _WNBase(nn.Module):
         self._perm: Optional[Tensor] = None       # packed row -> master row (qkv conv only)
         self._ipad: Optional[int] = None          # zero-padded input channels (conv_in only)
         self._want = ("fwd", "dgrad")
+        self._split_pack = None                   # (taps, O, 3*Ip) bf16 [w_hi | w_lo | w_hi]: the "f32x3" evaluation's operand
+        self._split_key = None
+        self._plain = None                        # plain packs for standalone module calls (see packs())
 
     def _taps(self) -> int:
         return self.weight[0, 0].numel() if self.weight.dim() == 4 else 1
@@ -91,6 +95,16 @@ class _WNBase(nn.Module):
             self._fresh = False
             return self._cache
         key = (w.data_ptr(), w._version, _WEIGHT_EPOCH)
+        if not self.training and not _IN_DENOISER[0] and self._cache is not None and self._cache_key == key and any(
+                getattr(t, "_edm_frag", False) for t in self._cache[:2] if t is not None):
+            # a Denoiser forward at the benchmarked shape left FRAGMENT-MAJOR packs here (the layout of k_conv3x3_s only); a
+            # standalone module call on another shape needs the plain layout: keep a private plain copy beside the plan's
+            if self._plain is None or self._plain[0] != key:
+                with torch.no_grad():
+                    self._plain = (key, ops.weight_prep(w.data, self._taps(), Ipad=self._ipad, want_fwd="fwd" in self._want,
+                                                        want_dgrad="dgrad" in self._want, want_hat="hat" in self._want,
+                                                        perm=self._perm, normalize_inplace=False))
+            return self._plain[1]
         if self.training or self._cache is None or self._cache_key != key:
             perm = self._perm
             if perm is not None and perm.device != w.device:
@@ -294,11 +308,18 @@ class _PrepPlan:
     """Multi-tensor weight preparation: ONE launch normalises and packs every weight of a network
     (edm_weight_prep_multi) into persistent kernel-layout buffers, instead of one launch per layer."""
 
-    def __init__(self, mods, frag=None):
+    def __init__(self, mods, frag=None, wants=None):
         """frag: {module: (fwd, dgrad)} -- the 3x3 convs whose forward / dgrad pack is written FRAGMENT-MAJOR (csrc/weights.hip)
-        because k_conv3x3_s, the 8x8 layers' kernel, runs them at the current input shape (Denoiser._frag_flags)"""
+        because k_conv3x3_s, the 8x8 layers' kernel, runs them at the current input shape (Denoiser._frag_flags).
+        wants: per module, the packs this plan keeps ("fwd", "dgrad", "hat", "split"); default = the module's own.  "split" =
+        the split-bf16 operand of the "f32x3" evaluation, a PERSISTENT buffer rewritten in place by run() (a captured solve
+        holds its address: ADVICE r4)."""
         self.mods = mods
         frag = frag or {}
+        wants = [tuple(m._want) for m in mods] if wants is None else list(wants)
+        self.wants = wants
+        self.pinned = False         # a captured graph reads this plan's buffers: never evicted
+        self.splits = []
         dev = mods[0].weight.device
         self.ptr_key = tuple(m.weight.data_ptr() for m in mods)
         desc = np.zeros(len(mods), dtype=np.dtype([
@@ -311,9 +332,12 @@ class _PrepPlan:
             w = m.weight
             O, I, taps = w.shape[0], w.shape[1], m._taps()
             ipad = I if m._ipad is None else m._ipad
-            wf = torch.empty(taps, O, ipad, device=dev, dtype=bf16) if "fwd" in m._want else None
-            wd = torch.empty(taps, I, O, device=dev, dtype=bf16) if "dgrad" in m._want else None
-            wh = torch.empty(O, I * taps, device=dev, dtype=f32) if "hat" in m._want else None
+            want = wants[k]
+            wf = torch.empty(taps, O, ipad, device=dev, dtype=bf16) if "fwd" in want else None
+            wd = torch.empty(taps, I, O, device=dev, dtype=bf16) if "dgrad" in want else None
+            wh = torch.empty(O, I * taps, device=dev, dtype=f32) if ("hat" in want or "split" in want) else None
+            self.splits.append(torch.empty(taps, O, 3 * ((I + 31) // 32 * 32), device=dev, dtype=bf16)
+                               if "split" in want else None)
             if m._perm is not None and m._perm.device != dev:
                 m._perm = m._perm.to(dev)
             # rows per workgroup: the bf16 tile rb x (I*taps) must fit LDS; power of two <= 32
@@ -348,12 +372,19 @@ class _PrepPlan:
         key = (tuple(m.weight._version for m in self.mods), _WEIGHT_EPOCH)
         if training or key != self.eval_key:
             ops.weight_prep_multi(self.desc, self.groups, self.lds_bytes, training)
+            for m, c, sp in zip(self.mods, self.caches, self.splits):
+                if sp is not None:          # in place: the address a captured f32x3 solve replays with stays valid
+                    ops.split_pack(c[2], m._taps(), out=sp)
             # the in-place normalisation does not go through torch: remember what the packs correspond to
             self.eval_key = None if training else key
-        for m, c in zip(self.mods, self.caches):
+        if torch.cuda.is_current_stream_capturing():
+            self.pinned = True
+        for m, c, sp in zip(self.mods, self.caches, self.splits):
             m._cache = c
             m._cache_key = (m.weight.data_ptr(), m.weight._version, _WEIGHT_EPOCH)
             m._fresh = training
+            m._split_pack = sp
+            m._split_key = m._cache_key if sp is not None else None
 
 
 class Conv2d(_WNBase):
@@ -1000,7 +1031,11 @@ def _conv_f32(mod: "_WNBase", x: Tensor, taps: int, pairs_out: bool = False, **k
     w_hat = mod.packs()[2]
     if _split_ok(mod):
         key = (mod.weight.data_ptr(), mod.weight._version, _WEIGHT_EPOCH)
-        if getattr(mod, "_split_key", None) != key:
+        if mod._split_pack is None or mod._split_key != key:
+            # not under a Denoiser plan (the plan's run() writes its persistent buffer and sets the key): build it here
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("tinyedm_amd: split-bf16 weight pack is stale under stream capture (the plan refreshes "
+                                   "it before the capture: Denoiser._prep_all)")
             mod._split_pack, mod._split_key = ops.split_pack(w_hat, taps), key
         xp = x if x.dtype == bf16 else ops.f32_to_pairs(x)
         return ops.split_conv(xp, mod._split_pack, taps, pairs_out=pairs_out, **kw)
@@ -1408,25 +1443,52 @@ class Denoiser(nn.Module):
             cache[key] = flags
         return cache[key]
 
+    MAX_PLANS = 6       # unpinned plans of the live weights kept per network (least recently used beyond that are dropped)
+
+    def _eff_wants(self, mods):
+        """per module, the packs the current mode needs.  Training and bf16 evaluation: the module's own (_want); the
+        reference-precision evaluation paths add the fp32 effective weight ("hat") and -- "f32x3", the convs the split back
+        end runs -- the persistent split-bf16 pack.  The TRAINING plan's key therefore never changes when a sampling callback
+        switches the evaluation precision for a while (set_eval_dtype used to grow every module's _want for good)."""
+        hat = (not self.training) and self.eval_dtype != "bf16"
+        split = (not self.training) and self.eval_dtype == "f32x3"
+        out = []
+        for m in mods:
+            w = tuple(m._want)
+            if hat and "hat" not in w:
+                w += ("hat",)
+            if split and m.weight.dim() == 4 and m.weight.shape[1] % 32 == 0 and m.weight.shape[0] % 8 == 0:
+                w += ("split",)
+            out.append(w)
+        return tuple(out)
+
     def _prep_all(self, shape=None):
         """One multi-tensor launch for every weight of the U-Net (forced normalisation in training + packs).
-        Plans (the persistent pack buffers) are kept per (weights, wanted packs, fragment-major set) and never freed: a
-        captured step or solve holds the addresses of the plan it was captured with."""
+        Plans (the persistent pack buffers) are kept per (weights, wanted packs, fragment-major set).  A plan that a captured
+        step or solve was recorded with is PINNED (the graph holds its addresses) and stays; of the others, those of weights
+        that no longer exist (re-allocated parameters) are dropped, and at most MAX_PLANS of the live weights are kept."""
         mods = [m for m in self.modules() if isinstance(m, _WNBase)]
         frag = self._frag_flags(*shape) if (shape is not None and FRAG_PACKS) else {}
-        base = (tuple(m.weight.data_ptr() for m in mods), tuple(m._want for m in mods))
+        ptrs = tuple(m.weight.data_ptr() for m in mods)
+        base = (ptrs, self._eff_wants(mods))
         key = base + (tuple((k, v) for k, v in enumerate(frag.get(m) for m in mods) if v),)
         plans = self.__dict__.setdefault("_plans", {})
         if shape is None and not self.training:
             # no shape given (the sampler's refresh before a graph replay, the fp32 evaluation route): every plan of these
-            # weights is brought up to date -- a captured solve reads the packs of the plan of ITS input shape (each
-            # run() is a no-op unless the master weights changed since that plan's last run)
+            # weights and this precision is brought up to date -- a captured solve reads the packs of the plan of ITS input
+            # shape (each run() is a no-op unless the master weights changed since that plan's last run)
             for k, plan in plans.items():
                 if k[:2] == base and k != key:
                     plan.run(False)
-        plan = plans.get(key)
+        plan = plans.pop(key, None)
         if plan is None:
-            plan = plans[key] = _PrepPlan(mods, frag)
+            plan = _PrepPlan(mods, frag, base[1])
+            for k in [k for k, p in plans.items() if k[0] != ptrs and not p.pinned]:
+                del plans[k]                    # packs of parameters that have been re-allocated since
+            live = [k for k, p in plans.items() if not p.pinned]
+            for k in live[:max(0, len(live) + 1 - self.MAX_PLANS)]:
+                del plans[k]                    # (dict order = least recently used first)
+        plans[key] = plan                       # most recently used last
         plan.run(self.training)
 
     # ---- reference-precision evaluation (round 3): the reference samples / validates in fp32 (generate.py:39-44,
@@ -1440,11 +1502,8 @@ class Denoiser(nn.Module):
         dtype = {"float32": "f32", "fp32": "f32", "bfloat16": "bf16", "split": "f32x3"}.get(str(dtype).replace("torch.", ""), str(dtype))
         if dtype not in ("bf16", "f32", "f32x3"):
             raise ValueError("Denoiser.set_eval_dtype: 'bf16', 'f32' (exact fp32 products) or 'f32x3' (split-bf16, fp32-accurate)")
-        if dtype != "bf16":         # every conv also keeps its fp32 effective weight ("hat") from now on
-            for m in self.modules():
-                if isinstance(m, _WNBase) and "hat" not in m._want:
-                    m._want = tuple(m._want) + ("hat",)
-                    m._cache = None
+        # (the evaluation plans keep the fp32 effective weights / split packs: _eff_wants -- the modules' own _want, and with it
+        # the training plan, is left alone)
         self.eval_dtype = dtype
         return self
 
@@ -1467,6 +1526,13 @@ class Denoiser(nn.Module):
         return ops.f32_conv_out(x, self.conv_out.packs()[2], self.gain_out.detach(), noisy, sig, self.sigma_data)
 
     def forward(self, noisy_image: Tensor, sigma: Tensor, embedding: Tensor):
+        prev, _IN_DENOISER[0] = _IN_DENOISER[0], True
+        try:
+            return self._forward(noisy_image, sigma, embedding)
+        finally:
+            _IN_DENOISER[0] = prev
+
+    def _forward(self, noisy_image: Tensor, sigma: Tensor, embedding: Tensor):
         if not noisy_image.is_cuda:
             raise RuntimeError("tinyedm_amd.Denoiser: inputs must be GPU tensors (there is no CPU path)")
         if self.eval_dtype != "bf16" and not self.training:

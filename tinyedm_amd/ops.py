@@ -104,8 +104,15 @@ def capture_begin():
 
 
 def capture_end():
+    """-> token of the launch-table slots the capture took: hand it to release_capture() when the graph is destroyed"""
     _zero_pool.buf = None
-    _tables.end()
+    return _tables.end()
+
+
+def release_capture(token):
+    """the graph captured between the capture_begin() / capture_end() that returned `token` no longer exists: its
+    launch-table slots may be reused by later captures (a long-lived process that re-captures does not grow)"""
+    _tables.release(token)
 
 
 class _LaunchTables:
@@ -118,31 +125,41 @@ class _LaunchTables:
     * Between ops.capture_begin() and ops.capture_end() (graph.CapturedTrainStep): the table of a captured launch never
       changes between replays, so it is uploaded ONCE -- the C side only fills a host buffer (defer_upload), the device
       slot comes from a pool allocated up front, and capture_end() copies all of them before the first replay can run
-      (no memcpy nodes in the graph: nine 4-us copies per replayed step otherwise).
+      (no memcpy nodes in the graph: nine 4-us copies per replayed step otherwise).  capture_end() returns the slots as a
+      token; release_capture(token) puts them on a free list once the graph is gone.
     * A capture made WITHOUT those hooks still works: the copy becomes a memcpy node that every replay executes again from
-      the same host address, so those slots come from a bump-allocated pinned pool that is never reused or freed
-      (allocated up front: pinning memory is not a capturable call)."""
+      the same host address, so those slots come from a bump-allocated pinned pool with ITS OWN index (`bare_i`: deferred
+      captures do not eat into it), never reused or freed (allocated up front: pinning memory is not a capturable call).
+    Per-device state is created by the first EAGER launch (or capture_begin()): creating it under capture would pin memory
+    and hipMalloc inside the capture, so that raises instead."""
     RING, POOL = 64, 512
 
     def __init__(self):
         self.dev = {}
         self.deferring = False
         self.pending = []           # (device tensor, host tensor) pairs to upload at capture_end()
+        self.taken = []             # (device index, slot) of the running deferred capture
 
     def _state(self, device):
         key = torch.device(device).index
         key = torch.cuda.current_device() if key is None else key
         st = self.dev.get(key)
         if st is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("tinyedm_amd: the launch-table pools of this device do not exist yet and cannot be "
+                                   "created under stream capture (pinned + device allocations): run one eager step first, "
+                                   "or bracket the capture with ops.capture_begin() / capture_end()")
             nb = max(int(_lib.call("edm_wgrad3_table_bytes")), int(_lib.call("edm_conv_wgrad_1x1_group_table_bytes")),
                      int(_lib.call("edm_wgrad_finish_multi_table_bytes")))
             nb = (nb + 255) // 256 * 256
             d = torch.device("cuda", key)
             st = self.dev[key] = {
-                "nb": nb, "i": 0, "events": [None] * self.RING,
+                "key": key, "nb": nb, "i": 0, "events": [None] * self.RING,
                 "host": torch.empty(self.RING, nb, dtype=torch.uint8).pin_memory(),
                 "devb": torch.empty(self.RING, nb, dtype=torch.uint8, device=d),
-                "pool": torch.empty(self.POOL, nb, dtype=torch.uint8).pin_memory(), "pool_i": 0,
+                "pool": torch.empty(self.POOL, nb, dtype=torch.uint8).pin_memory(), "bare_i": 0,
+                "bare_devb": torch.empty(self.POOL, nb, dtype=torch.uint8, device=d),
+                "pool_i": 0, "free": [],
                 # device slots for captured launches, allocated HERE (eagerly, ordinary memory): a buffer allocated inside a
                 # capture belongs to the graph's pool and a write to it from outside the graph (the deferred upload) did
                 # not reach what the replayed kernels read -- the first replay hung on a garbage table
@@ -150,27 +167,35 @@ class _LaunchTables:
         return st
 
     def _reserve(self, st, want):
-        """make sure `want` more captured launches find a device slot -- called OUTSIDE capture (capture_begin): a long-lived
-        process that captures again and again (new batch shapes, new models) grows the pool instead of running out"""
-        while len(st["pool_devb"]) * self.POOL - st["pool_i"] < want:
+        """make sure `want` more captured launches find a device slot -- called OUTSIDE capture (capture_begin): a process
+        that holds many live graphs grows the pool instead of running out"""
+        while len(st["free"]) + len(st["pool_devb"]) * self.POOL - st["pool_i"] < want:
             st["pool_devb"].append(torch.empty(self.POOL, st["nb"], dtype=torch.uint8, device=st["devb"].device))
 
     def take(self, device):
         """-> (host pointer, device pointer, defer_upload, release()): call release() right after the launch"""
         st = self._state(device)
         if torch.cuda.is_current_stream_capturing():
-            k = st["pool_i"]
-            if k >= len(st["pool_devb"]) * self.POOL or (not self.deferring and k >= self.POOL):
-                raise RuntimeError("tinyedm_amd: out of launch-table slots for captured graphs (ops._LaunchTables: captures "
-                                   "made between ops.capture_begin() / capture_end() grow the pool; bare captures share "
-                                   f"{self.POOL} pinned slots per process)")
-            st["pool_i"] = k + 1                    # never reused: the graph keeps reading it
-            dev = st["pool_devb"][k // self.POOL][k % self.POOL]
             if self.deferring:
+                if st["free"]:
+                    k = st["free"].pop()
+                else:
+                    k = st["pool_i"]
+                    if k >= len(st["pool_devb"]) * self.POOL:
+                        raise RuntimeError("tinyedm_amd: out of launch-table slots for this capture (more than the 64 "
+                                           "reserved by ops.capture_begin(): ops._LaunchTables._reserve)")
+                    st["pool_i"] = k + 1
+                self.taken.append((st["key"], k))
+                dev = st["pool_devb"][k // self.POOL][k % self.POOL]
                 host = torch.empty(st["nb"], dtype=torch.uint8)
                 self.pending.append((dev, host))
                 return host.data_ptr(), dev.data_ptr(), 1, (lambda: None)
-            return st["pool"][k].data_ptr(), dev.data_ptr(), 0, (lambda: None)
+            k = st["bare_i"]
+            if k >= self.POOL:
+                raise RuntimeError("tinyedm_amd: out of launch-table slots for bare captures (captures made without "
+                                   f"ops.capture_begin() / capture_end() share {self.POOL} pinned slots per process)")
+            st["bare_i"] = k + 1                    # never reused: the graph's memcpy node keeps reading the pinned slot
+            return st["pool"][k].data_ptr(), st["bare_devb"][k].data_ptr(), 0, (lambda: None)
         k = st["i"] % self.RING
         st["i"] += 1
         if st["events"][k] is not None:
@@ -183,17 +208,25 @@ class _LaunchTables:
         return st["host"][k].data_ptr(), st["devb"][k].data_ptr(), 0, release
 
     def begin(self):
-        self.deferring, self.pending = True, []
+        self.deferring, self.pending, self.taken = True, [], []
         if torch.cuda.is_available():
             self._reserve(self._state(torch.cuda.current_device()), 64)     # (a captured training step takes 9)
 
     def end(self):
         """upload the tables of the capture that just ended (their launches have only been recorded so far)"""
         pend, self.pending, self.deferring = self.pending, [], False
+        taken, self.taken = tuple(self.taken), []
         for dev, host in pend:
             dev.copy_(host)
         if pend:
             torch.cuda.synchronize(pend[0][0].device)
+        return taken
+
+    def release(self, token):
+        for key, k in token or ():
+            st = self.dev.get(key)
+            if st is not None and k not in st["free"]:
+                st["free"].append(k)
 
 
 _tables = _LaunchTables()
@@ -1001,6 +1034,29 @@ def attention_bwd(qkv, y, gy, heads):
     return gqkv
 
 
+ATTN_FUSED = os.environ.get("EDM_ATTN_FUSED", "1") != "0"      # qkv projection inside the attention kernels (attention_fused.hip)
+ATTN_HP = int(os.environ.get("EDM_ATTN_HP", "0"))               # heads per workgroup (0 = the kernel's default)
+
+
+def attention_qkv_supported(x, heads):
+    """the fused kernels cover this shape (C = 256, 4 heads of 64, 33..256 tokens)"""
+    B, H, W, C = x.shape
+    return bool(ATTN_FUSED and _lib.call("edm_attention_qkv_supported", H * W, C, heads))
+
+
+def attention_qkv_fwd(x, wf_qkv, heads, want_stat=True):
+    """x (B,H,W,C) bf16, wf_qkv (1, 3C, C) bf16 forward pack of the qkv conv (rows [head][q|k|v][d]) ->
+    y (B,H,W,C) bf16 = cosine attention of qkv_conv(x), stat (B, heads, H*W) fp32 or None (networks.py:193-202)"""
+    B, H, W, C = _nhwc(x, "x")
+    _chk(wf_qkv, bf16, "wf_qkv", (1, 3 * C, C))
+    N = H * W
+    y = torch.empty_like(x)
+    stat = torch.empty(B, heads, N, device=x.device, dtype=f32) if want_stat else None
+    with _prof("attention_qkv_fwd", 2.0 * B * N * C * 3 * C + 4.0 * B * N * N * C, 2.0 * B * N * 2 * C):
+        _lib.call("edm_attention_qkv_fwd", _p(x), _p(wf_qkv), _p(y), _p(stat), B, N, C, heads, ATTN_HP, _stream())
+    return y, stat
+
+
 # ------------------------------------------------------------------ fp32 linears / embedding
 def linear_fwd(x, w):
     _chk(x, f32, "x")
@@ -1203,12 +1259,14 @@ def f32_to_pairs(x):
     return p
 
 
-def split_pack(w_hat, taps):
-    """w_hat (Cout, I*taps) fp32 -> (taps, Cout, 3*Ip) bf16 = [w_hi | w_lo | w_hi], Ip = I rounded up to 32"""
+def split_pack(w_hat, taps, out=None):
+    """w_hat (Cout, I*taps) fp32 -> (taps, Cout, 3*Ip) bf16 = [w_hi | w_lo | w_hi], Ip = I rounded up to 32.
+    out: rewrite this buffer in place (the persistent pack of a weight-prep plan: a captured solve keeps its address)"""
     _chk(w_hat, f32, "w_hat")
     Cout, I = w_hat.shape[0], w_hat.shape[1] // taps
     Ip = (I + 31) // 32 * 32
-    pk = torch.empty(taps, Cout, 3 * Ip, device=w_hat.device, dtype=bf16)
+    pk = torch.empty(taps, Cout, 3 * Ip, device=w_hat.device, dtype=bf16) if out is None else \
+        _chk(out, bf16, "out", (taps, Cout, 3 * Ip))
     _lib.call("edm_split_pack", _p(w_hat), _p(pk), Cout, I, taps, Ip, _stream())
     return pk
 

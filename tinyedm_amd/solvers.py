@@ -14,6 +14,8 @@ class DeterministicSolver:
     host->device copies (63 sync points for 32 steps) disappear, which is what makes the whole
     solve capturable as one hipGraph (``solve(..., graph=True)``)."""
 
+    MAX_GRAPHS = 4      # captured solves kept per model (shape / precision combinations; least recently used dropped)
+
     def __init__(self, num_steps: int = 18, sigma_min: float = 0.002, sigma_max: float = 80.0, rho: float = 7.0,
                  dtype: str | None = None):
         self.num_steps = num_steps
@@ -85,13 +87,23 @@ class DeterministicSolver:
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
             ops.capture_begin()
+            ok = False
             try:
                 with torch.cuda.graph(g):
                     out = self._loop(model, sx, sl, t_dev)
+                ok = True
             finally:
-                ops.capture_end()
-            ent = per_model[key] = (g, sx, sl, out, t_dev)
-        g, sx, sl, out, _ = ent
+                token = ops.capture_end()
+                if not ok:
+                    ops.release_capture(token)
+            while len(per_model) >= self.MAX_GRAPHS:         # (dict order = least recently used first)
+                old = per_model.pop(next(iter(per_model)))
+                torch.cuda.synchronize()
+                ops.release_capture(old[5])
+            ent = per_model[key] = (g, sx, sl, out, t_dev, token)
+        else:
+            per_model[key] = per_model.pop(key)              # most recently used last
+        g, sx, sl, out, _, _ = ent
         # the captured evaluations read the persistent eval-mode weight packs: refresh them (a no-op unless the
         # master weights changed since the last solve: optimizer steps, EMA swap, load_state_dict) before replaying
         if isinstance(model, torch.nn.Module):

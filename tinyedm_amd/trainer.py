@@ -79,11 +79,14 @@ class Trainer:
         self.datamodule = None
         self.callback_metrics: dict = {}
         self._resume_skip = 0          # batches of the first epoch already consumed before the checkpoint was written
-        # EDM_GRAPH=1 (no gradient accumulation; any number of ranks): the step is replayed from a hipGraph.  Off by default: the
-        # step is GPU-bound on every configuration measured (round 2: eager with the weight-gradient side stream
-        # 15.2 / 18.2 / 146 ms vs replay 15.1 / 18.2 / 154 ms on CIFAR-10 / MNIST / ImageNet-64), so the replay only
-        # pays on a slower host
-        self.use_graph = os.environ.get("EDM_GRAPH", "0") != "0"
+        # The step is replayed from a hipGraph (graph.CapturedTrainStep) whenever that is possible: no gradient accumulation,
+        # the flat-arena optimizer, and the safe runtime setting in place (_runtime_env).  Round 5: this is the DEFAULT on one
+        # GPU -- the replay is 3 % faster than the eager loop since the step dropped below the host's ~10 ms of enqueue
+        # (13.16 vs 13.56 ms, BENCH_r04), and it is what bench.py times.  EDM_GRAPH=0 opts out; with more than one rank the
+        # captured step (RCCL nodes inside the graph) has only ever run with a forced single rank, so it stays opt-in there
+        # (EDM_GRAPH=1) until a multi-GPU node has seen it.
+        env = os.environ.get("EDM_GRAPH")
+        self.use_graph = (self.world_size == 1) if env is None else env != "0"
 
     # ------------------------------------------------------------------ setup
     def _setup_distributed(self, model):
