@@ -197,6 +197,14 @@ int edm_attention_bwd(const void* qkv, const void* y, const void* gy, void* gqkv
 int edm_attention_qkv_supported(int N, int C, int heads);
 int edm_attention_qkv_fwd(const void* x, const void* Wqkv, void* y, void* stat, int B, int N, int C, int heads,
                           int heads_per_wg, edm_stream_t stream);
+/* its backward (autograd of networks.py:193-205 up to the projections' own GEMMs): gqkv [B*N, 3C] bf16, packed channel order,
+ * = d loss / d qkv_conv(x) from gout = d loss / d out_conv(y) [B*N, C].  dO = alpha * gout . W_out is formed inside from
+ * Wd_out = the out conv's dgrad pack [C, C] (alpha = the mp_add coefficient of the attention branch); q, k, v are recomputed
+ * from x and Wqkv; y, stat = the forward's outputs.  The callers' remaining launches: the qkv conv's dgrad (gx) and the two
+ * weight gradients. */
+int edm_attention_qkv_bwd(const void* x, const void* y, const void* gout, const void* stat, const void* Wqkv,
+                          const void* Wd_out, void* gqkv, float alpha, int B, int N, int C, int heads, int heads_per_wg,
+                          edm_stream_t stream);
 
 /* ---------------------------------------------------------------- per-pixel / elementwise */
 /* pixel_norm over C + mp_silu (networks.py:9-14, 83-84, 249-252); dsave[p] = eps + |x_p|/sqrt(C) */

@@ -78,3 +78,44 @@ def test_attention_qkv_fwd_extreme_logits(ops):
     y, stat = ops.attention_qkv_fwd(nhwc(x), wf, heads)
     assert torch.isfinite(stat).all()
     close_bf16(nchw(y), y_ref, l2=6e-3, mx=3e-2)
+
+
+def pack_dgrad_1x1(w):
+    """(O, I) effective weight -> dgrad pack (1, I, O) bf16"""
+    return w.t().contiguous().view(1, w.shape[1], w.shape[0]).to(torch.bfloat16).to(DEV)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 16, 16), (3, 8, 8), (9, 8, 8), (1, 14, 14), (2, 7, 7), (2, 6, 11), (17, 16, 16)])
+def test_attention_qkv_bwd(ops, B, H, W):
+    """gqkv of the fused backward (q, k, v recomputed from x; dO = alpha * gout . W_out formed inside) against autograd of
+    the restated algorithm with the same rounding points, and against the unfused kernel sequence on the same operands."""
+    heads, C, alpha = 4, 256, 0.7071
+    if not ops._lib.call("edm_attention_qkv_supported", H * W, C, heads):
+        pytest.skip("shape not covered by the fused kernel")
+    g = torch.Generator().manual_seed(B * 100 + H + W + 1)
+    x = q(torch.randn(B, C, H, W, generator=g))
+    w = q(torch.randn(3 * C, C, generator=g) / math.sqrt(C))
+    wo = q(torch.randn(C, C, generator=g) / math.sqrt(C))
+    gout = q(torch.randn(B, C, H, W, generator=g))
+    # reference: d loss / d qkv with dO = bf16(alpha * W_out^T gout)
+    d, N = C // heads, H * W
+    qkv = O.q_bf16(torch.einsum("oc,bchw->bohw", w.double(), x.double())).detach().requires_grad_(True)
+    t = O.q_bf16(O.rms_div(qkv.view(B, heads, d, 3, N), [2]))
+    qq, kk, vv = t.unbind(3)
+    s = torch.einsum("bhdi,bhdj->bhij", qq, kk) / math.sqrt(d)
+    p = O.q_bf16(torch.softmax(s, dim=-1))
+    y_ref = torch.einsum("bhij,bhdj->bhdi", p, vv).reshape(B, C, H, W)
+    gy = O.q_bf16(alpha * torch.einsum("oc,bohw->bchw", wo.double(), gout.double()))
+    y_ref.backward(gy)
+    perm = _qkv_perm(C, heads)
+    wf = w[perm].view(1, 3 * C, C).contiguous().to(torch.bfloat16).to(DEV)
+    wd_out = pack_dgrad_1x1(wo)
+    y, stat = ops.attention_qkv_fwd(nhwc(x), wf, heads)
+    gqkv = ops.attention_qkv_bwd(nhwc(x), y, nhwc(gout), stat, wf, wd_out, heads, alpha=alpha)
+    close_bf16(nchw(gqkv), qkv.grad[:, perm], l2=1.5e-2, mx=6e-2)
+    # the unfused sequence (1x1 conv, attention.hip fwd / bwd, 1x1 dgrad) on the same operands
+    qkv_u = ops.conv_igemm(nhwc(x), wf, 1)
+    y_u = ops.attention_fwd(qkv_u, heads)
+    gy_u = ops.conv_igemm(nhwc(gout), wd_out, 1, alpha=alpha)
+    gqkv_u = ops.attention_bwd(qkv_u, y_u, gy_u, heads)
+    assert rel(nchw(gqkv), nchw(gqkv_u)) < 1.2e-2

@@ -73,6 +73,7 @@ SIGNATURES = {
     # attention_fused.hip
     "edm_attention_qkv_supported": [I, I, I],
     "edm_attention_qkv_fwd": [P, P, P, P, I, I, I, I, I, P],
+    "edm_attention_qkv_bwd": [P, P, P, P, P, P, P, F, I, I, I, I, I, P],
     # linear.hip
     "edm_linear_fwd": [P, P, P, I, I, I, P],
     "edm_linear_dgrad": [P, P, P, I, I, I, I, P],

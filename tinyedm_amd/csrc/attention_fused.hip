@@ -28,6 +28,15 @@ typedef __attribute__((ext_vector_type(4))) short short4v;
 typedef __attribute__((ext_vector_type(8))) short short8v;
 typedef short4v __attribute__((address_space(3))) * lds_s4p;
 
+#ifdef EDM_AF_TIMELINE   // diagnostic build only (tools/af_timeline.py): per-wave timestamps of the kernels' phases
+__device__ unsigned long long* g_af_timeline = nullptr;
+#define AF_STAMP(slot)                                                                                       \
+  if (g_af_timeline && (threadIdx.x & 63) == 0)                                                              \
+    g_af_timeline[((long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define AF_STAMP(slot)
+#endif
+
 constexpr int D = 64, C = 256;
 constexpr int RS = 2 * D + 16;          // padded image row (bytes): conflict-free ds_read_b128 / ds_write_b128 at a row per lane
 constexpr int KC = 32;                  // channels per streamed weight chunk
@@ -71,31 +80,38 @@ __device__ __forceinline__ f32x16 score_tile(const char* a_rows, const bf16x8 (&
 }
 
 // ---- streamed GEMM  acc[rb] (32 rows x 32 tokens) = Wrows[rb*32 .., 0..255] . X^T   for NRB row blocks
-// The ROWS rows x 256 channels of the A operand go through the LDS ring in NCH chunks of 32 channels (64-byte rows,
-// 16-byte pieces XOR-swizzled with (row >> 2) & 3 on the DMA source and on the fragment read: conv_igemm2.hip's layout).
-// Chunks are numbered by a counter `t` that runs across calls (ring slot t % 3): a call may find its first two chunks
-// already in flight (issued by the previous call's tail) and issues the first two of `next` (nullptr: none) in its own tail.
-template <int NT, int NRB>
+// The ROWS rows x 256 channels of the A operand go through an LDS ring in chunks of KCB channels by LDS-DMA.  KCB = 32:
+// 64-byte rows, 16-byte pieces XOR-swizzled with (row >> 2) & 3 on the DMA source and on the fragment read
+// (conv_igemm2.hip's layout); KCB = 64: 128-byte rows, swizzle row & 7.  A ring slot is SLOTB bytes (>= ROWS * 2 * KCB).
+template <int NT, int NRB, int KCB, int SLOTB_>
 struct Streamed {
   static constexpr int ROWS = NRB * 32;
-  static constexpr int SLOTS = ROWS / 16;            // 1-KiB DMA instructions per chunk
-  static constexpr int SLOTB = ROWS * WROWB;         // bytes of a ring slot
+  static constexpr int ROWB = KCB * 2;               // bytes of an LDS row
+  static constexpr int RPS = 1024 / ROWB;            // rows per 1-KiB DMA instruction
+  static constexpr int SLOTS = ROWS / RPS;           // DMA instructions per chunk
+  static constexpr int SLOTB = SLOTB_;
   static constexpr int PER_WAVE = (SLOTS + NT - 1) / NT;
+  static constexpr int PPR = ROWB / 16;              // 16-byte pieces per row
+  static_assert(SLOTB_ >= ROWS * ROWB, "ring slot too small");
+
+  static __device__ __forceinline__ int swz(int row) { return KCB == 32 ? ((row >> 2) & 3) : (row & 7); }
 
   // wave `wave` issues its share of chunk kc of the rows starting at `wrows` (row stride C elements) into ring slot `slot`
-  static __device__ __forceinline__ void issue(const bf16* wrows, int kc, char* ring, int slot, int wave, int lane,
-                                               const bf16* zeros) {
-    const int drow = lane >> 2, dp = lane & 3;
+  static __device__ __forceinline__ void issue(const bf16* wrows, int kc, char* ring, int slot, int wave, int lane) {
+    const int drow = lane / PPR, dp = lane % PPR;
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
       const int s = wave + NT * i;
       if (SLOTS % NT == 0 || s < SLOTS) {
-        const int row = s * 16 + drow;
-        const int c = dp ^ ((row >> 2) & 3);
-        dma16(wrows + (long)row * C + kc * KC + c * 8, ring + slot * SLOTB + s * 1024);
+        const int row = s * RPS + drow;
+        const int c = dp ^ swz(row);
+        dma16(wrows + (long)row * C + kc * KCB + c * 8, ring + slot * SLOTB + s * 1024);
       }
     }
-    (void)zeros;
+  }
+  // byte offset (inside a ring slot) of the fragment of k-step s (16 channels) for the lane's row of row block 0
+  static __device__ __forceinline__ int frag_off(int l31, int lhi, int s) {
+    return l31 * ROWB + (((2 * s + lhi) ^ swz(l31)) << 4);
   }
   // leave the chunk issued AFTER the one being retired in flight (`more`), or drain
   static __device__ __forceinline__ void retire(bool more, int wave) {
@@ -110,6 +126,8 @@ struct Streamed {
   }
 };
 
+constexpr int QKV_SLOTB = 192 * 64;                  // ring slot of the qkv projection (192 rows x 32 channels)
+
 template <int NT>
 __global__ __launch_bounds__(NT * 64) void k_attn_qkv_fwd(const bf16* __restrict__ x, const bf16* __restrict__ Wqkv,
                                                             bf16* __restrict__ y, float* __restrict__ stat,
@@ -117,7 +135,7 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_fwd(const bf16* __restrict
                                                             int HP) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NP = NT * 32;
-  using G = Streamed<NT, 6>;
+  using G = Streamed<NT, 6, KC, QKV_SLOTB>;
   char* Kn = smem;
   char* Vn = Kn + NP * RS;
   char* ring = Vn + NP * RS;
@@ -131,24 +149,19 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_fwd(const bf16* __restrict
   const int tok = wave * 32 + l31;
   const bool tvalid = tok < N;
 
+  AF_STAMP(0);
   // ---- the wave's token block as B fragments: bx[kk] = x[tok][16 kk + 8 lhi .. +8]
   bf16x8 bx[C / 16];
   {
-    const bf16* xr = x + ((long)b * N + (tvalid ? tok : 0)) * C + lhi * 8;
+    const bf16* xr = (tvalid ? x + ((long)b * N + tok) * C : zeros) + lhi * 8;      // (padding tokens read the zero page)
 #pragma unroll
     for (int kk = 0; kk < C / 16; ++kk) bx[kk] = *reinterpret_cast<const bf16x8*>(xr + kk * 16);
-    if (!tvalid) {
-#pragma unroll
-      for (int kk = 0; kk < C / 16; ++kk) bx[kk] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
   }
   const int head0 = hg * HP;
-  G::issue(Wqkv + (long)head0 * 3 * D * C, 0, ring, 0, wave, lane, zeros);
-  G::issue(Wqkv + (long)head0 * 3 * D * C, 1, ring, 1, wave, lane, zeros);
+  G::issue(Wqkv + (long)head0 * 3 * D * C, 0, ring, 0, wave, lane);
+  G::issue(Wqkv + (long)head0 * 3 * D * C, 1, ring, 1, wave, lane);
 
-  const int a_sw = (l31 >> 2) & 3;
-  const int a_off0 = l31 * WROWB + (((0 + lhi) ^ a_sw) << 4);
-  const int a_off1 = l31 * WROWB + (((2 + lhi) ^ a_sw) << 4);
+  const int a_off0 = G::frag_off(l31, lhi, 0), a_off1 = G::frag_off(l31, lhi, 1);
   const float sl2 = 0.125f * LOG2E, c0 = 8.0f * LOG2E;       // p = exp2(s * sl2 - c0) = exp(s / sqrt(d) - 8)
   const bool full = N == NP;
   const int tr_row = (lane & 15) >> 2;
@@ -173,27 +186,30 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_fwd(const bf16* __restrict
       {                                                        // chunk t+2: its slot was last read before this barrier
         int sl = base + (kc + 2) % WRING;
         sl -= sl >= WRING ? WRING : 0;
-        if (kc + 2 < NCH) G::issue(wrows, kc + 2, ring, sl, wave, lane, zeros);
-        else if (next_head) G::issue(wrows + (long)3 * D * C, kc + 2 - NCH, ring, sl, wave, lane, zeros);
+        if (kc + 2 < NCH) G::issue(wrows, kc + 2, ring, sl, wave, lane);
+        else if (next_head) G::issue(wrows + (long)3 * D * C, kc + 2 - NCH, ring, sl, wave, lane);
       }
       int cur = base + kc % WRING;
       cur -= cur >= WRING ? WRING : 0;
       const char* wt = ring + cur * G::SLOTB;
-      // all twelve fragment reads of the chunk are issued before its first MFMA (left to itself hipcc keeps ONE read in
-      // flight: ds_read -> lgkmcnt(0) -> MFMA, twelve exposed LDS round trips per chunk)
-      bf16x8 fa[6], fb[6];
+      // six fragment reads in flight before the chunk's first MFMA (left to itself hipcc keeps ONE read in flight:
+      // ds_read -> lgkmcnt(0) -> MFMA, twelve exposed LDS round trips per chunk)
+      bf16x8 fa[6];
 #pragma unroll
       for (int rb = 0; rb < 6; ++rb) fa[rb] = ld128(wt + rb * 32 * WROWB + a_off0);
-#pragma unroll
-      for (int rb = 0; rb < 6; ++rb) fb[rb] = ld128(wt + rb * 32 * WROWB + a_off1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int rb = 0; rb < 6; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rb], bx[2 * kc], acc[rb], 0, 0, 0);
+      for (int rb = 0; rb < 6; ++rb) {               // the second k-step's read goes out right behind the MFMA of the first
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rb], bx[2 * kc], acc[rb], 0, 0, 0);
+        fa[rb] = ld128(wt + rb * 32 * WROWB + a_off1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int rb = 0; rb < 6; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[rb], bx[2 * kc + 1], acc[rb], 0, 0, 0);
+      for (int rb = 0; rb < 6; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rb], bx[2 * kc + 1], acc[rb], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     base = (base + NCH) % WRING;
+    if (hi == 0) { AF_STAMP(1); }
 
     // ---- pixel norm of q, k, v over the 64 channels of the token on this lane (networks.py:195), bf16 rounding points of
     // the unfused path: the conv output, then the normalised value
@@ -235,6 +251,7 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_fwd(const bf16* __restrict
       }
     }
     __syncthreads();
+    if (hi == 0) { AF_STAMP(2); }
 
     // ---- streamed attention for the wave's 32 queries
     float l = 0.f;
@@ -269,6 +286,7 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_fwd(const bf16* __restrict
     }
     l += __shfl_xor(l, 32, 64);
     const float linv = 1.0f / l;
+    if (hi == 0) { AF_STAMP(3); }
     if (tvalid) {
       bf16* dst = y + ((long)b * N + tok) * C + head * D;
 #pragma unroll
@@ -284,10 +302,14 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_fwd(const bf16* __restrict
     }
     // (the next head's K / V writes come after NCH more barriers: every wave has left this head's attention by then)
   }
+#ifdef EDM_AF_TIMELINE
+  __builtin_amdgcn_s_waitcnt(0);
+  AF_STAMP(4);
+#endif
 }
 
 template <int NT>
-size_t lds_fwd() { return (size_t)2 * NT * 32 * RS + (size_t)WRING * Streamed<NT, 6>::SLOTB; }
+size_t lds_fwd() { return (size_t)2 * NT * 32 * RS + (size_t)WRING * QKV_SLOTB; }
 
 template <int NT>
 void launch_fwd(const void* x, const void* Wqkv, void* y, float* stat, int B, int N, int heads, int HP, hipStream_t st) {
@@ -299,7 +321,373 @@ void launch_fwd(const void* x, const void* Wqkv, void* y, float* stat, int B, in
                      (const bf16*)edm_zero_page(), B, N, heads, HP);
 }
 
+
+// ====================================================================================================================
+// backward: gqkv (packed order [head][q|k|v][d]) from x, y, gout -- the qkv tensor and dO = b * gout . W_out are rebuilt
+// in registers / LDS.  Per head: (B) dO^T = alpha * Wd_out[64 h .. +64, :] . gout^T through the ring (64-channel chunks),
+// delta = <dO, O>; (A) q, k, v as in the forward; images of Qn, Kn, Vn, dO (channel order) + the norm denominators in
+// LDS; then attention.hip's two passes (query-major: dQ; key-major: dK, dV), with the forward's saved normaliser instead
+// of a softmax sweep.  The ring shares the Q image's region: Qn is written after the last chunk has been consumed.
+// ====================================================================================================================
+
+// dx = (g - xn*<g,xn>*d/(D*(d-eps)))/d for one token per lane, g given as O^T-style accumulators
+__device__ __forceinline__ void norm_bwd_store(f32x16 (&g)[D / 32], const char* xn_row, float dn, bf16* dst, int lhi,
+                                               bool valid) {
+  float xn[D / 32][16];
+  float dot = 0.f;
+#pragma unroll
+  for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      bf16x4 v = *reinterpret_cast<const bf16x4*>(xn_row + (dt * 32 + 8 * gq + 4 * lhi) * 2);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        xn[dt][4 * gq + r] = (float)v[r];
+        dot += g[dt][4 * gq + r] * xn[dt][4 * gq + r];
+      }
+    }
+  dot += __shfl_xor(dot, 32, 64);
+  const float s = dn - NORM_EPS;
+  const float coef = s > 0.f ? dot * dn / ((float)D * s) : 0.f;
+  const float inv = 1.0f / dn;
+  if (valid) {
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16)((g[dt][4 * gq + r] - xn[dt][4 * gq + r] * coef) * inv);
+        *reinterpret_cast<bf16x4*>(dst + dt * 32 + 8 * gq + 4 * lhi) = o;
+      }
+  }
+}
+
+// a 32-channel x 32-token accumulator block -> rows of a channel-ordered LDS image (lane = token; 8-byte pieces)
+__device__ __forceinline__ void image_store(char* img_row, int rb, int lhi, const f32x16& a) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    bf16x4 v4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v4[r] = (bf16)a[4 * g + r];
+    *reinterpret_cast<bf16x4*>(img_row + (32 * rb + 8 * g + 4 * lhi) * 2) = v4;
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict__ x, const bf16* __restrict__ y,
+                                                            const bf16* __restrict__ gout, const float* __restrict__ stat,
+                                                            const bf16* __restrict__ Wqkv, const bf16* __restrict__ Wdo,
+                                                            bf16* __restrict__ gqkv, const bf16* __restrict__ zeros,
+                                                            float alpha, int B, int N, int heads, int HP) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NP = NT * 32;
+  using GA = Streamed<NT, 6, KC, QKV_SLOTB>;       // qkv rows, 32-channel chunks
+  using GB = Streamed<NT, 2, 64, QKV_SLOTB>;       // the head's 64 rows of the out conv's dgrad pack, 64-channel chunks
+  constexpr int NCHB = C / 64;
+  constexpr int QREG = (NP * RS > WRING * QKV_SLOTB) ? NP * RS : WRING * QKV_SLOTB;
+  char* Qn = smem;
+  char* ring = smem;
+  char* Kn = Qn + QREG;
+  char* Vn = Kn + NP * RS;
+  char* dO = Vn + NP * RS;
+  // LDS: [ring | Qn] Kn Vn dO stats -- the ring shares the Q image's region (Qn is written after the last chunk was read)
+  float* dsave = reinterpret_cast<float*>(dO + NP * RS);     // [3][NP]
+  float* st_l = dsave + 3 * NP;                               // [NP] softmax normaliser (forward's)
+  float* st_d = st_l + NP;                                    // [NP] delta = <dO, O>
+  const int groups = heads / HP;
+  const int id = blockIdx.x, xcd = id & 7, kk_ = id >> 3;
+  const int b = (kk_ / groups) * 8 + xcd, hg = kk_ % groups;
+  if (b >= B) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int tok = wave * 32 + l31;
+  const bool tvalid = tok < N;
+  const long trow = (long)b * N + tok;
+  const float scale = 0.125f;
+  const float sl2 = 0.125f * LOG2E, c0 = 8.0f * LOG2E;
+  const bool full = N == NP;
+  const int tr_row = (lane & 15) >> 2;
+  const int tr_col = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  const int a_off0 = GA::frag_off(l31, lhi, 0), a_off1 = GA::frag_off(l31, lhi, 1);
+
+  {
+    // ONE head per workgroup (HP = 1): with a loop over heads hipcc hoists ~1 400 instructions of loop-invariant address
+    // arithmetic in front of it and spills 43 registers of it
+    const int head = hg;
+    AF_STAMP(0);
+    // ---- operands of both projections as B fragments (token on the lane), the head's slice of y for delta
+    bf16x8 bg[C / 16], bx[C / 16];
+    bf16x4 yv[2][4];
+    {
+      const bf16* gr = (tvalid ? gout + trow * C : zeros) + lhi * 8;                  // (padding tokens read the zero page)
+      const bf16* yr = (tvalid ? y + trow * C + head * D : zeros) + 4 * lhi;
+#pragma unroll
+      for (int kk = 0; kk < C / 16; ++kk) bg[kk] = *reinterpret_cast<const bf16x8*>(gr + kk * 16);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) yv[dt][g] = *reinterpret_cast<const bf16x4*>(yr + dt * 32 + 8 * g);
+    }
+    const bf16* wdo = Wdo + (long)head * D * C;
+    const bf16* wrows = Wqkv + (long)head * 3 * D * C;
+    // chunk counter t: 0 .. NCHB-1 = phase B, NCHB .. NCHB+NCH-1 = phase A; ring slot t % 3
+    GB::issue(wdo, 0, ring, 0, wave, lane);
+    GB::issue(wdo, 1, ring, 1, wave, lane);
+
+    // ---- phase B: dO^T (64 channels x 32 tokens) = alpha * Wd_out rows . gout^T
+    f32x16 ad[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ad[rb][r] = 0.f;
+    // vmcnt order of a head: [bg, y] GB0 GB1 | t=0: GB2 | t=1: GB3 | t=2: GA0, x (16 loads) | t=3: GA1 | phase A ...
+    // (the x fragments of phase A are fetched under phase B's tail: the counted waits of t = 3 and kc = 0 step over them)
+    static_assert(NCHB == 4, "the wait counts below are written for four 64-channel chunks");
+#pragma unroll
+    for (int t = 0; t < NCHB; ++t) {
+      if (t < 3) {
+        GB::retire(true, wave);
+      } else {                                       // outstanding: GB3, GA0, x*16
+        if (GA::SLOTS % NT == 0) wait_vmcnt<GA::SLOTS / NT + 16>();
+        else if (wave < GA::SLOTS % NT) wait_vmcnt<GA::PER_WAVE + 16>();
+        else wait_vmcnt<GA::PER_WAVE - 1 + 16>();
+      }
+      __builtin_amdgcn_s_barrier();
+      if (t + 2 < NCHB) GB::issue(wdo, t + 2, ring, (t + 2) % WRING, wave, lane);
+      else GA::issue(wrows, t + 2 - NCHB, ring, (t + 2) % WRING, wave, lane);
+      if (t == 2) {
+        const bf16* xr = (tvalid ? x + trow * C : zeros) + lhi * 8;
+#pragma unroll
+        for (int kk = 0; kk < C / 16; ++kk) bx[kk] = *reinterpret_cast<const bf16x8*>(xr + kk * 16);
+      }
+      const char* wt = ring + (t % WRING) * QKV_SLOTB;
+      bf16x8 f[2];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) f[rb] = ld128(wt + rb * 32 * GB::ROWB + GB::frag_off(l31, lhi, 0));
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          ad[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[rb], bg[4 * t + s], ad[rb], 0, 0, 0);
+          if (s + 1 < 4) f[rb] = ld128(wt + rb * 32 * GB::ROWB + GB::frag_off(l31, lhi, s + 1));
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    AF_STAMP(1);
+    // dO rounded like the unfused path's gy (a bf16 tensor) -> its LDS image (channel order); delta = <dO, O>
+    float delta = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 v4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bf16 v = (bf16)(ad[dt][4 * g + r] * alpha);
+          v4[r] = v;
+          delta += (float)v * (float)yv[dt][g][r];
+        }
+        *reinterpret_cast<bf16x4*>(dO + tok * RS + (32 * dt + 8 * g + 4 * lhi) * 2) = v4;
+      }
+    delta += __shfl_xor(delta, 32, 64);
+    if (lhi == 0) {
+      st_d[tok] = delta;
+      st_l[tok] = tvalid ? stat[((long)b * heads + head) * N + tok] : 0.f;
+    }
+
+    // ---- phase A: q, k, v of the head (as the forward)
+    f32x16 acc[6];
+#pragma unroll
+    for (int rb = 0; rb < 6; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < NCH; ++kc) {
+      constexpr int T0 = NCHB;
+      if (kc == 0) {                                 // outstanding: GA0, x*16, GA1
+        if (GA::SLOTS % NT == 0) wait_vmcnt<GA::SLOTS / NT + 16>();
+        else if (wave < GA::SLOTS % NT) wait_vmcnt<GA::PER_WAVE + 16>();
+        else wait_vmcnt<GA::PER_WAVE - 1 + 16>();
+      } else {
+        GA::retire(kc + 1 < NCH, wave);
+      }
+      __builtin_amdgcn_s_barrier();
+      if (kc + 2 < NCH) GA::issue(wrows, kc + 2, ring, (T0 + kc + 2) % WRING, wave, lane);
+      const char* wt = ring + ((T0 + kc) % WRING) * QKV_SLOTB;
+      // six fragment registers: the second k-step's read of a row block is issued right behind the MFMA that consumed the first
+      bf16x8 fa[6];
+#pragma unroll
+      for (int rb = 0; rb < 6; ++rb) fa[rb] = ld128(wt + rb * 32 * WROWB + a_off0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int rb = 0; rb < 6; ++rb) {
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rb], bx[2 * kc], acc[rb], 0, 0, 0);
+        fa[rb] = ld128(wt + rb * 32 * WROWB + a_off1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int rb = 0; rb < 6; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rb], bx[2 * kc + 1], acc[rb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    AF_STAMP(2);
+    // every wave must be past its last ring read before the Q image overwrites the ring
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+      float ss = 0.f;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = rbf(acc[2 * w + rb][r]);
+          acc[2 * w + rb][r] = v;
+          ss += v * v;
+        }
+      ss += __shfl_xor(ss, 32, 64);
+      const float dn = NORM_EPS + sqrtf(ss) * 0.125f;
+      const float inv = 1.0f / dn;
+      if (lhi == 0) dsave[w * NP + tok] = dn;
+      char* img = (w == 0 ? Qn : w == 1 ? Kn : Vn) + tok * RS;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[2 * w + rb][r] *= inv;
+        image_store(img, rb, lhi, acc[2 * w + rb]);
+      }
+    }
+    __syncthreads();
+
+    AF_STAMP(3);
+    // ================= pass 1: query-major -> dQ =================
+    {
+      const int qi = tok;
+      bf16x8 bq[D / 16], bdo[D / 16];
+#pragma unroll
+      for (int s = 0; s < D / 16; ++s) {
+        bq[s] = ld128(Qn + qi * RS + s * 32 + lhi * 16);
+        bdo[s] = ld128(dO + qi * RS + s * 32 + lhi * 16);
+      }
+      const float ls = st_l[qi] * scale;
+      const float dlt = st_d[qi];
+      f32x16 accq[D / 32];
+#pragma unroll
+      for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accq[dt][r] = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+        f32x16 S = score_tile(Kn + (kt * 32 + l31) * RS + lhi * 16, bq);
+        f32x16 dP = score_tile(Vn + (kt * 32 + l31) * RS + lhi * 16, bdo);   // dP^T tile: keys x queries
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float p = __builtin_amdgcn_exp2f(fmaf(S[r], sl2, -c0));
+          if (!full) {
+            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            p = key < N ? p : 0.f;
+          }
+          dP[r] = p * ls * (dP[r] - dlt);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 ds = pack8(dP, s2);
+          const int row0 = kt * 32 + 16 * s2 + 4 * lhi + tr_row;
+#pragma unroll
+          for (int dt = 0; dt < D / 32; ++dt) {
+            const char* p0 = Kn + row0 * RS + dt * 64 + tr_col;
+            accq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(p0, p0 + 8 * RS), ds, accq[dt], 0, 0, 0);
+          }
+        }
+      }
+      norm_bwd_store(accq, Qn + qi * RS, dsave[0 * NP + qi], gqkv + ((long)b * N + qi) * 3 * C + head * 3 * D, lhi, tvalid);
+    }
+    AF_STAMP(4);
+    // ================= pass 2: key-major -> dK, dV =================
+    {
+      const int ki = tok;
+      bf16x8 bk[D / 16], bv[D / 16];
+#pragma unroll
+      for (int s = 0; s < D / 16; ++s) {
+        bk[s] = ld128(Kn + ki * RS + s * 32 + lhi * 16);
+        bv[s] = ld128(Vn + ki * RS + s * 32 + lhi * 16);
+      }
+      f32x16 acck[D / 32], accv[D / 32];
+#pragma unroll
+      for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acck[dt][r] = 0.f;
+          accv[dt][r] = 0.f;
+        }
+#pragma unroll 1
+      for (int qt = 0; qt < NT; ++qt) {
+        // S tile: rows = queries (registers), cols = keys (lane)
+        f32x16 S = score_tile(Qn + (qt * 32 + l31) * RS + lhi * 16, bk);
+        f32x16 dP = score_tile(dO + (qt * 32 + l31) * RS + lhi * 16, bv);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int q0 = qt * 32 + 8 * g + 4 * lhi;
+          const f32x4 ll = *reinterpret_cast<const f32x4*>(st_l + q0);
+          const f32x4 dd = *reinterpret_cast<const f32x4*>(st_d + q0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float p = __builtin_amdgcn_exp2f(fmaf(S[4 * g + r], sl2, -c0)) * ll[r];
+            if (!full) p = tvalid ? p : 0.f;
+            S[4 * g + r] = p;
+            dP[4 * g + r] = p * scale * (dP[4 * g + r] - dd[r]);
+          }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pb = pack8(S, s2), ds = pack8(dP, s2);
+          const int row0 = qt * 32 + 16 * s2 + 4 * lhi + tr_row;
+#pragma unroll
+          for (int dt = 0; dt < D / 32; ++dt) {
+            const char* p0 = dO + row0 * RS + dt * 64 + tr_col;
+            accv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(p0, p0 + 8 * RS), pb, accv[dt], 0, 0, 0);
+            const char* p1 = Qn + row0 * RS + dt * 64 + tr_col;
+            acck[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(p1, p1 + 8 * RS), ds, acck[dt], 0, 0, 0);
+          }
+        }
+      }
+      bf16* dst = gqkv + ((long)b * N + ki) * 3 * C + head * 3 * D;
+      norm_bwd_store(acck, Kn + ki * RS, dsave[1 * NP + ki], dst + D, lhi, tvalid);
+      AF_STAMP(5);
+      norm_bwd_store(accv, Vn + ki * RS, dsave[2 * NP + ki], dst + 2 * D, lhi, tvalid);
+    }
+  }
+#ifdef EDM_AF_TIMELINE
+  __builtin_amdgcn_s_waitcnt(0);
+  AF_STAMP(6);
+#endif
+}
+
+template <int NT>
+size_t lds_bwd() {
+  const size_t img = (size_t)NT * 32 * RS, ringb = (size_t)WRING * QKV_SLOTB;
+  return 3 * img + (img > ringb ? img : ringb) + (size_t)5 * NT * 32 * sizeof(float);
+}
+
+template <int NT>
+void launch_bwd(const void* x, const void* y, const void* gout, const void* stat, const void* Wqkv, const void* Wdo, void* gqkv,
+                float alpha, int B, int N, int heads, int HP, hipStream_t st) {
+  auto kern = k_attn_qkv_bwd<NT>;
+  EDM_MAX_LDS(kern, 160 * 1024);
+  const int groups = heads / HP;
+  const int grid = ((B + 7) / 8) * 8 * groups;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT * 64), lds_bwd<NT>(), st, (const bf16*)x, (const bf16*)y, (const bf16*)gout,
+                     (const float*)stat, (const bf16*)Wqkv, (const bf16*)Wdo, (bf16*)gqkv, (const bf16*)edm_zero_page(), alpha, B,
+                     N, heads, HP);
+}
+
 }  // namespace
+
+#ifdef EDM_AF_TIMELINE
+extern "C" int edm_af_set_timeline(unsigned long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_af_timeline), &buf, sizeof(buf)) == hipSuccess ? EDM_OK : EDM_ERR_LAUNCH;
+}
+#endif
 
 // 1 if the fused kernels cover (C, heads, N): head_dim 64, C = 256, 33..256 tokens
 extern "C" int edm_attention_qkv_supported(int N, int C, int heads) {
@@ -321,5 +709,25 @@ extern "C" int edm_attention_qkv_fwd(const void* x, const void* Wqkv, void* y, v
   else if (nt <= 4) launch_fwd<4>(x, Wqkv, y, (float*)stat, B, N, heads, HP, st);
   else launch_fwd<8>(x, Wqkv, y, (float*)stat, B, N, heads, HP, st);
   EDM_CHECK_LAUNCH("attention_qkv_fwd");
+  return EDM_OK;
+}
+
+// gqkv [B*N, 3C] (packed order) = d loss / d qkv_conv(x), given gout = d loss / d (out_conv output) [B*N, C]:
+// dO = alpha * gout . W_out (Wd_out = the out conv's dgrad pack [C(ci), C(co)]) is formed inside (networks.py:203-205 backward)
+extern "C" int edm_attention_qkv_bwd(const void* x, const void* y, const void* gout, const void* stat, const void* Wqkv,
+                                     const void* Wd_out, void* gqkv, float alpha, int B, int N, int C, int heads, int hp,
+                                     hipStream_t st) {
+  EDM_REQUIRE(x && y && gout && stat && Wqkv && Wd_out && gqkv, "attention_qkv_bwd: null pointer");
+  EDM_REQUIRE(B > 0 && edm_attention_qkv_supported(N, C, heads), "attention_qkv_bwd: C = 256, 4 heads, 33..256 tokens only "
+              "(got C %d, heads %d, N %d)", C, heads, N);
+  EDM_ZERO_PAGE(zero_page_, "attention_qkv_bwd");
+  (void)zero_page_;
+  const int nt = (N + 31) / 32;
+  const int HP = 1;           // (one head per workgroup: see the kernel)
+  (void)hp;
+  if (nt <= 2) launch_bwd<2>(x, y, gout, stat, Wqkv, Wd_out, gqkv, alpha, B, N, heads, HP, st);
+  else if (nt <= 4) launch_bwd<4>(x, y, gout, stat, Wqkv, Wd_out, gqkv, alpha, B, N, heads, HP, st);
+  else launch_bwd<8>(x, y, gout, stat, Wqkv, Wd_out, gqkv, alpha, B, N, heads, HP, st);
+  EDM_CHECK_LAUNCH("attention_qkv_bwd");
   return EDM_OK;
 }

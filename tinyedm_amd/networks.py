@@ -764,12 +764,24 @@ class CosineAttention(nn.Module):
 
 
 class _AttnFn(torch.autograd.Function):
+    """networks.py:191-207.  Where csrc/attention_fused.hip covers the shape (C = 256, 4 heads, <= 256 tokens: every attention
+    block of the CIFAR-10 nets) the qkv projection runs INSIDE the attention kernel -- forward: fused kernel + out conv (with
+    the mp_add epilogue), 2 launches instead of 3; backward: fused kernel (dO = b * gout . W_out, recomputed q / k / v) + the
+    qkv conv's dgrad, 2 instead of 3 -- and the qkv tensor never exists in HBM; the 1x1 weight gradients join the grouped
+    launches as before."""
+
     @staticmethod
     def forward(ctx, x, w_qkv, w_out, mod: CosineAttention, dest=None):
         wf_qkv, wd_qkv, _ = mod.qkv_conv.packs()
         wf_out, wd_out, _ = mod.out_conv.packs()
-        qkv = ops.conv_igemm(x, wf_qkv, 1)
-        y = ops.attention_fwd(qkv, mod.num_heads)
+        fused = ops.attention_qkv_supported(x, mod.num_heads)
+        stat = qkv = None
+        if fused:
+            # (grad mode is off inside Function.forward: needs_input_grad says whether a backward can follow)
+            y, stat = ops.attention_qkv_fwd(x, wf_qkv, mod.num_heads, want_stat=any(ctx.needs_input_grad[:3]))
+        else:
+            qkv = ops.conv_igemm(x, wf_qkv, 1)
+            y = ops.attention_fwd(qkv, mod.num_heads)
         a, b = _mp_coeffs(0.5)
         C = wf_out.shape[1]
         if _dest_ok(dest, y, 1, y.shape[-1], C):     # the block's output goes straight into the next block's cat / mp_silu(cat)
@@ -778,19 +790,29 @@ class _AttnFn(torch.autograd.Function):
             out._edm_cat = dest
         else:
             out = ops.conv_igemm(y, wf_out, 1, residual=x, alpha=b, beta=a)
-        ctx.mod = mod
-        ctx.save_for_backward(x, qkv, y, wd_qkv, wd_out)
+        ctx.mod, ctx.fused = mod, fused
+        if fused:
+            ctx.save_for_backward(x, stat, y, wd_qkv, wd_out, wf_qkv)
+        else:
+            ctx.save_for_backward(x, qkv, y, wd_qkv, wd_out)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        x, qkv, y, wd_qkv, wd_out = ctx.saved_tensors
         mod = ctx.mod
         gout = gout.contiguous()
         a, b = _mp_coeffs(0.5)
-        gy = ops.conv_igemm(gout, wd_out, 1, alpha=b)
+        if ctx.fused:
+            x, stat, y, wd_qkv, wd_out, wf_qkv = ctx.saved_tensors
+            if stat is None:
+                raise RuntimeError("tinyedm_amd: attention backward without the forward's softmax statistics (the forward ran "
+                                   "under torch.no_grad())")
+            gqkv = ops.attention_qkv_bwd(x, y, gout, stat, wf_qkv, wd_out, mod.num_heads, alpha=b)
+        else:
+            x, qkv, y, wd_qkv, wd_out = ctx.saved_tensors
+            gy = ops.conv_igemm(gout, wd_out, 1, alpha=b)
+            gqkv = ops.attention_bwd(qkv, y, gy, mod.num_heads)
         gw_out = _wgrad(mod.out_conv, y, gout, 1, b)
-        gqkv = ops.attention_bwd(qkv, y, gy, mod.num_heads)
         gx = ops.conv_igemm(gqkv, wd_qkv, 1, residual=gout, alpha=1.0, beta=a)
         gw_qkv = _wgrad(mod.qkv_conv, x, gqkv, 1)
         return gx, gw_qkv, gw_out, None, None

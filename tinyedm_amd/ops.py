@@ -1057,6 +1057,23 @@ def attention_qkv_fwd(x, wf_qkv, heads, want_stat=True):
     return y, stat
 
 
+def attention_qkv_bwd(x, y, gout, stat, wf_qkv, wd_out, heads, alpha=1.0):
+    """-> gqkv (B,H,W,3C) bf16 (packed channel order) = d loss / d qkv_conv(x); gout = d loss / d out_conv(y),
+    wd_out (1, C, C) = the out conv's dgrad pack; dO = alpha * gout . W_out is formed inside the kernel"""
+    B, H, W, C = _nhwc(x, "x")
+    _chk(y, bf16, "y", x.shape)
+    _chk(gout, bf16, "gout", x.shape)
+    _chk(stat, f32, "stat", (B, heads, H * W))
+    _chk(wf_qkv, bf16, "wf_qkv", (1, 3 * C, C))
+    _chk(wd_out, bf16, "wd_out", (1, C, C))
+    N = H * W
+    gqkv = torch.empty(B, H, W, 3 * C, device=x.device, dtype=bf16)
+    with _prof("attention_qkv_bwd", 2.0 * B * N * C * 4 * C + 10.0 * B * N * N * C, 2.0 * B * N * 6 * C):
+        _lib.call("edm_attention_qkv_bwd", _p(x), _p(y), _p(gout), _p(stat), _p(wf_qkv), _p(wd_out), _p(gqkv), float(alpha),
+                  B, N, C, heads, 0, _stream())
+    return gqkv
+
+
 # ------------------------------------------------------------------ fp32 linears / embedding
 def linear_fwd(x, w):
     _chk(x, f32, "x")
