@@ -249,9 +249,21 @@ def train_bench(args, rank, world, device):
         torch.cuda.synchronize()
         return (t2 - t0) / n * 1e3, sorted(hs)[len(hs) // 2] * 1e3, calls
     if rank == 0 or world > 1:
+        reducer.measure = reducer.active             # events around finish()'s wait for the comm stream
         e_ms, e_host, e_calls = probe(eager_step, 10)
+        reducer.measure = False
         launch_info = {"eager_probe_ms": round(e_ms, 3), "host_enqueue_ms_per_step": round(e_host, 3),
                        "entry_point_calls_per_step": round(e_calls, 1)}
+        exp_ms = reducer.exposed_comm_ms()
+        if exp_ms is not None:
+            # what the eager step could NOT hide of its gradient all-reduces: the time the main stream waited for the comm
+            # stream after the backward pass had ended (mean over the probe's steps; slowest rank)
+            if world > 1:
+                t = torch.tensor([exp_ms], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                exp_ms = t.item()
+            launch_info["exposed_comm_ms"] = round(exp_ms, 3)
+            launch_info["grad_buckets"] = len(reducer.buckets)
     watchdog = None
     if can_graph and mode in ("auto", "graph") and (world > 1 or os.environ.get("EDM_BENCH_WATCHDOG") == "1"):   # (test hook)
         # Insurance for the one configuration this code cannot rehearse on a one-GPU box: capturing a step whose RCCL

@@ -322,3 +322,84 @@ def test_bench_self_launches_two_rccl_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 64 and line["value"] > 0
     assert line["config"]["collective"].startswith("rccl")
+
+
+def _worker_tail(port, q):
+    """CIFAR-10 net, forced one-rank RCCL reducer, the data-parallel grouping policy (networks.W3_TAIL = 4): log the order
+    of grouped 3x3 weight-gradient launches and bucket all-reduce launches of one backward pass."""
+    try:
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                          HSA_ENABLE_IPC_MODE_LEGACY="0")
+        sys.path.insert(0, ROOT)
+        import tinyedm_amd as T
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        import tinyedm
+        from tinyedm.config import compose, instantiate
+        from tinyedm_amd import networks as N, ops
+        from tinyedm_amd.ddp import GradReducer
+        cfg = compose("cifar10", os.path.join(ROOT, "experiments", "conf"))
+        tinyedm.manual_seed(cfg.seed)
+        torch.manual_seed(cfg.seed)
+        model = instantiate(cfg.model).to(dev).train()
+        base = model.configure_optimizers()["optimizer"]
+        base.fuse_zero_grad = True
+        red = GradReducer(base.arena, force=True)
+        N.W3_TAIL = GradReducer.W3_TAIL                 # what a multi-rank reducer switches on
+        g = torch.Generator().manual_seed(1)
+        x = (0.5 * torch.randn(16, 3, 32, 32, generator=g)).to(dev)
+        log = []
+        o_launch, o_w3 = red._launch, ops.wgrad3_group
+        red._launch = lambda b: (log.append(("allreduce", (b["hi"] - b["lo"]) * 4)), o_launch(b))[1]
+        ops.wgrad3_group = lambda items: (log.append(("wgrad3", len(items))), o_w3(items))[1]
+        try:
+            for step in range(3):                       # (the layer count of a pass is learned from the previous one)
+                del log[:]
+                loss = model.training_step((x, None), step)
+                loss.backward()
+                in_backward = len(log)
+                base.grad_scale = red.finish()
+                base.step()
+                base.zero_grad()
+            torch.cuda.synchronize()
+        finally:
+            ops.wgrad3_group = o_w3
+            N.W3_TAIL = 0
+        assert torch.isfinite(loss).item()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put(("ok", dict(log=list(log), in_backward=in_backward, arena_bytes=base.arena.numel * 4,
+                          buckets=[(b["hi"] - b["lo"]) * 4 for b in red.buckets])))
+    except Exception:          # noqa: BLE001
+        import traceback
+        q.put(("err", traceback.format_exc()))
+
+
+def test_small_final_weight_gradient_group_leaves_little_to_reduce_after_backward():
+    """Round-4 review #7: with the data-parallel grouping policy the LAST grouped weight-gradient launch of a pass holds 4 of
+    the 43 3x3 layers (16 + 16 + 7 + 4), the buckets over the last-finished part of the arena are 8 MB instead of 32, and at
+    least 85 % of the gradient bytes have their all-reduce ISSUED before that last launch -- what remains (<= 15 %) is all an
+    8-rank step can have exposed behind its backward pass."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_tail, args=(_free_port(), q))
+    p.start()
+    status, out = q.get(timeout=600)
+    p.join(120)
+    assert status == "ok", out
+    log, total = out["log"], out["arena_bytes"]
+    groups = [n for kind, n in log if kind == "wgrad3"]
+    assert len(groups) == 4 and groups[:2] == [16, 16] and groups[3] == 4 and sum(groups) in (42, 43), groups
+    last = max(i for i, (kind, _) in enumerate(log) if kind == "wgrad3")
+    before = sum(n for kind, n in log[:last] if kind == "allreduce")
+    assert sum(n for kind, n in log if kind == "allreduce") == total          # every byte is reduced exactly once
+    frac = before / total
+    print(f"all-reduce bytes issued before the last weight-gradient launch: {frac:.3f} of {total / 2**20:.1f} MiB; "
+          f"buckets (MiB): {[round(b / 2**20, 1) for b in out['buckets']]}")
+    from parity_log import record
+    record("ddp/allreduce_bytes_issued_before_last_wgrad_launch (fraction; must be >= limit)", 1.0 - frac, 0.15)
+    assert frac >= 0.85, frac

@@ -78,13 +78,24 @@ __device__ __forceinline__ f32x16 score_tile(const char* a_rows, const bf16x8 (&
   for (int s = 0; s < D / 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld128(a_rows + s * 32), bq[s], acc, 0, 0, 0);
   return acc;
 }
+// the same product on top of an initial accumulator (row / column constants ride in for free: the softmax offset, -delta)
+__device__ __forceinline__ f32x16 score_tile_init(const char* a_rows, const bf16x8 (&bq)[D / 16], f32x16 acc) {
+#pragma unroll
+  for (int s = 0; s < D / 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld128(a_rows + s * 32), bq[s], acc, 0, 0, 0);
+  return acc;
+}
 
 // ---- streamed GEMM  acc[rb] (32 rows x 32 tokens) = Wrows[rb*32 .., 0..255] . X^T   for NRB row blocks
 // The ROWS rows x 256 channels of the A operand go through an LDS ring in chunks of KCB channels by LDS-DMA.  KCB = 32:
 // 64-byte rows, 16-byte pieces XOR-swizzled with (row >> 2) & 3 on the DMA source and on the fragment read
 // (conv_igemm2.hip's layout); KCB = 64: 128-byte rows, swizzle row & 7.  A ring slot is SLOTB bytes (>= ROWS * 2 * KCB).
+// (k is a loop counter of a fully unrolled loop: the chain folds to one s_waitcnt)
+template <class SA, int KMAX>
+__device__ __forceinline__ void leave_in_flight_k(int k, int wave);
+
 template <int NT, int NRB, int KCB, int SLOTB_>
 struct Streamed {
+  static constexpr int NTW = NT;
   static constexpr int ROWS = NRB * 32;
   static constexpr int ROWB = KCB * 2;               // bytes of an LDS row
   static constexpr int RPS = 1024 / ROWB;            // rows per 1-KiB DMA instruction
@@ -128,7 +139,58 @@ struct Streamed {
 
 constexpr int QKV_SLOTB = 192 * 64;                  // ring slot of the qkv projection (192 rows x 32 channels)
 
-template <int NT>
+// s_waitcnt that leaves the wave's DMA instructions of KA chunks of stream SA (and KB chunks of stream SB) in flight
+template <class SA, int KA, class SB = SA, int KB = 0>
+__device__ __forceinline__ void leave_in_flight(int wave) {
+  constexpr int NTW = SA::NTW;
+  constexpr bool evenA = SA::SLOTS % NTW == 0 || KA == 0, evenB = SB::SLOTS % NTW == 0 || KB == 0;
+  if constexpr (evenA && evenB) {
+    wait_vmcnt<KA * (SA::SLOTS / NTW) + KB * (SB::SLOTS / NTW)>();
+  } else {
+    // uneven share (12 one-KiB pieces over 8 waves): waves below SLOTS % NT issue one more.  Only ONE uneven stream occurs.
+    constexpr int cut = evenA ? SB::SLOTS % NTW : SA::SLOTS % NTW;
+    constexpr int hi_ = KA * SA::PER_WAVE + KB * SB::PER_WAVE;
+    constexpr int lo_ = KA * (evenA ? SA::PER_WAVE : SA::PER_WAVE - 1) + KB * (evenB ? SB::PER_WAVE : SB::PER_WAVE - 1);
+    static_assert(hi_ < 64, "vmcnt immediate");
+    if (wave < cut) wait_vmcnt<hi_>();
+    else wait_vmcnt<lo_>();
+  }
+}
+
+template <class SA, int KMAX>
+__device__ __forceinline__ void leave_in_flight_k(int k, int wave) {
+  if constexpr (KMAX == 0) {
+    leave_in_flight<SA, 0>(wave);
+  } else {
+    if (k >= KMAX) leave_in_flight<SA, KMAX>(wave);
+    else leave_in_flight_k<SA, KMAX - 1>(k, wave);
+  }
+}
+
+template <class SA, class SB, int KA, int KBMAX>
+__device__ __forceinline__ void leave_ab_b(int kb, int wave) {
+  if constexpr (KBMAX == 0) {
+    leave_in_flight<SA, KA, SB, 0>(wave);
+  } else {
+    if (kb >= KBMAX) leave_in_flight<SA, KA, SB, KBMAX>(wave);
+    else leave_ab_b<SA, SB, KA, KBMAX - 1>(kb, wave);
+  }
+}
+// leave ka chunks of stream SA and kb chunks of stream SB in flight (ka, kb: counters of fully unrolled loops)
+template <class SA, class SB, int KAMAX, int KBMAX>
+__device__ __forceinline__ void leave_ab(int ka, int kb, int wave) {
+  if constexpr (KAMAX == 0) {
+    leave_ab_b<SA, SB, 0, KBMAX>(kb, wave);
+  } else {
+    if (ka >= KAMAX) leave_ab_b<SA, SB, KAMAX, KBMAX>(kb, wave);
+    else leave_ab<SA, SB, KAMAX - 1, KBMAX>(ka, kb, wave);
+  }
+}
+
+// RING: slots of the weight ring.  A chunk needs 12 MFMAs per wave (0.2 us) and an L2 -> LDS round trip of > 1 us: with two
+// chunks in flight the projection ran at 16 % of the MFMA rate (tools/af_timeline.py: 12 us for a head's 8 chunks); RING - 1
+// chunks are kept in flight -- with 7 slots nearly the whole head's 96 KB of weights.
+template <int NT, int RING>
 __global__ __launch_bounds__(NT * 64) void k_attn_qkv_fwd(const bf16* __restrict__ x, const bf16* __restrict__ Wqkv,
                                                             bf16* __restrict__ y, float* __restrict__ stat,
                                                             const bf16* __restrict__ zeros, int B, int N, int heads,
@@ -158,8 +220,10 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_fwd(const bf16* __restrict
     for (int kk = 0; kk < C / 16; ++kk) bx[kk] = *reinterpret_cast<const bf16x8*>(xr + kk * 16);
   }
   const int head0 = hg * HP;
-  G::issue(Wqkv + (long)head0 * 3 * D * C, 0, ring, 0, wave, lane);
-  G::issue(Wqkv + (long)head0 * 3 * D * C, 1, ring, 1, wave, lane);
+  constexpr int AHEAD = RING - 1;                              // chunks in flight behind the one being consumed
+  static_assert(AHEAD >= 2 && AHEAD < NCH, "ring depth");
+#pragma unroll
+  for (int j = 0; j < AHEAD; ++j) G::issue(Wqkv + (long)head0 * 3 * D * C, j, ring, j, wave, lane);
 
   const int a_off0 = G::frag_off(l31, lhi, 0), a_off1 = G::frag_off(l31, lhi, 1);
   const float sl2 = 0.125f * LOG2E, c0 = 8.0f * LOG2E;       // p = exp2(s * sl2 - c0) = exp(s / sqrt(d) - 8)
@@ -171,44 +235,55 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_fwd(const bf16* __restrict
   for (int hi = 0; hi < HP; ++hi) {
     const int head = head0 + hi;
     const bf16* wrows = Wqkv + (long)head * 3 * D * C;
+    const bool next_head = hi + 1 < HP;
     f32x16 acc[6];
 #pragma unroll
     for (int rb = 0; rb < 6; ++rb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+    // The chunk loop is software-pipelined by half a chunk (see k_attn_qkv_bwd): chunk kc + 1 becomes visible (wait + barrier)
+    // in the MIDDLE of chunk kc's MFMAs and its first fragments are read under chunk kc's last MFMAs.
+    if (hi > 0) wait_vmcnt<0>();                              // (the previous head's y stores sit behind the prefetched chunks)
+    else leave_in_flight<G, AHEAD - 1>(wave);                 // chunk 0 of AHEAD issued
+    __builtin_amdgcn_s_barrier();
+    bf16x8 fa[6];
+#pragma unroll
+    for (int rb = 0; rb < 6; ++rb) fa[rb] = ld128(ring + base * G::SLOTB + rb * 32 * WROWB + a_off0);
 #pragma unroll
     for (int kc = 0; kc < NCH; ++kc) {
-      const bool next_head = hi + 1 < HP;
-      const bool more = (kc + 1 < NCH) || next_head;
-      if (kc == 0 && hi > 0) wait_vmcnt<0>();                 // (the previous head's y stores sit behind the prefetched chunks)
-      else G::retire(more, wave);
-      __builtin_amdgcn_s_barrier();
-      {                                                        // chunk t+2: its slot was last read before this barrier
-        int sl = base + (kc + 2) % WRING;
-        sl -= sl >= WRING ? WRING : 0;
-        if (kc + 2 < NCH) G::issue(wrows, kc + 2, ring, sl, wave, lane);
-        else if (next_head) G::issue(wrows + (long)3 * D * C, kc + 2 - NCH, ring, sl, wave, lane);
-      }
-      int cur = base + kc % WRING;
-      cur -= cur >= WRING ? WRING : 0;
+      int cur = base + kc % RING, nxt = base + (kc + 1) % RING, sl = base + (kc + AHEAD) % RING;
+      cur -= cur >= RING ? RING : 0;
+      nxt -= nxt >= RING ? RING : 0;
+      sl -= sl >= RING ? RING : 0;
       const char* wt = ring + cur * G::SLOTB;
-      // six fragment reads in flight before the chunk's first MFMA (left to itself hipcc keeps ONE read in flight:
-      // ds_read -> lgkmcnt(0) -> MFMA, twelve exposed LDS round trips per chunk)
-      bf16x8 fa[6];
-#pragma unroll
-      for (int rb = 0; rb < 6; ++rb) fa[rb] = ld128(wt + rb * 32 * WROWB + a_off0);
-      __builtin_amdgcn_sched_barrier(0);
+      const char* wn = ring + nxt * G::SLOTB;
 #pragma unroll
       for (int rb = 0; rb < 6; ++rb) {               // the second k-step's read goes out right behind the MFMA of the first
         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rb], bx[2 * kc], acc[rb], 0, 0, 0);
         fa[rb] = ld128(wt + rb * 32 * WROWB + a_off1);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (kc + 1 < NCH) {
+        // retire chunk kc + 1: chunks up to kc + AHEAD - 1 have been issued (all of them exist if another head follows)
+        if (next_head) leave_in_flight<G, AHEAD - 2>(wave);
+        else leave_in_flight_k<G, AHEAD - 2>(NCH - 2 - kc, wave);
+        __builtin_amdgcn_s_barrier();
+        if (kc + AHEAD < NCH) G::issue(wrows, kc + AHEAD, ring, sl, wave, lane);
+        else if (next_head) G::issue(wrows + (long)3 * D * C, kc + AHEAD - NCH, ring, sl, wave, lane);
+      } else if (next_head) {
+        // last chunk of the head: nothing to retire, but the slot of chunk kc - 1 is only free once EVERY wave has consumed
+        // the fragments it read from it (i.e. has arrived here)
+        __builtin_amdgcn_s_barrier();
+        G::issue(wrows + (long)3 * D * C, kc + AHEAD - NCH, ring, sl, wave, lane);
+      }
 #pragma unroll
-      for (int rb = 0; rb < 6; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rb], bx[2 * kc + 1], acc[rb], 0, 0, 0);
+      for (int rb = 0; rb < 6; ++rb) {
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rb], bx[2 * kc + 1], acc[rb], 0, 0, 0);
+        if (kc + 1 < NCH) fa[rb] = ld128(wn + rb * 32 * WROWB + a_off0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
-    base = (base + NCH) % WRING;
+    base = (base + NCH) % RING;
     if (hi == 0) { AF_STAMP(1); }
 
     // ---- pixel norm of q, k, v over the 64 channels of the token on this lane (networks.py:195), bf16 rounding points of
@@ -308,26 +383,24 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_fwd(const bf16* __restrict
 #endif
 }
 
-template <int NT>
-size_t lds_fwd() { return (size_t)2 * NT * 32 * RS + (size_t)WRING * QKV_SLOTB; }
-
-template <int NT>
+template <int NT, int RING>
 void launch_fwd(const void* x, const void* Wqkv, void* y, float* stat, int B, int N, int heads, int HP, hipStream_t st) {
-  auto kern = k_attn_qkv_fwd<NT>;
+  auto kern = k_attn_qkv_fwd<NT, RING>;
   EDM_MAX_LDS(kern, 160 * 1024);
+  const size_t lds = (size_t)2 * NT * 32 * RS + (size_t)RING * QKV_SLOTB;
+  static_assert((size_t)2 * NT * 32 * RS + (size_t)RING * QKV_SLOTB <= 160 * 1024, "LDS budget");
   const int groups = heads / HP;
   const int grid = ((B + 7) / 8) * 8 * groups;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT * 64), lds_fwd<NT>(), st, (const bf16*)x, (const bf16*)Wqkv, (bf16*)y, stat,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT * 64), lds, st, (const bf16*)x, (const bf16*)Wqkv, (bf16*)y, stat,
                      (const bf16*)edm_zero_page(), B, N, heads, HP);
 }
-
 
 // ====================================================================================================================
 // backward: gqkv (packed order [head][q|k|v][d]) from x, y, gout -- the qkv tensor and dO = b * gout . W_out are rebuilt
 // in registers / LDS.  Per head: (B) dO^T = alpha * Wd_out[64 h .. +64, :] . gout^T through the ring (64-channel chunks),
 // delta = <dO, O>; (A) q, k, v as in the forward; images of Qn, Kn, Vn, dO (channel order) + the norm denominators in
 // LDS; then attention.hip's two passes (query-major: dQ; key-major: dK, dV), with the forward's saved normaliser instead
-// of a softmax sweep.  The ring shares the Q image's region: Qn is written after the last chunk has been consumed.
+// of a softmax sweep.  For 256 tokens the ring lies over the Q, K, V images' regions (written after the last chunk).
 // ====================================================================================================================
 
 // dx = (g - xn*<g,xn>*d/(D*(d-eps)))/d for one token per lane, g given as O^T-style accumulators
@@ -374,7 +447,10 @@ __device__ __forceinline__ void image_store(char* img_row, int rb, int lhi, cons
   }
 }
 
-template <int NT>
+// RING slots of 12 KB; OVERLAY: the ring occupies the Q | K | V image regions (all three are written after the last chunk
+// has been consumed) instead of LDS of its own.  The 12 chunks of a head (4 of the out conv's dgrad rows, 64 channels each;
+// 8 of the qkv rows, 32 channels each) are one stream: RING - 1 of them are kept in flight.
+template <int NT, int RING, bool OVERLAY>
 __global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict__ x, const bf16* __restrict__ y,
                                                             const bf16* __restrict__ gout, const float* __restrict__ stat,
                                                             const bf16* __restrict__ Wqkv, const bf16* __restrict__ Wdo,
@@ -384,17 +460,17 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict
   constexpr int NP = NT * 32;
   using GA = Streamed<NT, 6, KC, QKV_SLOTB>;       // qkv rows, 32-channel chunks
   using GB = Streamed<NT, 2, 64, QKV_SLOTB>;       // the head's 64 rows of the out conv's dgrad pack, 64-channel chunks
-  constexpr int NCHB = C / 64;
-  constexpr int QREG = (NP * RS > WRING * QKV_SLOTB) ? NP * RS : WRING * QKV_SLOTB;
+  constexpr int NCHB = C / 64, TOT = NCHB + NCH, AHEAD = RING - 1;
+  static_assert(AHEAD >= 2 && AHEAD < TOT, "ring depth");
+  static_assert(!OVERLAY || RING * QKV_SLOTB <= 3 * NP * RS, "the overlaid ring must fit the Q, K, V image regions");
   char* Qn = smem;
-  char* ring = smem;
-  char* Kn = Qn + QREG;
+  char* Kn = Qn + NP * RS;
   char* Vn = Kn + NP * RS;
   char* dO = Vn + NP * RS;
-  // LDS: [ring | Qn] Kn Vn dO stats -- the ring shares the Q image's region (Qn is written after the last chunk was read)
   float* dsave = reinterpret_cast<float*>(dO + NP * RS);     // [3][NP]
   float* st_l = dsave + 3 * NP;                               // [NP] softmax normaliser (forward's)
   float* st_d = st_l + NP;                                    // [NP] delta = <dO, O>
+  char* ring = OVERLAY ? smem : reinterpret_cast<char*>(st_d + NP);
   const int groups = heads / HP;
   const int id = blockIdx.x, xcd = id & 7, kk_ = id >> 3;
   const int b = (kk_ / groups) * 8 + xcd, hg = kk_ % groups;
@@ -417,24 +493,43 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict
     // arithmetic in front of it and spills 43 registers of it
     const int head = hg;
     AF_STAMP(0);
-    // ---- operands of both projections as B fragments (token on the lane), the head's slice of y for delta
+    // ---- operands of both projections as B fragments (token on the lane), the head's slice of y for delta: all loads first
     bf16x8 bg[C / 16], bx[C / 16];
     bf16x4 yv[2][4];
     {
       const bf16* gr = (tvalid ? gout + trow * C : zeros) + lhi * 8;                  // (padding tokens read the zero page)
       const bf16* yr = (tvalid ? y + trow * C + head * D : zeros) + 4 * lhi;
+      const bf16* xr = (tvalid ? x + trow * C : zeros) + lhi * 8;
 #pragma unroll
       for (int kk = 0; kk < C / 16; ++kk) bg[kk] = *reinterpret_cast<const bf16x8*>(gr + kk * 16);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) yv[dt][g] = *reinterpret_cast<const bf16x4*>(yr + dt * 32 + 8 * g);
+#pragma unroll
+      for (int kk = 0; kk < C / 16; ++kk) bx[kk] = *reinterpret_cast<const bf16x8*>(xr + kk * 16);
     }
     const bf16* wdo = Wdo + (long)head * D * C;
     const bf16* wrows = Wqkv + (long)head * 3 * D * C;
-    // chunk counter t: 0 .. NCHB-1 = phase B, NCHB .. NCHB+NCH-1 = phase A; ring slot t % 3
-    GB::issue(wdo, 0, ring, 0, wave, lane);
-    GB::issue(wdo, 1, ring, 1, wave, lane);
+    // chunk j of the stream: j < NCHB -> rows of the out conv (64 channels), else chunk j - NCHB of the qkv rows; slot j % RING
+    auto issue = [&](int j) {
+      if (j < NCHB) GB::issue(wdo, j, ring, j % RING, wave, lane);
+      else GA::issue(wrows, j - NCHB, ring, j % RING, wave, lane);
+    };
+    // The chunk loop is software-pipelined by half a chunk: the wait + barrier that make chunk j visible sit in the MIDDLE of
+    // chunk j-1's MFMAs (which keep the matrix pipe busy while the wave waits), and chunk j's first fragments are read under
+    // chunk j-1's last MFMAs.  (Per-chunk lockstep -- barrier, all waves read, all waves multiply -- ran both projections at
+    // ~40 % of the LDS / MFMA bound: tools/af_timeline.py, 0.75 us per 12-MFMA chunk.)
+    // retire(j): chunks 0 .. j + AHEAD - 2 have been issued when chunk j >= 1 is retired (0 .. AHEAD - 1 for j = 0)
+    auto retire = [&](int j) {
+      const int issued = (j == 0 ? AHEAD - 1 : j + AHEAD - 2);
+      const int last = issued < TOT - 1 ? issued : TOT - 1;
+      const int kb = (last < NCHB ? last : NCHB - 1) - j;               // out-conv chunks among j+1 .. last
+      const int nb = kb > 0 ? kb : 0;
+      leave_ab<GA, GB, NCH, NCHB - 1>(last - j - nb, nb, wave);
+    };
+#pragma unroll
+    for (int j = 0; j < AHEAD; ++j) issue(j);
 
     // ---- phase B: dO^T (64 channels x 32 tokens) = alpha * Wd_out rows . gout^T
     f32x16 ad[2];
@@ -442,37 +537,43 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) ad[rb][r] = 0.f;
-    // vmcnt order of a head: [bg, y] GB0 GB1 | t=0: GB2 | t=1: GB3 | t=2: GA0, x (16 loads) | t=3: GA1 | phase A ...
-    // (the x fragments of phase A are fetched under phase B's tail: the counted waits of t = 3 and kc = 0 step over them)
-    static_assert(NCHB == 4, "the wait counts below are written for four 64-channel chunks");
+    bf16x8 f[2], fa[6];
+    retire(0);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) f[rb] = ld128(ring + rb * 32 * GB::ROWB + GB::frag_off(l31, lhi, 0));
 #pragma unroll
     for (int t = 0; t < NCHB; ++t) {
-      if (t < 3) {
-        GB::retire(true, wave);
-      } else {                                       // outstanding: GB3, GA0, x*16
-        if (GA::SLOTS % NT == 0) wait_vmcnt<GA::SLOTS / NT + 16>();
-        else if (wave < GA::SLOTS % NT) wait_vmcnt<GA::PER_WAVE + 16>();
-        else wait_vmcnt<GA::PER_WAVE - 1 + 16>();
-      }
-      __builtin_amdgcn_s_barrier();
-      if (t + 2 < NCHB) GB::issue(wdo, t + 2, ring, (t + 2) % WRING, wave, lane);
-      else GA::issue(wrows, t + 2 - NCHB, ring, (t + 2) % WRING, wave, lane);
-      if (t == 2) {
-        const bf16* xr = (tvalid ? x + trow * C : zeros) + lhi * 8;
+      const char* wt = ring + (t % RING) * QKV_SLOTB;
+      const char* wn = ring + ((t + 1) % RING) * QKV_SLOTB;
 #pragma unroll
-        for (int kk = 0; kk < C / 16; ++kk) bx[kk] = *reinterpret_cast<const bf16x8*>(xr + kk * 16);
-      }
-      const char* wt = ring + (t % WRING) * QKV_SLOTB;
-      bf16x8 f[2];
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb) f[rb] = ld128(wt + rb * 32 * GB::ROWB + GB::frag_off(l31, lhi, 0));
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
           ad[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[rb], bg[4 * t + s], ad[rb], 0, 0, 0);
-          if (s + 1 < 4) f[rb] = ld128(wt + rb * 32 * GB::ROWB + GB::frag_off(l31, lhi, s + 1));
+          f[rb] = ld128(wt + rb * 32 * GB::ROWB + GB::frag_off(l31, lhi, s + 1));
         }
+      __builtin_amdgcn_sched_barrier(0);
+      retire(t + 1);
+      __builtin_amdgcn_s_barrier();
+      if (t + AHEAD < TOT) issue(t + AHEAD);            // (the slot of chunk t - 1: every wave has consumed it)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        ad[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[rb], bg[4 * t + 2], ad[rb], 0, 0, 0);
+        f[rb] = ld128(wt + rb * 32 * GB::ROWB + GB::frag_off(l31, lhi, 3));
+      }
+      if (t + 1 < NCHB) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          ad[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[rb], bg[4 * t + 3], ad[rb], 0, 0, 0);
+          f[rb] = ld128(wn + rb * 32 * GB::ROWB + GB::frag_off(l31, lhi, 0));
+        }
+      } else {
+#pragma unroll
+        for (int rb = 0; rb < 6; ++rb) fa[rb] = ld128(wn + rb * 32 * WROWB + a_off0);     // phase A's first fragments
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) ad[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[rb], bg[4 * t + 3], ad[rb], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     AF_STAMP(1);
@@ -492,9 +593,15 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict
         *reinterpret_cast<bf16x4*>(dO + tok * RS + (32 * dt + 8 * g + 4 * lhi) * 2) = v4;
       }
     delta += __shfl_xor(delta, 32, 64);
+    // per-query constants of the two passes, in the form the score accumulators are initialised with:
+    //   st_l = (log2(1 / l) - 8 log2 e) / (log2 e / sqrt(d))  ->  exp2((S + st_l) * sl2) = the normalised probability
+    //   st_d = -delta                                          ->  (dP + st_d) = dP - delta
+    // (a padding query has 1 / l = 0: st_l = -inf, its probabilities are exp2(-inf) = 0)
+    const float linv = tvalid ? stat[((long)b * heads + head) * N + tok] : 0.f;
+    const float s0 = (__builtin_amdgcn_logf(linv) - c0) * (1.0f / sl2);
     if (lhi == 0) {
-      st_d[tok] = delta;
-      st_l[tok] = tvalid ? stat[((long)b * heads + head) * N + tok] : 0.f;
+      st_d[tok] = -delta;
+      st_l[tok] = s0;
     }
 
     // ---- phase A: q, k, v of the head (as the forward)
@@ -506,29 +613,24 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict
 #pragma unroll
     for (int kc = 0; kc < NCH; ++kc) {
       constexpr int T0 = NCHB;
-      if (kc == 0) {                                 // outstanding: GA0, x*16, GA1
-        if (GA::SLOTS % NT == 0) wait_vmcnt<GA::SLOTS / NT + 16>();
-        else if (wave < GA::SLOTS % NT) wait_vmcnt<GA::PER_WAVE + 16>();
-        else wait_vmcnt<GA::PER_WAVE - 1 + 16>();
-      } else {
-        GA::retire(kc + 1 < NCH, wave);
-      }
-      __builtin_amdgcn_s_barrier();
-      if (kc + 2 < NCH) GA::issue(wrows, kc + 2, ring, (T0 + kc + 2) % WRING, wave, lane);
-      const char* wt = ring + ((T0 + kc) % WRING) * QKV_SLOTB;
-      // six fragment registers: the second k-step's read of a row block is issued right behind the MFMA that consumed the first
-      bf16x8 fa[6];
+      const char* wt = ring + ((T0 + kc) % RING) * QKV_SLOTB;
+      const char* wn = ring + ((T0 + kc + 1) % RING) * QKV_SLOTB;
 #pragma unroll
-      for (int rb = 0; rb < 6; ++rb) fa[rb] = ld128(wt + rb * 32 * WROWB + a_off0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int rb = 0; rb < 6; ++rb) {
+      for (int rb = 0; rb < 6; ++rb) {               // the second k-step's read goes out right behind the MFMA of the first
         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rb], bx[2 * kc], acc[rb], 0, 0, 0);
         fa[rb] = ld128(wt + rb * 32 * WROWB + a_off1);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (kc + 1 < NCH) {
+        retire(T0 + kc + 1);
+        __builtin_amdgcn_s_barrier();
+        if (T0 + kc + AHEAD < TOT) issue(T0 + kc + AHEAD);
+      }
 #pragma unroll
-      for (int rb = 0; rb < 6; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rb], bx[2 * kc + 1], acc[rb], 0, 0, 0);
+      for (int rb = 0; rb < 6; ++rb) {
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rb], bx[2 * kc + 1], acc[rb], 0, 0, 0);
+        if (kc + 1 < NCH) fa[rb] = ld128(wn + rb * 32 * WROWB + a_off0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     AF_STAMP(2);
@@ -569,8 +671,17 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict
         bq[s] = ld128(Qn + qi * RS + s * 32 + lhi * 16);
         bdo[s] = ld128(dO + qi * RS + s * 32 + lhi * 16);
       }
-      const float ls = st_l[qi] * scale;
-      const float dlt = st_d[qi];
+      // dS = P * scale * (dP - delta): the query's constants start the accumulators (log2(scale) / sl2 = -3 / sl2 folds
+      // the 1 / sqrt(d) of the chain rule into the exponent), three vector instructions per score are left: mul, exp2, mul
+      f32x16 s_init, d_init;
+      {
+        const float si = s0 - 3.0f / sl2, di = -delta;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s_init[r] = si;
+          d_init[r] = di;
+        }
+      }
       f32x16 accq[D / 32];
 #pragma unroll
       for (int dt = 0; dt < D / 32; ++dt)
@@ -578,16 +689,16 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict
         for (int r = 0; r < 16; ++r) accq[dt][r] = 0.f;
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
-        f32x16 S = score_tile(Kn + (kt * 32 + l31) * RS + lhi * 16, bq);
-        f32x16 dP = score_tile(Vn + (kt * 32 + l31) * RS + lhi * 16, bdo);   // dP^T tile: keys x queries
+        f32x16 S = score_tile_init(Kn + (kt * 32 + l31) * RS + lhi * 16, bq, s_init);
+        f32x16 dP = score_tile_init(Vn + (kt * 32 + l31) * RS + lhi * 16, bdo, d_init);   // dP^T tile: keys x queries
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float p = __builtin_amdgcn_exp2f(fmaf(S[r], sl2, -c0));
+          float p = __builtin_amdgcn_exp2f(S[r] * sl2);
           if (!full) {
             const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
             p = key < N ? p : 0.f;
           }
-          dP[r] = p * ls * (dP[r] - dlt);
+          dP[r] = p * dP[r];
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -622,9 +733,8 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict
         }
 #pragma unroll 1
       for (int qt = 0; qt < NT; ++qt) {
-        // S tile: rows = queries (registers), cols = keys (lane)
-        f32x16 S = score_tile(Qn + (qt * 32 + l31) * RS + lhi * 16, bk);
-        f32x16 dP = score_tile(dO + (qt * 32 + l31) * RS + lhi * 16, bv);
+        // S tile: rows = queries (registers), cols = keys (lane); the queries' constants are the initial accumulators
+        f32x16 s_init, d_init;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int q0 = qt * 32 + 8 * g + 4 * lhi;
@@ -632,11 +742,18 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict
           const f32x4 dd = *reinterpret_cast<const f32x4*>(st_d + q0);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float p = __builtin_amdgcn_exp2f(fmaf(S[4 * g + r], sl2, -c0)) * ll[r];
-            if (!full) p = tvalid ? p : 0.f;
-            S[4 * g + r] = p;
-            dP[4 * g + r] = p * scale * (dP[4 * g + r] - dd[r]);
+            s_init[4 * g + r] = ll[r];
+            d_init[4 * g + r] = dd[r];
           }
+        }
+        f32x16 S = score_tile_init(Qn + (qt * 32 + l31) * RS + lhi * 16, bk, s_init);
+        f32x16 dP = score_tile_init(dO + (qt * 32 + l31) * RS + lhi * 16, bv, d_init);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float p = __builtin_amdgcn_exp2f(S[r] * sl2);            // the normalised probability
+          if (!full) p = tvalid ? p : 0.f;
+          S[r] = p;
+          dP[r] = p * dP[r];                                       // (the 1 / sqrt(d) of dS is applied to dK at the end)
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -651,6 +768,10 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict
           }
         }
       }
+#pragma unroll
+      for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acck[dt][r] *= scale;
       bf16* dst = gqkv + ((long)b * N + ki) * 3 * C + head * 3 * D;
       norm_bwd_store(acck, Kn + ki * RS, dsave[1 * NP + ki], dst + D, lhi, tvalid);
       AF_STAMP(5);
@@ -663,20 +784,16 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict
 #endif
 }
 
-template <int NT>
-size_t lds_bwd() {
-  const size_t img = (size_t)NT * 32 * RS, ringb = (size_t)WRING * QKV_SLOTB;
-  return 3 * img + (img > ringb ? img : ringb) + (size_t)5 * NT * 32 * sizeof(float);
-}
-
-template <int NT>
+template <int NT, int RING, bool OVERLAY>
 void launch_bwd(const void* x, const void* y, const void* gout, const void* stat, const void* Wqkv, const void* Wdo, void* gqkv,
                 float alpha, int B, int N, int heads, int HP, hipStream_t st) {
-  auto kern = k_attn_qkv_bwd<NT>;
+  auto kern = k_attn_qkv_bwd<NT, RING, OVERLAY>;
   EDM_MAX_LDS(kern, 160 * 1024);
+  constexpr size_t lds = (size_t)4 * NT * 32 * RS + (size_t)5 * NT * 32 * sizeof(float) + (OVERLAY ? 0 : (size_t)RING * QKV_SLOTB);
+  static_assert(lds <= 160 * 1024, "LDS budget");
   const int groups = heads / HP;
   const int grid = ((B + 7) / 8) * 8 * groups;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT * 64), lds_bwd<NT>(), st, (const bf16*)x, (const bf16*)y, (const bf16*)gout,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT * 64), lds, st, (const bf16*)x, (const bf16*)y, (const bf16*)gout,
                      (const float*)stat, (const bf16*)Wqkv, (const bf16*)Wdo, (bf16*)gqkv, (const bf16*)edm_zero_page(), alpha, B,
                      N, heads, HP);
 }
@@ -705,9 +822,10 @@ extern "C" int edm_attention_qkv_fwd(const void* x, const void* Wqkv, void* y, v
   const int nt = (N + 31) / 32;
   int HP = hp > 0 ? hp : (nt > 4 ? 2 : 1);
   EDM_REQUIRE(heads % HP == 0, "attention_qkv_fwd: heads per workgroup must divide heads");
-  if (nt <= 2) launch_fwd<2>(x, Wqkv, y, (float*)stat, B, N, heads, HP, st);
-  else if (nt <= 4) launch_fwd<4>(x, Wqkv, y, (float*)stat, B, N, heads, HP, st);
-  else launch_fwd<8>(x, Wqkv, y, (float*)stat, B, N, heads, HP, st);
+  // (64-token maps: 66 KB of LDS per 128-thread workgroup, two per CU; larger maps: the seven-slot ring, one per CU)
+  if (nt <= 2) launch_fwd<2, 4>(x, Wqkv, y, (float*)stat, B, N, heads, HP, st);
+  else if (nt <= 4) launch_fwd<4, 7>(x, Wqkv, y, (float*)stat, B, N, heads, HP, st);
+  else launch_fwd<8, 7>(x, Wqkv, y, (float*)stat, B, N, heads, HP, st);
   EDM_CHECK_LAUNCH("attention_qkv_fwd");
   return EDM_OK;
 }
@@ -725,9 +843,10 @@ extern "C" int edm_attention_qkv_bwd(const void* x, const void* y, const void* g
   const int nt = (N + 31) / 32;
   const int HP = 1;           // (one head per workgroup: see the kernel)
   (void)hp;
-  if (nt <= 2) launch_bwd<2>(x, y, gout, stat, Wqkv, Wd_out, gqkv, alpha, B, N, heads, HP, st);
-  else if (nt <= 4) launch_bwd<4>(x, y, gout, stat, Wqkv, Wd_out, gqkv, alpha, B, N, heads, HP, st);
-  else launch_bwd<8>(x, y, gout, stat, Wqkv, Wd_out, gqkv, alpha, B, N, heads, HP, st);
+  // 256-token maps: nine ring slots laid over the Q | K | V image regions (152 KB in all); smaller maps: a ring of its own
+  if (nt <= 2) launch_bwd<2, 3, false>(x, y, gout, stat, Wqkv, Wd_out, gqkv, alpha, B, N, heads, HP, st);
+  else if (nt <= 4) launch_bwd<4, 6, false>(x, y, gout, stat, Wqkv, Wd_out, gqkv, alpha, B, N, heads, HP, st);
+  else launch_bwd<8, 9, true>(x, y, gout, stat, Wqkv, Wd_out, gqkv, alpha, B, N, heads, HP, st);
   EDM_CHECK_LAUNCH("attention_qkv_bwd");
   return EDM_OK;
 }

@@ -30,6 +30,12 @@ class GradReducer:
     element) and writes the fp32 result back.  `force=True` (or EDM_FORCE_REDUCE=1) registers the hooks and runs the
     collectives even in a one-rank group, so a single GPU exercises the whole comm-stream path through RCCL."""
 
+    # buckets over the part of the arena whose gradients become final LAST (the lowest offsets: the first layers of the
+    # network) are smaller: what is still to be all-reduced when the backward pass ends is what the step cannot hide
+    TAIL_REGION_BYTES = 16 << 20
+    TAIL_BUCKET_BYTES = 8 << 20
+    W3_TAIL = 4         # 3x3 layers in the last grouped weight-gradient launch of a pass (networks.W3_TAIL)
+
     def __init__(self, arena, bucket_bytes: int = 32 << 20, process_group=None, transport: str = None, force=None):
         self.arena = arena
         self.group = process_group
@@ -50,6 +56,8 @@ class GradReducer:
         # the arena's tail of 0-dim parameters (block gains, gain_out: FlatArena layout 2) is ONE more bucket, the last --
         # the block gains' gradients are final only when the backward pass ends (networks._EmbedAllFn.backward)
         per_bucket = max(1, bucket_bytes // 4)
+        per_tail = max(1, min(bucket_bytes, self.TAIL_BUCKET_BYTES) // 4)
+        tail_region = self.TAIL_REGION_BYTES // 4
         self.buckets: List[dict] = []
         cur = None
         scalar_lo = getattr(arena, "scalar_lo", arena.numel)
@@ -60,7 +68,7 @@ class GradReducer:
             idx = body[k]
             off = arena.offsets[idx]
             end = arena.offsets[body[k + 1]] if k + 1 < len(body) else scalar_lo
-            if cur is None or cur["hi"] - off > per_bucket:
+            if cur is None or cur["hi"] - off > (per_tail if cur["hi"] <= tail_region else per_bucket):
                 cur = {"lo": off, "hi": end, "params": [], "pending": 0, "work": None}
                 self.buckets.append(cur)
             cur["lo"] = off
@@ -72,6 +80,11 @@ class GradReducer:
             for idx in b["params"]:
                 self._bucket_of[idx] = b
         self._hooks = []
+        self.measure = False                     # record events around finish()'s wait for the comm stream (bench.py)
+        self._exposed = []
+        if self.world > 1 and "EDM_W3_TAIL" not in os.environ:
+            from . import networks
+            networks.W3_TAIL = self.W3_TAIL      # a small final group: see networks.W3_TAIL
         if self.active:
             for idx, p in enumerate(arena.params):
                 hook = self._make_hook(idx)
@@ -153,9 +166,25 @@ class GradReducer:
                         self.arena.grad[b["lo"]:b["hi"]].copy_(b["wire"])
                 b["wire"] = None
             if self.is_cuda and self.comm_stream is not None:
-                torch.cuda.current_stream().wait_stream(self.comm_stream)
+                if self.measure and not torch.cuda.is_current_stream_capturing():
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()                  # the main stream gets here when the backward pass has ended ...
+                    torch.cuda.current_stream().wait_stream(self.comm_stream)
+                    e1.record()                  # ... and here when the last all-reduce has: the difference is exposed
+                    self._exposed.append((e0, e1))
+                else:
+                    torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.reset()
         return 1.0 / self.world
+
+    def exposed_comm_ms(self):
+        """mean time finish() kept the main stream waiting for the comm stream over the measured steps (call after a
+        synchronisation; measure=True must have been set), or None"""
+        if not self._exposed:
+            return None
+        ms = [a.elapsed_time(b) for a, b in self._exposed]
+        self._exposed = []
+        return sum(ms) / len(ms)
 
     def broadcast_parameters(self, src: int = 0):
         """DDP's initial parameter broadcast: one collective over the parameter arena."""

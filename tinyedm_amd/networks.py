@@ -148,6 +148,15 @@ WGRAD_STREAM = os.environ.get("EDM_WGRAD_STREAM", "1") != "0"
 # overlaps the backward pass at a finer grain (ImageNet-64 config, 64x64 layers at batch 176: 144 vs 147 ms).  Only with
 # the side stream: on one chain (captured step) everything is grouped (154.6 vs 161 ms).
 W3_GROUP = max(0, min(16, int(os.environ.get("EDM_W3_GROUP", "16"))))
+# Data-parallel runs: the LAST grouped launch of a backward pass finishes at the very end of it, so the all-reduce of its
+# layers' gradients has nothing left to hide under except the optimizer.  W3_TAIL > 0 cuts the groups so that the final one
+# holds at most that many layers (CIFAR-10: 43 layers as 16 + 16 + 7 + 4 instead of 16 + 16 + 11: 9.4 MB = 6.6 % of the
+# gradient bytes left for the exposed tail instead of 26 MB) at the price of one more launch.  The number of 3x3 layers of
+# a pass is learned from the previous pass.  Set by ddp.GradReducer when more than one rank takes part (EDM_W3_TAIL overrides;
+# 0 = off: one GPU keeps the three launches).
+W3_TAIL = max(0, int(os.environ.get("EDM_W3_TAIL", "0")))
+_w3_seen = {}               # device index -> 3x3 layers queued so far in the running backward pass
+_w3_total = {}              # device index -> 3x3 layers queued by the previous (complete) backward pass
 W3_MAXPIX = int(os.environ.get("EDM_W3_MAXPIX", str(1 << 18)))
 FIN_GROUP = 40              # small weight gradients per multi-tensor finish launch (csrc/weights.hip)
 # 1x1 weight gradients: layers per grouped launch (csrc/conv_wgrad1x1.hip k_wgrad1x1_group; 0 = one launch per layer)
@@ -224,6 +233,8 @@ def _backward_end(key):
     """End of a backward pass on device `key`: flush the last partial group, then make the stream that ran the
     backward wait for the auxiliary stream (the optimizer reads what the weight-gradient kernels wrote)."""
     _bwd_end_queued.discard(key)
+    if key in _w3_seen:
+        _w3_total[key] = _w3_seen.pop(key)
     _flush_w3(key)
     _flush_fin(key)
     if WGRAD_STREAM:
@@ -258,6 +269,7 @@ def reset_backward_state():
             for m, _, _, _ in items:
                 m.weight._edm_deferred = False
         _w3_pending.clear()
+        _w3_seen.clear()
         if WGRAD_STREAM:
             for s in ops.side_streams():
                 torch.cuda.current_stream(s.device).wait_stream(s)
@@ -279,7 +291,8 @@ def _wgrad(mod, x, dy, taps, scale=1.0):
                 pend = _w3_pending.setdefault(key, [])
             pend.append((mod, x, dy, scale))
             w._edm_deferred = True                    # autograd may run the parameter's hooks before the group is launched
-            if len(pend) >= W3_GROUP:
+            seen = _w3_seen[key] = _w3_seen.get(key, 0) + 1
+            if len(pend) >= W3_GROUP or (W3_TAIL and seen == _w3_total.get(key, 0) - W3_TAIL):
                 _flush_w3(key)
             _queue_backward_end(w.device)
             return None
