@@ -194,35 +194,49 @@ def test_reference_yaml_sections_instantiate():
                 assert isinstance(model, tinyedm.EDM) and model.hparams["_target_"] == "tinyedm.edm.EDM"
 
 
-def test_flat_arena_layout2_and_layout1_checkpoint_migration():
-    """FlatArena layout 2 keeps the 0-dim parameters in a tail region (their gradients are final last); an optimizer state
-    written with the sequential layout of rounds 1-2 (no "layout" key) is moved slice by slice; torch-Adam states keep
-    mapping by parameter INDEX."""
+def test_flat_arena_layout3_and_older_checkpoint_migration():
+    """FlatArena layout 3 keeps every parameter whose gradient is final only at the END of the backward pass in a tail
+    region -- tensors flagged `_edm_late` (the blocks' embed Linears, the Embedding module), then the 0-dim parameters -- so
+    that no data-parallel bucket of the body has to wait for them; optimizer states written with the sequential layout of
+    rounds 1-2 (no "layout" key) or with layout 2 (rounds 3-4: only the 0-dim parameters in the tail) are moved slice by
+    slice; torch-Adam states keep mapping by parameter INDEX."""
     import torch
-    from tinyedm_amd.ema import FlatArena, FusedAdam, sequential_offsets
+    from tinyedm_amd.ema import FlatArena, FusedAdam, layout_offsets, sequential_offsets
     torch.manual_seed(0)
     ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.tensor(0.5)), torch.nn.Parameter(torch.randn(70)),
           torch.nn.Parameter(torch.tensor(-1.5)), torch.nn.Parameter(torch.randn(2, 2, 3, 3))]
+    ps[0]._edm_late = True                       # e.g. a block's embed.weight
     vals = [p.detach().clone() for p in ps]
     opt = FusedAdam(ps, lr=1e-3)
     a = opt.arena
-    assert a.LAYOUT == 2 and a.scalar_lo == 64 + 128 + 64 and a.numel == a.scalar_lo + 128
-    assert a.offsets == [0, a.scalar_lo, 64, a.scalar_lo + 64, 192]
+    # body: ps[2] (128 aligned), ps[4] (64); late region: ps[0] (64), then the scalars ps[1], ps[3] (64 each)
+    assert a.LAYOUT == 3 and a.scalar_lo == 128 + 64 and a.numel == a.scalar_lo + 64 + 128
+    assert a.offsets == [192, 256, 0, 320, 128]
     for p, v, o in zip(ps, vals, a.offsets):
         assert torch.equal(p.detach(), v) and p.data_ptr() == a.theta.data_ptr() + 4 * o and p.grad.data_ptr() == a.grad.data_ptr() + 4 * o
-    # a layout-1 state: m / v laid out sequentially in list order
-    old, total = sequential_offsets(ps)
-    m1, v1 = torch.zeros(total), torch.zeros(total)
-    for k, (p, o) in enumerate(zip(ps, old)):
-        m1[o:o + p.numel()] = k + 1
-        v1[o:o + p.numel()] = 10 * (k + 1)
-    opt.load_state_dict({"m": m1, "v": v1, "step": 7, "param_groups": [{"lr": 1e-3, "betas": (0.9, 0.999), "eps": 1e-8}]})
-    assert opt.step_count == 7
-    for k, (p, o) in enumerate(zip(ps, a.offsets)):
-        assert (opt.m[o:o + p.numel()] == k + 1).all() and (opt.v[o:o + p.numel()] == 10 * (k + 1)).all()
-    # its own (layout 2) state round-trips unchanged
+    # older states: layout 1 (m / v laid out sequentially in list order) and layout 2 (only the scalars in the tail)
+    for layout in (1, 2):
+        old, _, total = layout_offsets(ps, layout)
+        if layout == 1:
+            assert (old, total) == sequential_offsets(ps)
+        else:
+            assert old == [0, 256, 64, 320, 192] and total == 384
+        m1, v1 = torch.zeros(total), torch.zeros(total)
+        for k, (p, o) in enumerate(zip(ps, old)):
+            m1[o:o + p.numel()] = k + 1
+            v1[o:o + p.numel()] = 10 * (k + 1)
+        sd_old = {"m": m1, "v": v1, "step": 7, "param_groups": [{"lr": 1e-3, "betas": (0.9, 0.999), "eps": 1e-8}]}
+        if layout > 1:
+            sd_old["layout"] = layout
+        opt.load_state_dict(sd_old)
+        assert opt.step_count == 7
+        for k, (p, o) in enumerate(zip(ps, a.offsets)):
+            assert (opt.m[o:o + p.numel()] == k + 1).all() and (opt.v[o:o + p.numel()] == 10 * (k + 1)).all()
+    # its own (layout 3) state round-trips unchanged
     sd = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in opt.state_dict().items()}
-    assert sd["layout"] == 2
-    opt2 = FusedAdam([torch.nn.Parameter(v.clone()) for v in vals], lr=1e-3)
+    assert sd["layout"] == 3
+    ps2 = [torch.nn.Parameter(v.clone()) for v in vals]
+    ps2[0]._edm_late = True
+    opt2 = FusedAdam(ps2, lr=1e-3)
     opt2.load_state_dict(sd)
     assert torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v)

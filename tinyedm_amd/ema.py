@@ -42,32 +42,54 @@ def sequential_offsets(params):
     return offs, off
 
 
+def _is_late(p) -> bool:
+    """the parameter's gradient becomes final only when the backward pass ENDS: 0-dim parameters (block gains: one
+    modulation finish per step; gain_out rides along) and the weights flagged by the network (`_edm_late`: the blocks'
+    embed Linears and the Embedding module, whose weight gradients are ONE launch behind every block's backward)"""
+    return p.dim() == 0 or bool(getattr(p, "_edm_late", False))
+
+
+def layout_offsets(params, layout: int):
+    """-> (offsets in the caller's parameter order, first offset of the late region, total elements) of arena layout 1 / 2 / 3"""
+    if layout == 1:
+        offs, total = sequential_offsets(params)
+        return offs, total, total
+    late = (lambda p: p.dim() == 0) if layout == 2 else _is_late
+    offs, off = [0] * len(params), 0
+    for i, p in enumerate(params):
+        if not late(p):
+            offs[i] = off
+            off += _align(p.numel())
+    lo = off
+    for tensors_first in (True, False):          # late tensors, then the 0-dim parameters (layout 2: only the latter exist)
+        for i, p in enumerate(params):
+            if late(p) and (p.dim() > 0) == tensors_first:
+                offs[i] = off
+                off += _align(p.numel())
+    return offs, lo, off
+
+
 class FlatArena:
     """Re-homes a parameter list into one contiguous fp32 buffer (views keep names/shapes/strides).
 
-    Layout 2 (round 3): the tensor parameters in list order, then a TAIL holding the 0-dim parameters (block gains,
-    gain_out) -- `self.params` keeps the caller's order (index i is the i-th parameter of the optimizer, which is what
-    torch-Adam checkpoints are keyed on), only the offsets differ.  The scalar gradients are the last to become final in
-    a backward pass (the blocks' modulation finish is ONE launch at its very end), so they must not sit inside the
-    buckets of the weights around them: the data-parallel reducer gives the tail its own, last bucket."""
-    LAYOUT = 2
+    Layout 3 (round 5): the parameters whose gradients are final when their own layer's backward has run, in list order;
+    then a TAIL with every parameter whose gradient becomes final only at the END of the backward pass -- the blocks' embed
+    Linear weights and the Embedding module (their weight gradients are one launch behind all blocks), then the 0-dim
+    parameters (block gains, gain_out).  `self.params` keeps the caller's order (index i is the i-th parameter of the
+    optimizer, which is what torch-Adam checkpoints are keyed on), only the offsets differ.  Why: the data-parallel
+    reducer launches a bucket's all-reduce when ALL its gradients are final.  In layout 2 (round 3: only the 0-dim parameters
+    in the tail) every 32 MB bucket contained some block's embed weight, so NO bucket could start before the backward pass
+    ended (tests/test_rccl_gpu.py, round 5: 0.00 of the bytes issued before the last weight-gradient launch); now the
+    tail is the reducer's last bucket(s) and the body's buckets follow the weight-gradient launches."""
+    LAYOUT = 3
 
     def __init__(self, params: List[torch.nn.Parameter]):
         self.params = [p for p in params if p.requires_grad]
         dev = self.params[0].device
-        self.offsets, off = [0] * len(self.params), 0
         for p in self.params:
             if p.dtype != torch.float32:
                 raise TypeError("FlatArena expects fp32 master parameters")
-        for i, p in enumerate(self.params):
-            if p.dim() > 0:
-                self.offsets[i] = off
-                off += _align(p.numel())
-        self.scalar_lo = off                 # [scalar_lo, numel): the 0-dim parameters
-        for i, p in enumerate(self.params):
-            if p.dim() == 0:
-                self.offsets[i] = off
-                off += _align(p.numel())
+        self.offsets, self.scalar_lo, off = layout_offsets(self.params, self.LAYOUT)   # [scalar_lo, numel): the late region
         self.numel = off
         self.theta = torch.zeros(off, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(off, device=dev, dtype=torch.float32)
@@ -155,9 +177,9 @@ class FusedAdam(torch.optim.Optimizer):
             if sd.get("layout", 1) == FlatArena.LAYOUT:
                 self.m.copy_(sd["m"])
                 self.v.copy_(sd["v"])
-            else:       # a checkpoint of rounds 1-2: parameters laid out in list order -- move every slice to its new home
+            else:       # a checkpoint of an earlier round's arena layout: move every slice to its new home
                 a = self.arena
-                old, total = sequential_offsets(a.params)
+                old, _, total = layout_offsets(a.params, int(sd.get("layout", 1)))
                 if sd["m"].numel() != total:
                     raise ValueError(f"optimizer state: flat arena of {sd['m'].numel()} elements, expected {total}")
                 for p, o_new, o_old in zip(a.params, a.offsets, old):

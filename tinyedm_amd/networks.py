@@ -704,9 +704,11 @@ class Embedding(nn.Module):
         self.num_classes = num_classes
         self.fourier_embed = FourierEmbedding(fourier_dim)
         self.sigma_embed = Linear(fourier_dim, embedding_dim)
+        self.sigma_embed.weight._edm_late = True      # (gradients written at the very end of a backward pass: ema.FlatArena)
         self.class_embed = None
         if num_classes is not None and num_classes != -1:
             self.class_embed = ClassEmbedding(num_classes, embedding_dim)
+            self.class_embed.linear.weight._edm_late = True
 
     def forward(self, sigmas: Tensor, class_labels: Tensor | None = None):
         if class_labels is not None and self.class_embed is None:
@@ -1017,6 +1019,7 @@ class _BlockBase(nn.Module):
         self.dropout = nn.Dropout(dropout_rate)
         self.attention = CosineAttention(out_channels, num_heads) if attention else nn.Identity()
         self.embed = Linear(embedding_dim, out_channels)
+        self.embed.weight._edm_late = True        # its gradient is written by _EmbedAllFn.backward, behind every block (ema.FlatArena)
         self.gain = nn.Parameter(torch.ones(()))
         _rng_sub_counter[0] += 1
         self.rng_sub = _rng_sub_counter[0]

@@ -185,6 +185,7 @@ class Trainer:
             if done:
                 break
             self.current_epoch = epoch
+            ep_t0, ep_imgs = time.time(), imgs
             if hasattr(train, "epoch"):
                 train.epoch = epoch               # resident loaders: the shuffle is a function of (seed, epoch)
             for bi, batch in enumerate(train):
@@ -219,6 +220,10 @@ class Trainer:
                         done = True
                         break
             self._batch_in_epoch = 0
+            if self.global_rank == 0 and os.environ.get("EDM_FIT_EPOCH_RATE") == "1" and torch.cuda.is_available():
+                torch.cuda.synchronize()      # (diagnostic: the steady-state rate of the training loop, one epoch at a time)
+                print(f"[fit] epoch {epoch} rate {(imgs - ep_imgs) / (time.time() - ep_t0):.1f} img/s "
+                      f"({'hipGraph replay' if captured is not None else 'eager loop'})", flush=True)
             if self.scheduler_interval == "epoch":
                 self.lr_scheduler.step()
             if hasattr(model, "train_mse") and int(model.train_mse.total) > 0:
