@@ -335,9 +335,14 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_fwd(const bf16* __restrict
     for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    // software-pipelined by one key block: the QK^T MFMAs of block kt + 1 are in the matrix pipe while the vector ALU turns
+    // block kt's scores into probabilities
+    f32x16 Sn = score_tile(Kn + l31 * RS + lhi * 16, bq);
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
-      f32x16 S = score_tile(Kn + (kt * 32 + l31) * RS + lhi * 16, bq);
+      f32x16 S = Sn;
+      if (kt + 1 < NT) Sn = score_tile(Kn + ((kt + 1) * 32 + l31) * RS + lhi * 16, bq);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float p = __builtin_amdgcn_exp2f(fmaf(S[r], sl2, -c0));
@@ -358,6 +363,7 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_fwd(const bf16* __restrict
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(p0, p0 + 8 * RS), pb, o[dt], 0, 0, 0);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     l += __shfl_xor(l, 32, 64);
     const float linv = 1.0f / l;
@@ -687,10 +693,17 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict
       for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accq[dt][r] = 0.f;
+      // software-pipelined by one key block: the score / dP MFMAs of block kt + 1 run while the vector ALU works on block kt
+      f32x16 Sn = score_tile_init(Kn + l31 * RS + lhi * 16, bq, s_init);
+      f32x16 dPn = score_tile_init(Vn + l31 * RS + lhi * 16, bdo, d_init);   // dP^T tile: keys x queries
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
-        f32x16 S = score_tile_init(Kn + (kt * 32 + l31) * RS + lhi * 16, bq, s_init);
-        f32x16 dP = score_tile_init(Vn + (kt * 32 + l31) * RS + lhi * 16, bdo, d_init);   // dP^T tile: keys x queries
+        f32x16 S = Sn, dP = dPn;
+        if (kt + 1 < NT) {
+          Sn = score_tile_init(Kn + ((kt + 1) * 32 + l31) * RS + lhi * 16, bq, s_init);
+          dPn = score_tile_init(Vn + ((kt + 1) * 32 + l31) * RS + lhi * 16, bdo, d_init);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float p = __builtin_amdgcn_exp2f(S[r] * sl2);
@@ -710,6 +723,7 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict
             accq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(p0, p0 + 8 * RS), ds, accq[dt], 0, 0, 0);
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
       norm_bwd_store(accq, Qn + qi * RS, dsave[0 * NP + qi], gqkv + ((long)b * N + qi) * 3 * C + head * 3 * D, lhi, tvalid);
     }
@@ -731,9 +745,9 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict
           acck[dt][r] = 0.f;
           accv[dt][r] = 0.f;
         }
-#pragma unroll 1
-      for (int qt = 0; qt < NT; ++qt) {
-        // S tile: rows = queries (registers), cols = keys (lane); the queries' constants are the initial accumulators
+      // the queries' constants are the initial accumulators of a tile (rows = queries in the registers, columns = keys on
+      // the lanes); software-pipelined by one query block like pass 1
+      auto tiles = [&](int qt, f32x16& S, f32x16& dP) {
         f32x16 s_init, d_init;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -746,8 +760,16 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict
             d_init[4 * g + r] = dd[r];
           }
         }
-        f32x16 S = score_tile_init(Qn + (qt * 32 + l31) * RS + lhi * 16, bk, s_init);
-        f32x16 dP = score_tile_init(dO + (qt * 32 + l31) * RS + lhi * 16, bv, d_init);
+        S = score_tile_init(Qn + (qt * 32 + l31) * RS + lhi * 16, bk, s_init);
+        dP = score_tile_init(dO + (qt * 32 + l31) * RS + lhi * 16, bv, d_init);
+      };
+      f32x16 Sn, dPn;
+      tiles(0, Sn, dPn);
+#pragma unroll
+      for (int qt = 0; qt < NT; ++qt) {
+        f32x16 S = Sn, dP = dPn;
+        if (qt + 1 < NT) tiles(qt + 1, Sn, dPn);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float p = __builtin_amdgcn_exp2f(S[r] * sl2);            // the normalised probability
@@ -767,6 +789,7 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict
             acck[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(p1, p1 + 8 * RS), ds, acck[dt], 0, 0, 0);
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int dt = 0; dt < D / 32; ++dt)
