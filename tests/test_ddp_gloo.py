@@ -186,3 +186,39 @@ def test_ranks_keep_distinct_philox_seeds_across_a_resume(tmp_path):
     assert resumed0 == fresh0 and resumed1 == fresh1
     assert step0 == step1 == 17
     assert torch.load(ckpt, weights_only=False)["tinyedm_amd"]["rng_seed"] == 42
+
+
+def test_bucket_plan_keeps_late_gradients_out_of_the_body_and_shrinks_the_tail():
+    """Round 5: a bucket's all-reduce starts when ALL its gradients are final, so (1) the parameters whose
+    gradients are written at the very end of a backward pass (flagged `_edm_late`: the blocks' embed Linears, the Embedding
+    module; and the 0-dim gains) live in the arena's tail = the reducer's LAST bucket, none of them inside a body bucket,
+    and (2) the buckets over the last-finished 16 MB of the body (lowest offsets = first layers) are at most 8 MB while the
+    others go up to the requested 32 MB.  Pure host logic: no process group needed."""
+    from tinyedm_amd.ddp import GradReducer
+    from tinyedm_amd.ema import FlatArena
+    torch.manual_seed(0)
+    params, late = [], set()
+    for blk in range(40):                           # 40 "blocks": a 2.25 MB conv weight, a late embed weight, a late gain
+        params.append(torch.nn.Parameter(torch.empty(256, 256, 3, 3)))
+        e = torch.nn.Parameter(torch.empty(256, 64))
+        e._edm_late = True
+        g = torch.nn.Parameter(torch.zeros(()))
+        params += [e, g]
+        late |= {len(params) - 2, len(params) - 1}
+    arena = FlatArena(params)
+    red = GradReducer(arena)                        # world 1, inactive: only the plan is built
+    assert not red.active
+    lo = arena.scalar_lo
+    assert all((arena.offsets[i] >= lo) == (i in late) for i in range(len(params)))
+    tail = red.buckets[-1]
+    assert tail["lo"] == lo and tail["hi"] == arena.numel and set(tail["params"]) == late
+    body = red.buckets[:-1]
+    assert all(set(b["params"]).isdisjoint(late) for b in body)
+    assert sum(b["hi"] - b["lo"] for b in red.buckets) == arena.numel
+    region = GradReducer.TAIL_REGION_BYTES // 4
+    sizes_tail = [(b["hi"] - b["lo"]) * 4 for b in body if b["hi"] <= region]
+    sizes_rest = [(b["hi"] - b["lo"]) * 4 for b in body if b["hi"] > region]
+    assert sizes_tail and max(sizes_tail) <= GradReducer.TAIL_BUCKET_BYTES + 4 * 256 * 256 * 9     # (one tensor of slack)
+    assert max(sizes_rest) > GradReducer.TAIL_BUCKET_BYTES and max(sizes_rest) <= (32 << 20) + 4 * 256 * 256 * 9
+    # buckets are in backward order: the first one holds the LAST body parameters, the last body bucket starts at offset 0
+    assert body[0]["hi"] == lo and body[-1]["lo"] == 0

@@ -68,7 +68,9 @@ class GradReducer:
             idx = body[k]
             off = arena.offsets[idx]
             end = arena.offsets[body[k + 1]] if k + 1 < len(body) else scalar_lo
-            if cur is None or cur["hi"] - off > (per_tail if cur["hi"] <= tail_region else per_bucket):
+            in_tail = cur is not None and cur["hi"] <= tail_region
+            crossing = cur is not None and not in_tail and end <= tail_region       # (a new bucket starts AT the region's edge)
+            if cur is None or crossing or cur["hi"] - off > (per_tail if in_tail else per_bucket):
                 cur = {"lo": off, "hi": end, "params": [], "pending": 0, "work": None}
                 self.buckets.append(cur)
             cur["lo"] = off
