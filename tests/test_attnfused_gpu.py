@@ -119,3 +119,46 @@ def test_attention_qkv_bwd(ops, B, H, W):
     gy_u = ops.conv_igemm(nhwc(gout), wd_out, 1, alpha=alpha)
     gqkv_u = ops.attention_bwd(qkv_u, y_u, gy_u, heads)
     assert rel(nchw(gqkv), nchw(gqkv_u)) < 1.2e-2
+
+
+def test_attention_module_runs_the_fused_kernels_and_matches_the_unfused_path():
+    """`CosineAttention` (the module API, networks.py:181-207): with the fused kernels on (default) and off
+    (`ops.ATTN_FUSED = False`) the block's output and all three gradients (input, qkv weight, out weight) agree to bf16
+    rounding; a forward under torch.no_grad() keeps no softmax statistics."""
+    import tinyedm_amd as T
+    from tinyedm_amd import networks as N, ops as O_
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    g = torch.Generator().manual_seed(3)
+    att = N.CosineAttention(256, 4).to(DEV)
+    x0 = nhwc(q(torch.randn(5, 256, 8, 8, generator=g)))
+    gy = nhwc(q(torch.randn(5, 256, 8, 8, generator=g)))
+    res = {}
+    old = O_.ATTN_FUSED
+    try:
+        for fused in (True, False):
+            O_.ATTN_FUSED = fused
+            att.train()
+            for p in att.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            calls = []
+            orig = O_.attention_qkv_fwd
+            O_.attention_qkv_fwd = lambda *a, **k: (calls.append(k.get("want_stat", True)), orig(*a, **k))[1]
+            try:
+                y = att.forward_nhwc(x)
+                y.backward(gy)
+                att.eval()
+                with torch.no_grad():
+                    y2 = att.forward_nhwc(x0)
+            finally:
+                O_.attention_qkv_fwd = orig
+            torch.cuda.synchronize()
+            assert calls == ([True, False] if fused else []), calls        # grad pass keeps stat, no_grad pass does not
+            assert rel(y2.float(), y.detach().float()) < 4e-3        # (eval re-derives the packs from the renormalised weights)
+            res[fused] = (y.detach().float().cpu(), x.grad.float().cpu(), att.qkv_conv.weight.grad.float().cpu(),
+                          att.out_conv.weight.grad.float().cpu())
+    finally:
+        O_.ATTN_FUSED = old
+    for a, b, lim in zip(res[True], res[False], (6e-3, 1.2e-2, 1.2e-2, 1.2e-2)):
+        assert rel(a, b) < lim, (rel(a, b), lim)
