@@ -754,7 +754,8 @@ class CosineAttention(nn.Module):
 
     def forward_nhwc(self, x: Tensor, dest=None) -> Tensor:
         """dest = (cat, sil) buffers of the next decoder block: see FUSE_CAT"""
-        out = _AttnFn.apply(x, self.qkv_conv.weight, self.out_conv.weight, self, dest)
+        # (grad mode is always off INSIDE Function.forward: whether a backward can follow is decided here)
+        out = _AttnFn.apply(x, self.qkv_conv.weight, self.out_conv.weight, self, dest, torch.is_grad_enabled())
         if dest is not None and out.data_ptr() == dest[0].data_ptr():
             out._edm_cat = dest
         return out
@@ -786,14 +787,13 @@ class _AttnFn(torch.autograd.Function):
     launches as before."""
 
     @staticmethod
-    def forward(ctx, x, w_qkv, w_out, mod: CosineAttention, dest=None):
+    def forward(ctx, x, w_qkv, w_out, mod: CosineAttention, dest=None, grad_mode: bool = True):
         wf_qkv, wd_qkv, _ = mod.qkv_conv.packs()
         wf_out, wd_out, _ = mod.out_conv.packs()
         fused = ops.attention_qkv_supported(x, mod.num_heads)
         stat = qkv = None
         if fused:
-            # (grad mode is off inside Function.forward: needs_input_grad says whether a backward can follow)
-            y, stat = ops.attention_qkv_fwd(x, wf_qkv, mod.num_heads, want_stat=any(ctx.needs_input_grad[:3]))
+            y, stat = ops.attention_qkv_fwd(x, wf_qkv, mod.num_heads, want_stat=grad_mode and any(ctx.needs_input_grad[:3]))
         else:
             qkv = ops.conv_igemm(x, wf_qkv, 1)
             y = ops.attention_fwd(qkv, mod.num_heads)
@@ -830,7 +830,7 @@ class _AttnFn(torch.autograd.Function):
         gw_out = _wgrad(mod.out_conv, y, gout, 1, b)
         gx = ops.conv_igemm(gqkv, wd_qkv, 1, residual=gout, alpha=1.0, beta=a)
         gw_qkv = _wgrad(mod.qkv_conv, x, gqkv, 1)
-        return gx, gw_qkv, gw_out, None, None
+        return gx, gw_qkv, gw_out, None, None, None
 
 
 # --------------------------------------------------------------------------------------
