@@ -195,6 +195,8 @@ def test_bench_and_fit_through_the_nccl_backend_on_one_gpu(tmp_path):
     # the collective-bearing step is host-cheap: the all-reduces are nodes of the replayed graph
     assert line["config"]["graph_host_ms_per_step"] <= 5.0, line["config"]
     assert line["config"]["step_launch"] in ("hipGraph replay", "eager")
+    # round 5: the eager probe reports what the step could not hide of its all-reduces (events around finish()'s wait)
+    assert 0.0 <= line["config"]["exposed_comm_ms"] < 50.0 and line["config"]["grad_buckets"] >= 2, line["config"]
 
 
 def test_bench_capture_watchdog_reports_the_eager_line(tmp_path):
