@@ -317,6 +317,10 @@ def _wgrad(mod, x, dy, taps, scale=1.0):
     return mod.finish_grad(ops.conv_wgrad(x, dy, taps), scale=scale)
 
 
+# bf16 tile of a weight-prep workgroup (rows x fan_in): 96 KB = 16 rows of a 256-channel 3x3 layer, two workgroups per CU
+PREP_TILE_BYTES = int(os.environ.get("EDM_PREP_TILE_KB", "96")) * 1024
+
+
 class _PrepPlan:
     """Multi-tensor weight preparation: ONE launch normalises and packs every weight of a network
     (edm_weight_prep_multi) into persistent kernel-layout buffers, instead of one launch per layer."""
@@ -355,7 +359,7 @@ class _PrepPlan:
                 m._perm = m._perm.to(dev)
             # rows per workgroup: the bf16 tile rb x (I*taps) must fit LDS; power of two <= 32
             rb = 32
-            while rb > 1 and (rb * I * taps * 2 > 96 * 1024 or rb > O):
+            while rb > 1 and (rb * I * taps * 2 > PREP_TILE_BYTES or rb > O):
                 rb //= 2
             lds = max(lds, rb * I * taps * 2)
             ff, fd = frag.get(m, (False, False))
