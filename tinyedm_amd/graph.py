@@ -261,6 +261,8 @@ class CapturedTrainStep:
 
     def __del__(self):
         try:
+            if self._graphs:
+                torch.cuda.synchronize()        # (a replay of a dying graph may still be running: see _drop)
             for ent in self._graphs.values():
                 ops.release_capture(ent[4])
         except Exception:       # noqa: BLE001  (interpreter shutdown)
