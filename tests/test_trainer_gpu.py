@@ -324,3 +324,32 @@ def test_generate_cli_reference_precision(tmp_path):
     assert np.abs(outs["f32x3"] - outs["f32"]).max() <= 1    # rounds to the exact-fp32 path's bytes (a grey level at most)
     d = np.abs(outs["bf16"] - outs["f32"])
     assert d.max() <= 3 and (d > 0).mean() < 0.2, (d.max(), (d > 0).mean())
+
+
+def test_fit_probes_eager_against_replay_and_trains_the_same(monkeypatch):
+    """Round 5: with EDM_GRAPH unset `Trainer.fit` captures the step, then runs a block of steps through the eager loop and
+    a block through the replay and keeps the faster form (`trainer.step_launch`).  Whatever it settles on, and however the
+    two forms were mixed on the way, the run equals an all-eager and an all-replay run of the same steps (same counters,
+    same Philox positions; weights up to the order of the fp32 atomics)."""
+    import tinyedm_amd as T
+    from tinyedm_amd import trainer as TR
+    monkeypatch.setattr(TR._LaunchProbe, "PROBE_STEPS", 3)
+    data = Batches(n=6)
+    res = {}
+    for mode in ("auto", "0", "1"):
+        if mode == "auto":
+            monkeypatch.delenv("EDM_GRAPH", raising=False)
+        else:
+            monkeypatch.setenv("EDM_GRAPH", mode)
+        m, *_ = build_model()
+        t = T.Trainer(max_epochs=3, max_steps=16)
+        t.fit(m.to(DEV), train_dataloaders=data)
+        res[mode] = (_state(t), t.step_launch, t.global_step)
+    assert res["auto"][1] in ("hipGraph replay", "eager loop") and res["0"][1] == "eager loop" and res["1"][1] == "hipGraph replay"
+    assert res["auto"][2] == res["0"][2] == res["1"][2] == 16
+    for other in ("0", "1"):
+        assert res["auto"][0]["step"] == res[other][0]["step"] and res["auto"][0]["ema_step"] == res[other][0]["ema_step"]
+        for k, lim in (("theta", 2e-4), ("ema", 2e-4), ("m", 1e-2), ("v", 1e-2)):
+            e = rel(res["auto"][0][k], res[other][0][k])
+            record(f"fit_probe/auto_vs_EDM_GRAPH={other}/{k}", e, lim)
+            assert e <= lim, (other, k, e)

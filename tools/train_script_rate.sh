@@ -6,9 +6,10 @@ O=$R/gpurun_out/train_script.txt
 : > $O
 echo "# experiments/train.py --config-name=cifar10 (synthetic resident data, batch 256, 195 full batches + one of 80 per epoch)," >> $O
 echo "# per-epoch rate of Trainer.fit (EDM_FIT_EPOCH_RATE=1), validation and callbacks off; then bench.py at the same batch" >> $O
-for g in 1 0; do
-  echo "## EDM_GRAPH=$g" >> $O
-  EDM_GRAPH=$g EDM_FIT_EPOCH_RATE=1 timeout -k 10 400 python3 $R/experiments/train.py --config-name=cifar10 trainer.max_epochs=5 \
+for g in auto 1 0; do
+  echo "## EDM_GRAPH=$g (auto = unset: fit() probes both forms and keeps the faster)" >> $O
+  if [ $g = auto ]; then unset EDM_GRAPH; else export EDM_GRAPH=$g; fi
+  EDM_FIT_EPOCH_RATE=1 timeout -k 10 400 python3 $R/experiments/train.py --config-name=cifar10 trainer.max_epochs=5 \
       trainer.check_val_every_n_epoch=1000 callbacks=null 2>&1 | grep "rate" >> $O || exit 1
 done
 echo "## bench.py --batch 256 (hipGraph replay of the same step, one resident batch)" >> $O
