@@ -201,7 +201,7 @@ int edm_attention_qkv_fwd(const void* x, const void* Wqkv, void* y, void* stat, 
  * = d loss / d qkv_conv(x) from gout = d loss / d out_conv(y) [B*N, C].  dO = alpha * gout . W_out is formed inside from
  * Wd_out = the out conv's dgrad pack [C, C] (alpha = the mp_add coefficient of the attention branch); q, k, v are recomputed
  * from x and Wqkv; y, stat = the forward's outputs.  The callers' remaining launches: the qkv conv's dgrad (gx) and the two
- * weight gradients. */
+ * weight gradients.  heads_per_wg: 0 or 1 (the backward runs one head per workgroup; anything else is refused). */
 int edm_attention_qkv_bwd(const void* x, const void* y, const void* gout, const void* stat, const void* Wqkv,
                           const void* Wd_out, void* gqkv, float alpha, int B, int N, int C, int heads, int heads_per_wg,
                           edm_stream_t stream);

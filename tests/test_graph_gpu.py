@@ -336,3 +336,39 @@ def test_launch_table_slots_are_released_and_bare_captures_have_their_own_index(
         _ = torch.ones(4, device="cuda") + 1
         h, d, defer, _rel = t.take(dev)
     assert defer == 0 and st["bare_i"] == bare0 + 1
+
+
+def test_plans_are_unpinned_when_their_graphs_go():
+    """a weight-prep plan is pinned while a captured graph reads its buffers -- and ONLY that long.  Evicting a
+    captured solve (the solver keeps MAX_GRAPHS per model) and releasing a captured training step give the pins back, so the
+    plans can be evicted again (before: pinned for the life of the Denoiser, every evicted graph kept its full pack set)."""
+    import tinyedm
+    from tinyedm_amd.graph import CapturedTrainStep
+    model, _ = _build(pdrop=0.0)
+    model.eval()
+    den = model.denoiser
+    solver = tinyedm.DeterministicSolver(num_steps=3)
+    solver.MAX_GRAPHS = 1
+    g = torch.Generator().manual_seed(3)
+    xa = torch.randn(4, 3, 16, 16, generator=g).to(DEV)
+    xb = torch.randn(6, 3, 16, 16, generator=g).to(DEV)
+    la, lb = torch.randint(0, 10, (4,), generator=g).to(DEV), torch.randint(0, 10, (6,), generator=g).to(DEV)
+    out_a = solver.solve(model, xa, la, graph=True)
+    pins_a = sum(p.pins for p in den._plans.values())
+    assert pins_a >= 1 and not any(p._pinned_forever for p in den._plans.values())
+    solver.solve(model, xb, lb, graph=True)                 # evicts the first solve: its pins go, the new solve's come
+    assert sum(p.pins for p in den._plans.values()) == pins_a
+    out_a2 = solver.solve(model, xa, la, graph=True)        # re-captured: same result
+    assert torch.equal(out_a, out_a2)
+    # a captured training step pins the training plan and release() unpins it
+    model.train()
+    opt, base, _ = _opt(model)
+    opt.zero_grad()
+    step = CapturedTrainStep(model, opt)
+    batch = ((0.5 * torch.randn(8, 3, 16, 16, generator=g)).to(DEV), torch.randint(0, 10, (8,), generator=g).to(DEV))
+    for _ in range(4):
+        step(batch)
+    assert step._graphs
+    before = sum(p.pins for p in den._plans.values())
+    step.release()
+    assert sum(p.pins for p in den._plans.values()) < before

@@ -240,3 +240,58 @@ def test_flat_arena_layout3_and_older_checkpoint_migration():
     opt2 = FusedAdam(ps2, lr=1e-3)
     opt2.load_state_dict(sd)
     assert torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v)
+    # a model whose late flags differ from the writer's (flag lost on a re-created Parameter) has other offsets
+    # for the same "layout 3": the stored offsets move every slice to its new home instead of scrambling the moments
+    ps3 = [torch.nn.Parameter(v.clone()) for v in vals]
+    opt3 = FusedAdam(ps3, lr=1e-3)
+    assert opt3.arena.offsets != a.offsets and sd["offsets"] == a.offsets
+    opt3.load_state_dict(sd)
+    for p, o3, o in zip(ps3, opt3.arena.offsets, a.offsets):
+        n = p.numel()
+        assert torch.equal(opt3.m[o3:o3 + n], opt.m[o:o + n]) and torch.equal(opt3.v[o3:o3 + n], opt.v[o:o + n])
+    bad = dict(sd, numels=[1] + sd["numels"][1:])
+    with pytest.raises(ValueError):
+        opt3.load_state_dict(bad)
+
+
+def test_launch_probe_verdict_follows_the_timed_blocks_only():
+    """the fit() probe times PROBE_STEPS steps per launch form AFTER untimed steps of that form (a cold first
+    eager step must not hand the verdict to the replay), and keeps the faster.  Stubbed clock: a step costs what the
+    table says; the first eager step (cold side stream) costs 50x."""
+    from tinyedm_amd import trainer as TR
+
+    class Captured:
+        _graphs = {((4, 3, 8, 8), None, None): object()}
+
+    class Clock:
+        def __init__(self):
+            self.t = 0.0
+
+        def mark(self):
+            return self.t
+
+        def elapsed(self, a, b):
+            return b - a
+
+    batch = (torch.zeros(4, 3, 8, 8), None)
+    for eager_ms, graph_ms, want_graph in ((10.0, 10.5, False), (10.0, 9.5, True)):
+        clock = Clock()
+        probe = TR._LaunchProbe(clock)
+        forms, first_eager = [], True
+        for _ in range(64):
+            use_graph = probe.choose(Captured, batch)
+            if probe.done:
+                break
+            forms.append(use_graph)
+            cost = graph_ms if use_graph else eager_ms
+            if not use_graph and first_eager:
+                cost, first_eager = 50 * eager_ms, False
+            clock.t += cost
+        assert probe.done and probe.graph_wins is want_graph
+        n, we, wg = probe.PROBE_STEPS, probe.WARM_STEPS["eager"], probe.WARM_STEPS["graph"]
+        assert forms == [False] * (we + n) + [True] * (wg + n)
+        assert abs(probe.times["eager"] - n * eager_ms) < 1e-9 and abs(probe.times["graph"] - n * graph_ms) < 1e-9
+        # a ragged batch in the middle of a probe is passed through untimed
+        probe2 = TR._LaunchProbe(Clock())
+        probe2.choose(Captured, batch)
+        assert probe2.choose(Captured, (torch.zeros(2, 3, 8, 8), None)) is False and probe2.n == 1 - probe2.WARM_STEPS["eager"]

@@ -868,7 +868,7 @@ extern "C" int edm_attention_qkv_bwd(const void* x, const void* y, const void* g
   (void)zero_page_;
   const int nt = (N + 31) / 32;
   const int HP = 1;           // (one head per workgroup: see the kernel)
-  (void)hp;
+  EDM_REQUIRE(hp == 0 || hp == 1, "attention_qkv_bwd: the backward runs one head per workgroup (heads_per_wg 0 or 1, got %d)", hp);
   // 256-token maps: nine ring slots laid over the Q | K | V image regions (152 KB in all); smaller maps: a ring of its own
   if (nt <= 2) launch_bwd<2, 3, false>(x, y, gout, stat, Wqkv, Wd_out, gqkv, alpha, B, N, heads, HP, st);
   else if (nt <= 4) launch_bwd<4, 6, false>(x, y, gout, stat, Wqkv, Wd_out, gqkv, alpha, B, N, heads, HP, st);

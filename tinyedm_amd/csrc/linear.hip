@@ -1,140 +1,93 @@
 // fp32 side path: the weight-normalised Linear layers (networks.py:58-60) and the noise / class
 // embedding (networks.py:121-178).  The reference keeps these in fp32 under autocast
-// (networks.py:164, 255, 319); they are tiny ((B,64..1000)->(B,256..768)), so a plain LDS-tiled
-// fp32 FMA GEMM with arbitrary strides covers forward, dgrad and wgrad.
+// (networks.py:164, 255, 319); they are tiny ((B,64..1000)->(B,256..768)): one LDS-tiled fp32 GEMM on the
+// f32-input matrix instruction, with arbitrary operand strides, covers forward, dgrad and wgrad.
 #include "common.h"
 
 namespace {
 
 // C[m,n] (=|+=) alpha * sum_k A[m*asm + k*ask] * B[k*bsk + n*bsn]
-__global__ __launch_bounds__(256) void k_sgemm(const float* __restrict__ A, long asm_, long ask,
-                                                 const float* __restrict__ Bm, long bsk, long bsn,
-                                                 float* __restrict__ C, long csm, long csn, int M, int N, int K,
-                                                 float alpha, int accumulate) {
-  constexpr int TM = 32, TN = 32, TK = 32;
-  __shared__ float As[TK][TM + 1];
-  __shared__ float Bs[TK][TN + 1];
-  // 256 threads: 16x16 threads x (2x2 outputs) = 32x32 tile (small tiles: these GEMMs are tiny, parallelism first)
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+// Round 6: the same GEMM on the f32-input matrix instruction (v_mfma_f32_32x32x2_f32: every product and sum a plain fp32
+// operation, as in csrc/eval_f32.hip).  k_sgemm_smallk staged the whole K extent of BOTH operands per 32x32 tile -- the
+// batched embed Linear of a sampler evaluation (512 x 256 -> 5 376: networks._EmbedAllFn) re-read 176 MB through L2 and took
+// 121 us; this kernel gives a wave a 32x32 output block, a workgroup WM x WN of them, and walks K in chunks of 32 through LDS
+// (operands of any stride: forward, dgrad and wgrad of the Linears share it).  Split-K over gridDim.z as k_sgemm.
+template <int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void k_sgemm_mfma(const float* __restrict__ A, long asm_, long ask,
+                                                               const float* __restrict__ Bm, long bsk, long bsn,
+                                                               float* __restrict__ C, long csm, long csn, int M, int N, int K,
+                                                               float alpha, int accumulate) {
+  constexpr int TM = 32 * WM, TN = 32 * WN, TK = 32, NT = 64 * WM * WN;
+  constexpr int LDA = TM + 1, LDB = TN + 1;        // odd row pitch: the k-contiguous staging writes hit distinct banks
+  __shared__ float As[TK * LDA];
+  __shared__ float Bs[TK * LDB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lhi = lane >> 5;
   const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-  float acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = 0.f;
-  // split-K over gridDim.z (partial sums are combined with float atomics; C pre-zeroed by the launcher)
   const int kper = ((K + gridDim.z - 1) / gridDim.z + TK - 1) / TK * TK;
   const int kbeg = blockIdx.z * kper;
   const int kend = min(K, kbeg + kper);
-  K = kend;
-  for (int k0 = kbeg; k0 < K; k0 += TK) {
-    for (int e = threadIdx.x; e < TM * TK; e += 256) {
-      const int kk = e % TK, mm = e / TK;
-      const int m = m0 + mm, k = k0 + kk;
-      As[kk][mm] = (m < M && k < K) ? A[m * asm_ + k * ask] : 0.f;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = kbeg; k0 < kend; k0 += TK) {
+    if (ask == 1) {          // k contiguous: a wave's half reads 32 consecutive k of one row
+      for (int e = tid; e < TM * TK; e += NT) {
+        const int kk = e & 31, mm = e >> 5;
+        const int m = m0 + mm, k = k0 + kk;
+        As[kk * LDA + mm] = (m < M && k < kend) ? A[m * asm_ + k] : 0.f;
+      }
+    } else {                 // rows contiguous (or general strides)
+      for (int e = tid; e < TM * TK; e += NT) {
+        const int mm = e % TM, kk = e / TM;
+        const int m = m0 + mm, k = k0 + kk;
+        As[kk * LDA + mm] = (m < M && k < kend) ? A[m * asm_ + k * ask] : 0.f;
+      }
     }
-    for (int e = threadIdx.x; e < TN * TK; e += 256) {
-      const int kk = e % TK, nn = e / TK;
-      const int n = n0 + nn, k = k0 + kk;
-      Bs[kk][nn] = (n < N && k < K) ? Bm[k * bsk + n * bsn] : 0.f;
+    if (bsk == 1) {
+      for (int e = tid; e < TN * TK; e += NT) {
+        const int kk = e & 31, nn = e >> 5;
+        const int n = n0 + nn, k = k0 + kk;
+        Bs[kk * LDB + nn] = (n < N && k < kend) ? Bm[k + n * bsn] : 0.f;
+      }
+    } else {
+      for (int e = tid; e < TN * TK; e += NT) {
+        const int nn = e % TN, kk = e / TN;
+        const int n = n0 + nn, k = k0 + kk;
+        Bs[kk * LDB + nn] = (n < N && k < kend) ? Bm[k * bsk + n * bsn] : 0.f;
+      }
     }
     __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < TK; ++kk) {
-      float a[2], b[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = As[kk][ty * 2 + i];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = Bs[kk][tx * 2 + j];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] += a[i] * b[j];
+    for (int kk = 0; kk < TK; kk += 2) {
+      const float a = As[(kk + lhi) * LDA + wm * 32 + l31];
+      const float b = Bs[(kk + lhi) * LDB + wn * 32 + l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
     __syncthreads();
   }
+  // accumulator register r of a lane: row (of A) 8 (r / 4) + 4 lhi + (r % 4), column (of B) l31
+  const int n = n0 + wn * 32 + l31;
+  if (n >= N) return;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int m = m0 + ty * 2 + i, n = n0 + tx * 2 + j;
-      if (m < M && n < N) {
-        float* c = C + m * csm + n * csn;
-        if (gridDim.z > 1) atomicAdd(c, alpha * acc[i][j]);
-        else *c = accumulate ? *c + alpha * acc[i][j] : alpha * acc[i][j];
-      }
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+    if (m < M) {
+      float* c = C + m * csm + n * csn;
+      if (gridDim.z > 1) atomicAdd(c, alpha * acc[r]);
+      else *c = accumulate ? *c + alpha * acc[r] : alpha * acc[r];
     }
-}
-
-// Fast path for K <= 512: the whole K extent of a 32x32 output tile is staged at once (one barrier, no K loop),
-// because these GEMMs are latency-bound (a 128x256x256 problem is 17 MFLOP).  Round 4: the staging loops carry no integer
-// division (the thread -> (k, row) map is fixed per operand orientation; the old `e % K`, `e / K` per element were ~1 300 of
-// the kernel's ~3 500 instructions per thread), and a thread reads its two A rows / two B columns of a k with ONE 8-byte
-// LDS read each (rows padded to 34 floats: even, so the pairs are aligned).  The sum over k runs in the same order with
-// the same fma per element as before: results are bit-identical.
-__global__ __launch_bounds__(256) void k_sgemm_smallk(const float* __restrict__ A, long asm_, long ask,
-                                                        const float* __restrict__ Bm, long bsk, long bsn,
-                                                        float* __restrict__ C, long csm, long csn, int M, int N, int K,
-                                                        float alpha, int accumulate) {
-  constexpr int TM = 32, TN = 32, LD = 34;
-  extern __shared__ __attribute__((aligned(16))) float sm_[];
-  float (*As)[LD] = reinterpret_cast<float (*)[LD]>(sm_);
-  float (*Bs)[LD] = reinterpret_cast<float (*)[LD]>(sm_ + (size_t)K * LD);
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-  // the unit-stride dimension of each operand is the fast index of the thread map
-  if (ask == 1) {            // k contiguous: 64 k per pass, 4 rows per pass
-    const int tk = threadIdx.x & 63, tr = threadIdx.x >> 6;
-    for (int mm = tr; mm < TM; mm += 4) {
-      const int m = m0 + mm;
-      for (int kk = tk; kk < K; kk += 64) As[kk][mm] = (m < M) ? A[m * asm_ + kk] : 0.f;
-    }
-  } else {                   // rows contiguous (or general strides): 32 rows per pass, 8 k per pass
-    const int tr = threadIdx.x & 31, tk = threadIdx.x >> 5;
-    const int m = m0 + tr;
-    for (int kk = tk; kk < K; kk += 8) As[kk][tr] = (m < M) ? A[m * asm_ + kk * ask] : 0.f;
   }
-  if (bsk == 1) {
-    const int tk = threadIdx.x & 63, tr = threadIdx.x >> 6;
-    for (int nn = tr; nn < TN; nn += 4) {
-      const int n = n0 + nn;
-      for (int kk = tk; kk < K; kk += 64) Bs[kk][nn] = (n < N) ? Bm[kk + n * bsn] : 0.f;
-    }
-  } else {
-    const int tr = threadIdx.x & 31, tk = threadIdx.x >> 5;
-    const int n = n0 + tr;
-    for (int kk = tk; kk < K; kk += 8) Bs[kk][tr] = (n < N) ? Bm[kk * bsk + n * bsn] : 0.f;
-  }
-  __syncthreads();
-  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll 8
-  for (int kk = 0; kk < K; ++kk) {
-    const float2 a = *reinterpret_cast<const float2*>(&As[kk][ty * 2]);
-    const float2 b = *reinterpret_cast<const float2*>(&Bs[kk][tx * 2]);
-    acc[0][0] += a.x * b.x; acc[0][1] += a.x * b.y; acc[1][0] += a.y * b.x; acc[1][1] += a.y * b.y;
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int m = m0 + ty * 2 + i, n = n0 + tx * 2 + j;
-      if (m < M && n < N) {
-        float* c = C + m * csm + n * csn;
-        *c = accumulate ? *c + alpha * acc[i][j] : alpha * acc[i][j];
-      }
-    }
 }
 
 int sgemm(const float* A, long asm_, long ask, const float* B, long bsk, long bsn, float* C, long csm, long csn, int M,
           int N, int K, float alpha, int accumulate, hipStream_t st) {
-  if (K <= 512) {
-    EDM_MAX_LDS(k_sgemm_smallk, 160 * 1024);
-    hipLaunchKernelGGL(k_sgemm_smallk, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), (size_t)2 * K * 34 * sizeof(float),
-                       st, A, asm_, ask, B, bsk, bsn, C, csm, csn, M, N, K, alpha, accumulate);
-    return 0;
-  }
+  // tile: 64x64 (four waves) when that still gives every CU a workgroup, 32x64 (two waves) for the small problems
+  const long t64 = (long)((N + 63) / 64) * ((M + 63) / 64);
+  const bool big = t64 >= 256;
+  const long tiles = big ? t64 : (long)((N + 63) / 64) * ((M + 31) / 32);
   int splits = 1;
-  const long tiles = (long)((N + 31) / 32) * ((M + 31) / 32);
   if (K >= 1024 && tiles < 512 && csn == 1 && csm == N) {  // long-K, few tiles: split K to fill the chip
     long sp = K / 256, cap = (1024 + tiles - 1) / tiles;
     if (sp > cap) sp = cap;
@@ -142,8 +95,12 @@ int sgemm(const float* A, long asm_, long ask, const float* B, long bsk, long bs
     splits = (int)(sp < 1 ? 1 : sp);
     if (splits > 1 && !accumulate) (void)hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), st);
   }
-  hipLaunchKernelGGL(k_sgemm, dim3((N + 31) / 32, (M + 31) / 32, splits), dim3(256), 0, st, A, asm_, ask, B, bsk, bsn, C,
-                     csm, csn, M, N, K, alpha, accumulate);
+  if (big)
+    hipLaunchKernelGGL((k_sgemm_mfma<2, 2>), dim3((N + 63) / 64, (M + 63) / 64, splits), dim3(256), 0, st, A, asm_, ask, B,
+                       bsk, bsn, C, csm, csn, M, N, K, alpha, accumulate);
+  else
+    hipLaunchKernelGGL((k_sgemm_mfma<1, 2>), dim3((N + 63) / 64, (M + 31) / 32, splits), dim3(128), 0, st, A, asm_, ask, B,
+                       bsk, bsn, C, csm, csn, M, N, K, alpha, accumulate);
   return 0;
 }
 

@@ -52,9 +52,10 @@ class GradReducer:
         # fallback if forked capture misbehaves
         self.inline = os.environ.get("EDM_COMM_INLINE") == "1"
         self.comm_stream = torch.cuda.Stream() if (self.is_cuda and not self.inline) else None
-        # buckets = contiguous arena ranges, built in REVERSE parameter order (backward order) over the tensor parameters;
-        # the arena's tail of 0-dim parameters (block gains, gain_out: FlatArena layout 2) is ONE more bucket, the last --
-        # the block gains' gradients are final only when the backward pass ends (networks._EmbedAllFn.backward)
+        # buckets = contiguous arena ranges, built in REVERSE parameter order (backward order) over the arena's body; the
+        # arena's LATE region (FlatArena layout 3: the blocks' embed Linear weights, the Embedding module, then the 0-dim
+        # block gains and gain_out) is ONE more bucket, the last -- those gradients are final only when the backward pass
+        # ends (networks._EmbedAllFn.backward)
         per_bucket = max(1, bucket_bytes // 4)
         per_tail = max(1, min(bucket_bytes, self.TAIL_BUCKET_BYTES) // 4)
         tail_region = self.TAIL_REGION_BYTES // 4
@@ -84,9 +85,13 @@ class GradReducer:
         self._hooks = []
         self.measure = False                     # record events around finish()'s wait for the comm stream (bench.py)
         self._exposed = []
+        self._w3_tail_prev = None
         if self.world > 1 and "EDM_W3_TAIL" not in os.environ:
+            # a small final group (networks.W3_TAIL).  Process-global: it shapes every backward pass of this process while
+            # the reducer lives -- build the reducer BEFORE capturing a step, and close() it when the run is over
             from . import networks
-            networks.W3_TAIL = self.W3_TAIL      # a small final group: see networks.W3_TAIL
+            self._w3_tail_prev = networks.W3_TAIL
+            networks.W3_TAIL = self.W3_TAIL
         if self.active:
             for idx, p in enumerate(arena.params):
                 hook = self._make_hook(idx)
@@ -94,6 +99,21 @@ class GradReducer:
                 if hasattr(p, "_edm_hooks"):      # gradients written directly by the HIP finish kernel
                     p._edm_hooks.append(hook)
         self.reset()
+
+    def close(self):
+        """the run is over: take the hooks off the parameters and give networks.W3_TAIL back (the setting used to
+        outlive the reducer and regroup the weight-gradient launches of every later model in the process)"""
+        for h in self._hooks:
+            h.remove()
+        for idx, p in enumerate(self.arena.params):
+            hooks = getattr(p, "_edm_hooks", None)
+            if hooks:
+                hooks.clear()
+        self._hooks = []
+        self.active = False
+        if self._w3_tail_prev is not None:
+            from . import networks
+            networks.W3_TAIL, self._w3_tail_prev = self._w3_tail_prev, None
 
     def capturable(self) -> bool:
         """True when the collectives of a step can be captured into a hipGraph: RCCL on GPU tensors, all-reduced in place"""

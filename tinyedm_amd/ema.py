@@ -167,21 +167,33 @@ class FusedAdam(torch.optim.Optimizer):
                      g["eps"], max(1, self.step_count), 0.0, 1.0, dyn=dyn, zero_grad=True)
 
     def state_dict(self):
+        # "offsets": where each parameter's slice sits in m / v.  Layout 3 derives them from a Python attribute of the
+        # parameters (`_edm_late`); a checkpoint that only said "layout 3" could not tell a model whose flags differ
+        # (Parameter re-created, deepcopy, user re-init) from the one that wrote it
         return {"m": self.m, "v": self.v, "step": self.step_count, "layout": FlatArena.LAYOUT,
+                "offsets": list(self.arena.offsets), "numels": [p.numel() for p in self.arena.params],
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
         """Accepts this class's own layout ({m, v, step}: flat arenas) or torch.optim.Adam's
         ({state: {i: {step, exp_avg, exp_avg_sq}}, param_groups}: what the reference's checkpoints hold)."""
         if "m" in sd:
-            if sd.get("layout", 1) == FlatArena.LAYOUT:
-                self.m.copy_(sd["m"])
-                self.v.copy_(sd["v"])
-            else:       # a checkpoint of an earlier round's arena layout: move every slice to its new home
-                a = self.arena
+            a = self.arena
+            if "offsets" in sd:     # round 6 checkpoints carry the slices themselves
+                old = [int(o) for o in sd["offsets"]]
+                if len(old) != len(a.params) or [int(n) for n in sd["numels"]] != [p.numel() for p in a.params]:
+                    raise ValueError("optimizer state: the checkpoint's parameter list (count / sizes) does not match the model")
+                total = sd["m"].numel()
+                if any(o < 0 or o + p.numel() > total for p, o in zip(a.params, old)):
+                    raise ValueError("optimizer state: a stored offset lies outside the stored arena")
+            else:                   # older checkpoints: the slices follow from the layout number and the CURRENT flags
                 old, _, total = layout_offsets(a.params, int(sd.get("layout", 1)))
                 if sd["m"].numel() != total:
                     raise ValueError(f"optimizer state: flat arena of {sd['m'].numel()} elements, expected {total}")
+            if old == list(a.offsets) and sd["m"].numel() == self.m.numel():
+                self.m.copy_(sd["m"])
+                self.v.copy_(sd["v"])
+            else:       # another arena layout (an earlier round's, or different late flags): every slice to its new home
                 for p, o_new, o_old in zip(a.params, a.offsets, old):
                     n = p.numel()
                     self.m[o_new:o_new + n].copy_(sd["m"][o_old:o_old + n])

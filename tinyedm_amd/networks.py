@@ -325,8 +325,11 @@ class _PrepPlan:
     """Multi-tensor weight preparation: ONE launch normalises and packs every weight of a network
     (edm_weight_prep_multi) into persistent kernel-layout buffers, instead of one launch per layer."""
 
-    def __init__(self, mods, frag=None, wants=None):
-        """frag: {module: (fwd, dgrad)} -- the 3x3 convs whose forward / dgrad pack is written FRAGMENT-MAJOR (csrc/weights.hip)
+    def __init__(self, mods, frag=None, wants=None, cat=None):
+        """cat: Linear modules (same in_features) whose fp32 effective weights are laid out back to back in ONE buffer
+        (`self.wcat`, rows in the order given): the batched embed Linear of a Denoiser reads it as one GEMM operand -- no
+        torch.cat of 21 packs per forward (an ATen copy kernel in every captured step and sampler evaluation until round 6).
+        frag: {module: (fwd, dgrad)} -- the 3x3 convs whose forward / dgrad pack is written FRAGMENT-MAJOR (csrc/weights.hip)
         because k_conv3x3_s, the 8x8 layers' kernel, runs them at the current input shape (Denoiser._frag_flags).
         wants: per module, the packs this plan keeps ("fwd", "dgrad", "hat", "split"); default = the module's own.  "split" =
         the split-bf16 operand of the "f32x3" evaluation, a PERSISTENT buffer rewritten in place by run() (a captured solve
@@ -335,7 +338,8 @@ class _PrepPlan:
         frag = frag or {}
         wants = [tuple(m._want) for m in mods] if wants is None else list(wants)
         self.wants = wants
-        self.pinned = False         # a captured graph reads this plan's buffers: never evicted
+        self.pins = 0               # captured graphs that read this plan's buffers (ops.note_capture_pin / release_capture)
+        self._pinned_forever = False  # ... or a capture made without ops.capture_begin(): nobody can tell when it dies
         self.splits = []
         dev = mods[0].weight.device
         self.ptr_key = tuple(m.weight.data_ptr() for m in mods)
@@ -345,6 +349,15 @@ class _PrepPlan:
         assert desc.dtype.itemsize == 64
         groups, row0, lds = [], 0, 0
         self.caches = []
+        self.wcat, cat_rows = None, {}
+        if cat:
+            kin = cat[0].weight.shape[1]
+            if all(c.weight.dim() == 2 and c.weight.shape[1] == kin for c in cat):
+                self.wcat = torch.empty(sum(c.weight.shape[0] for c in cat), kin, device=dev, dtype=f32)
+                r = 0
+                for c in cat:
+                    cat_rows[c] = r
+                    r += c.weight.shape[0]
         for k, m in enumerate(mods):
             w = m.weight
             O, I, taps = w.shape[0], w.shape[1], m._taps()
@@ -352,7 +365,10 @@ class _PrepPlan:
             want = wants[k]
             wf = torch.empty(taps, O, ipad, device=dev, dtype=bf16) if "fwd" in want else None
             wd = torch.empty(taps, I, O, device=dev, dtype=bf16) if "dgrad" in want else None
-            wh = torch.empty(O, I * taps, device=dev, dtype=f32) if ("hat" in want or "split" in want) else None
+            if m in cat_rows:
+                wh = self.wcat[cat_rows[m]:cat_rows[m] + O]
+            else:
+                wh = torch.empty(O, I * taps, device=dev, dtype=f32) if ("hat" in want or "split" in want) else None
             self.splits.append(torch.empty(taps, O, 3 * ((I + 31) // 32 * 32), device=dev, dtype=bf16)
                                if "split" in want else None)
             if m._perm is not None and m._perm.device != dev:
@@ -382,6 +398,11 @@ class _PrepPlan:
         self.lds_bytes = lds
         self.eval_key = None
 
+    @property
+    def pinned(self) -> bool:
+        """a live captured graph reads this plan's buffers: never evicted"""
+        return self.pins > 0 or self._pinned_forever
+
     def valid_for(self, mods):
         return tuple(m.weight.data_ptr() for m in mods) == self.ptr_key
 
@@ -394,8 +415,8 @@ class _PrepPlan:
                     ops.split_pack(c[2], m._taps(), out=sp)
             # the in-place normalisation does not go through torch: remember what the packs correspond to
             self.eval_key = None if training else key
-        if torch.cuda.is_current_stream_capturing():
-            self.pinned = True
+        if torch.cuda.is_current_stream_capturing() and not ops.note_capture_pin(self):
+            self._pinned_forever = True
         for m, c, sp in zip(self.mods, self.caches, self.splits):
             m._cache = c
             m._cache_key = (m.weight.data_ptr(), m.weight._version, _WEIGHT_EPOCH)
@@ -1286,8 +1307,7 @@ class _EmbedAllFn(torch.autograd.Function):
     def forward(ctx, emb, den, *weights):
         ctx.set_materialize_grads(False)
         blocks = den._res_blocks()
-        whs = [b.embed.packs()[2] for b in blocks]
-        wcat = torch.cat(whs, 0)
+        wcat = den._wcat(blocks)
         lin_all = ops.linear_fwd(emb, wcat)
         glin_all = ops.zeros_f32(lin_all.shape, lin_all.device)
         # shared raw modulation-gradient buffer + the per-block table of ONE finish launch (only when every block gain's
@@ -1524,7 +1544,7 @@ class Denoiser(nn.Module):
                     plan.run(False)
         plan = plans.pop(key, None)
         if plan is None:
-            plan = _PrepPlan(mods, frag, base[1])
+            plan = _PrepPlan(mods, frag, base[1], cat=[b.embed for b in self._res_blocks()])
             for k in [k for k, p in plans.items() if k[0] != ptrs and not p.pinned]:
                 del plans[k]                    # packs of parameters that have been re-allocated since
             live = [k for k, p in plans.items() if not p.pinned]
@@ -1532,6 +1552,16 @@ class Denoiser(nn.Module):
                 del plans[k]                    # (dict order = least recently used first)
         plans[key] = plan                       # most recently used last
         plan.run(self.training)
+        self.__dict__["_embed_wcat"] = plan.wcat
+
+    def _wcat(self, blocks) -> Tensor:
+        """(sum C, E) fp32: the blocks' effective embed weights as one GEMM operand -- the current plan's contiguous buffer
+        when the modules' packs are its row blocks (always, inside a Denoiser forward), else a concatenation"""
+        whs = [b.embed.packs()[2] for b in blocks]
+        w = self.__dict__.get("_embed_wcat")
+        if w is not None and all(wh._base is w for wh in whs) and sum(wh.shape[0] for wh in whs) == w.shape[0]:
+            return w
+        return torch.cat(whs, 0)
 
     # ---- reference-precision evaluation (round 3): the reference samples / validates in fp32 (generate.py:39-44,
     # callbacks.py:41-49).  eval_dtype "f32" routes EVAL-mode forwards (no grad) through the exact-fp32 kernels of
@@ -1551,7 +1581,7 @@ class Denoiser(nn.Module):
 
     def _forward_f32(self, noisy: Tensor, sig: Tensor, emb: Tensor) -> Tensor:
         blocks = self._res_blocks()
-        lin_all = ops.linear_fwd(emb, torch.cat([b.embed.packs()[2] for b in blocks], 0))
+        lin_all = ops.linear_fwd(emb, self._wcat(blocks))
         lins, off = {}, 0
         for b in blocks:
             C = b.embed.weight.shape[0]

@@ -103,6 +103,18 @@ def capture_begin():
     _tables.begin()
 
 
+def note_capture_pin(obj) -> bool:
+    """`obj` (a weight-prep plan) is read by the graph being captured: it gets one pin (`obj.pins += 1`) that
+    release_capture() of this capture's token takes back.  False when the capture runs without capture_begin() /
+    capture_end() (nobody could release the pin: the caller pins for good)."""
+    if not _tables.deferring:
+        return False
+    if not any(o is obj for o in _tables.pins):
+        obj.pins += 1
+        _tables.pins.append(obj)
+    return True
+
+
 def capture_end():
     """-> token of the launch-table slots the capture took: hand it to release_capture() when the graph is destroyed"""
     _zero_pool.buf = None
@@ -139,6 +151,7 @@ class _LaunchTables:
         self.deferring = False
         self.pending = []           # (device tensor, host tensor) pairs to upload at capture_end()
         self.taken = []             # (device index, slot) of the running deferred capture
+        self.pins = []              # objects pinned by the running deferred capture (note_capture_pin)
 
     def _state(self, device):
         key = torch.device(device).index
@@ -208,7 +221,7 @@ class _LaunchTables:
         return st["host"][k].data_ptr(), st["devb"][k].data_ptr(), 0, release
 
     def begin(self):
-        self.deferring, self.pending, self.taken = True, [], []
+        self.deferring, self.pending, self.taken, self.pins = True, [], [], []
         if torch.cuda.is_available():
             self._reserve(self._state(torch.cuda.current_device()), 64)     # (a captured training step takes 9)
 
@@ -216,17 +229,37 @@ class _LaunchTables:
         """upload the tables of the capture that just ended (their launches have only been recorded so far)"""
         pend, self.pending, self.deferring = self.pending, [], False
         taken, self.taken = tuple(self.taken), []
+        pins, self.pins = tuple(self.pins), []
         for dev, host in pend:
             dev.copy_(host)
         if pend:
             torch.cuda.synchronize(pend[0][0].device)
-        return taken
+        return _CaptureToken(taken, pins)
 
     def release(self, token):
-        for key, k in token or ():
+        if token is None or token.released:
+            return
+        token.released = True
+        for key, k in token.slots:
             st = self.dev.get(key)
             if st is not None and k not in st["free"]:
                 st["free"].append(k)
+        for obj in token.pins:          # the graph that read these plans' buffers is gone (ADVICE r5: they used to stay
+            obj.pins = max(0, obj.pins - 1)   # pinned -- and their packs alive -- for the life of the Denoiser)
+
+
+class _CaptureToken:
+    """what a captured graph holds on to: launch-table slots and pinned weight-prep plans (ops.release_capture frees both)"""
+    __slots__ = ("slots", "pins", "released")
+
+    def __init__(self, slots, pins):
+        self.slots, self.pins, self.released = slots, pins, False
+
+    def __iter__(self):             # (round-4/5 callers iterated the token as its slot list)
+        return iter(self.slots)
+
+    def __len__(self):
+        return len(self.slots)
 
 
 _tables = _LaunchTables()
@@ -1035,7 +1068,8 @@ def attention_bwd(qkv, y, gy, heads):
 
 
 ATTN_FUSED = os.environ.get("EDM_ATTN_FUSED", "1") != "0"      # qkv projection inside the attention kernels (attention_fused.hip)
-ATTN_HP = int(os.environ.get("EDM_ATTN_HP", "0"))               # heads per workgroup (0 = the kernel's default)
+ATTN_HP = int(os.environ.get("EDM_ATTN_HP", "0"))               # heads per workgroup of the FORWARD (0 = the kernel's default;
+                                                                # the backward always runs one head per workgroup)
 
 
 def attention_qkv_supported(x, heads):

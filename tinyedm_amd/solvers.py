@@ -6,6 +6,15 @@ import torch
 from . import _runtime_env, ops
 
 
+def _release_solves(per_model: dict):
+    try:
+        for ent in per_model.values():
+            ops.release_capture(ent[5])
+        per_model.clear()
+    except Exception:       # noqa: BLE001  (interpreter shutdown)
+        pass
+
+
 class DeterministicSolver:
     """Algorithm 1 of Karras et al. 2022 with sigma(t)=t, s(t)=1.  Same constructor as the reference.
 
@@ -68,6 +77,8 @@ class DeterministicSolver:
         per_model = self._graphs.get(owner)
         if per_model is None:
             per_model = self._graphs[owner] = {}
+            # when the model is collected its captured solves go with it: give their launch-table slots and plan pins back
+            weakref.finalize(owner, _release_solves, per_model)
         # the evaluation precision of the denoiser(s) is part of the key: set_eval_dtype() between two solves must not
         # replay a graph captured with the other path's kernels
         dtypes = ()

@@ -1,7 +1,7 @@
 """Per-WAVE timeline of the fused attention kernels (diagnostic build -DEDM_AF_TIMELINE, library given by EDM_LIB_PATH);
 s_memrealtime ticks (10 ns).
     python tools/build_diag_lib.py ab/lib_af_timeline.so -DEDM_AF_TIMELINE
-    EDM_LIB_PATH=$PWD/ab/lib_af_timeline.so python tools/af_timeline.py [B] [HW] [hp]"""
+    EDM_LIB_PATH=$PWD/ab/lib_af_timeline.so python tools/af_timeline.py [B] [HW] [hp]    (hp: heads per workgroup of the FORWARD kernel only)"""
 import ctypes
 import os
 import sys
