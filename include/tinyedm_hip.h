@@ -214,6 +214,14 @@ int edm_pixelnorm_silu_fwd(const void* x, void* xn, void* a, float* dsave, long 
  * decoder block) */
 int edm_pixelnorm_silu_bwd(const void* xn, const float* dsave, const void* gxn, float gxn_scale, const void* ga,
                            const void* gadd, void* gx, long P, int C, edm_stream_t stream);
+/* round 6: the same pair with the 2x2 average pool of an EncD block folded in (networks.py:246-252, blocks without a 1x1
+ * conv): x / gx / gadd are (B, 2 Hp, 2 Wp, C) -- the tensor BEFORE the pool --, xn / a / dsave / gxn / ga (B, Hp, Wp, C); the
+ * pooled tensor is never written.  Bit-identical to edm_pool2(0.25) + edm_pixelnorm_silu_fwd and to edm_pixelnorm_silu_bwd +
+ * edm_up2(0.25, add = gadd).  C <= 1024. */
+int edm_pool_pixelnorm_silu_fwd(const void* x, void* xn, void* a, float* dsave, int B, int Hp, int Wp, int C,
+                                edm_stream_t stream);
+int edm_pool_pixelnorm_silu_bwd(const void* xn, const float* dsave, const void* gxn, float gxn_scale, const void* ga,
+                                const void* gadd, void* gx, int B, int Hp, int Wp, int C, edm_stream_t stream);
 /* mp_silu (networks.py:316) and its backward: gx = mp_silu'(x)*ga + extra_scale*gextra */
 int edm_silu_fwd(const void* x, void* a, long n, edm_stream_t stream);
 int edm_silu_bwd(const void* x, const void* ga, const void* gextra, float extra_scale, void* gx, long n,
@@ -233,6 +241,8 @@ int edm_dropout_mask(unsigned char* mask, long n, float pdrop, unsigned long lon
 int edm_pool2(const void* x, void* y, int B, int Hout, int Wout, int C, float scale, edm_stream_t stream);
 /* up2: y = scale * up(x) + add (add optional, same shape as y: see edm_pixelnorm_silu_bwd's gadd) */
 int edm_up2(const void* x, const void* add, void* y, int B, int Hout, int Wout, int C, float scale, edm_stream_t stream);
+/* DecU blocks (networks.py:312-316): y = nearest-exact x2 of x and a = mp_silu(y) in one pass (== edm_up2 + edm_silu_fwd) */
+int edm_up2_silu(const void* x, void* y, void* a, int B, int Hout, int Wout, int C, edm_stream_t stream);
 /* out[b,c] = scale * sum_hw x[b,hw,c] (* y[b,hw,c])  -- ScaleLong mean (networks.py:116) and its gate gradient;
  * written, not accumulated, in a fixed summation order (bit-reproducible) */
 int edm_reduce_hw(const void* x, long x_stride, const void* y, long y_stride, float* out, int B, int HW, int C,
@@ -338,6 +348,17 @@ int edm_split_pack(const float* w_hat, void* pack, int O, int I, int taps, int I
 int edm_split_conv(const void* Xp, const void* Wp3, float* Y, void* Ypairs, const float* R, float alpha, float beta,
                    const float* lin, long lin_stride, const float* gain, int B, int H, int W, int C, int Cout, int taps,
                    edm_stream_t stream);
+/* the same with an output descriptor for the pairs (round 6; how the split evaluation's torch.cat((input, skip * gate)),
+ * networks.py:311, stops being a copy): Ypairs rows have ld_pairs elements (0 = 2 Cout) and the lo halves sit lo_off elements
+ * behind the hi halves (0 = Cout) -- i.e. Ypairs may be the left column blocks of the NEXT decoder block's concatenated
+ * operand [hi(Ci + Cs) | lo(Ci + Cs)]; Ysilu_pairs (optional) receives mp_silu of the result as pairs at the same offsets of
+ * a second buffer (that block's first 3x3 conv reads it, networks.py:316).  Any of Y / Ypairs / Ysilu_pairs may be NULL
+ * (not all three).  edm_f32_skip_half fills the right column blocks (the gated skip and mp_silu of it). */
+int edm_split_conv_o(const void* Xp, const void* Wp3, float* Y, void* Ypairs, long ld_pairs, long lo_off, void* Ysilu_pairs,
+                     const float* R, float alpha, float beta, const float* lin, long lin_stride, const float* gain, int B,
+                     int H, int W, int C, int Cout, int taps, edm_stream_t stream);
+int edm_f32_skip_half(const float* skip, const float* gate, void* cat_pairs, void* silu_pairs, int B, int HW, int Ci, int Cs,
+                      edm_stream_t stream);
 /* cosine attention (networks.py:194-202) on the qkv conv's own output order: channel head*3d + 3*dd + {q,k,v};
  * y [B*N][C] with channel head*d + dd.  head_dim in {32, 64, 128, 144, 192}; any number of tokens (key tiles of 64). */
 int edm_f32_attention(const float* qkv, float* y, int B, int N, int C, int heads, edm_stream_t stream);
@@ -352,6 +373,12 @@ int edm_f32_pixelnorm_silu(const float* x, float* xn, float* s, long P, int C, i
 int edm_f32_silu(const float* x, float* s, long n, int pairs_row, edm_stream_t stream);
 int edm_f32_pool2(const float* x, float* y, int B, int Hout, int Wout, int C, edm_stream_t stream);
 int edm_f32_up2(const float* x, float* y, int B, int Hout, int Wout, int C, edm_stream_t stream);
+/* round 6, one pass each: EncD blocks without a 1x1 conv (networks.py:246-252): 2x2 average pool -> pixel norm -> mp_silu,
+ * the pooled tensor never written (bit-identical to edm_f32_pool2 + edm_f32_pixelnorm_silu; C <= 1024); DecU blocks
+ * (networks.py:312-316): y = nearest-exact x2 of x and s = mp_silu(y) (floats, or pairs when s_pairs != 0) */
+int edm_f32_pool_pixelnorm_silu(const float* x, float* xn, float* s, int B, int Hout, int Wout, int C, int s_pairs,
+                                edm_stream_t stream);
+int edm_f32_up2_silu(const float* x, float* y, float* s, int B, int Hout, int Wout, int C, int s_pairs, edm_stream_t stream);
 /* ScaleLong gate of a skip tensor (networks.py:112-118): mean over H*W in a fixed order + the gate MLP, per sample */
 int edm_f32_skip_gate(const float* skip, const float* W1h, const float* W2h, float* gate, int B, int HW, int C, int R,
                       edm_stream_t stream);

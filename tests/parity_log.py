@@ -1,5 +1,5 @@
 """Collects the parity error every GPU test measured (test -> worst rel-L2, its limit) so the margins are visible:
-written at session end to gpurun_out/parity_r05.json (copied into profiles/ for the record).  EDM_PARITY_LOG=0 (child
+written at session end to gpurun_out/parity_r06.json (copied into profiles/ for the record).  EDM_PARITY_LOG=0 (child
 pytest processes that re-run a subset under another kernel selection) keeps a session from writing."""
 import json
 import os
@@ -22,7 +22,7 @@ def dump() -> None:
     out_dir = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out_dir, exist_ok=True)
-        path = os.path.join(out_dir, "parity_r05.json")
+        path = os.path.join(out_dir, "parity_r06.json")
         old = {}
         if os.path.exists(path):
             with open(path) as f:

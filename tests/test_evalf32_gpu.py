@@ -232,7 +232,11 @@ def test_heun_32_step_trajectory_f32_vs_fp32_oracle():
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k", [
     (2, 8, 8, 64, 64, 3), (3, 16, 16, 128, 192, 3), (5, 7, 7, 64, 72, 3), (2, 14, 14, 32, 64, 3),     # k_conv_igemm
     (4, 16, 16, 256, 768, 1), (3, 5, 7, 96, 72, 1), (16, 8, 8, 512, 256, 1),
-    (128, 32, 32, 256, 256, 3), (64, 32, 32, 512, 256, 3), (128, 16, 16, 256, 256, 3), (32, 64, 64, 64, 128, 3)])  # k_conv3x3_v6
+    (128, 32, 32, 256, 256, 3), (64, 32, 32, 512, 256, 3), (128, 16, 16, 256, 256, 3), (32, 64, 64, 64, 128, 3),   # k_conv3x3_v6
+    # round 6: the 8x8-class 3x3 layers on k_conv3x3_s (K rounds wrap from the hi to the lo half of X; ragged last tile,
+    # Cout not a multiple of the 64-channel tile) and the 1x1 layers on k_conv_igemm2 (>= 512 tiles of 256 x 128)
+    (256, 8, 8, 256, 256, 3), (67, 8, 8, 256, 200, 3), (96, 16, 16, 256, 64, 3),
+    (256, 16, 16, 256, 768, 1), (130, 32, 32, 512, 256, 1), (261, 16, 16, 256, 264, 1)])
 @pytest.mark.parametrize("res", [False, True])
 def test_split_conv_vs_fp64(ops, B, H, W, Cin, Cout, k, res):
     """ops.split_conv (hi/lo bf16 pairs, three MFMA passes, fp32 out) against an fp64 convolution of the fp32 operands:
@@ -251,6 +255,10 @@ def test_split_conv_vs_fp64(ops, B, H, W, Cin, Cout, k, res):
     e = rel(nchw(y)[sel], ref)
     record(f"evalf32/split_conv[{B}x{H}x{W} {Cin}->{Cout} k{k}{' +R' if res else ''}]", e, 1e-5)
     assert e <= 1e-5, e
+    if B >= 64:     # the pairs output of the same launch form reassembles to the float output, bit for bit in hi + lo
+        yp = ops.split_conv(ops.f32_to_pairs(nhwc(x)), pk, k * k, residual=None if r is None else nhwc(r), alpha=0.8,
+                            beta=0.6 if res else 0.0, pairs_out=True)
+        assert torch.equal(yp, ops.f32_to_pairs(y))
 
 
 def test_split_conv_modulation_epilogue(ops):
@@ -318,6 +326,21 @@ def test_cifar10_forward_and_trajectory_f32x3():
     e = rel(D.cpu() - base, D_or - base)
     record("evalf32/f32x3_uncond_forward_vs_fp32_oracle", e, 1e-4)
     assert e <= 1e-4, e
+    # round 6: each block's last conv writes what its consumer reads (concat halves, mp_silu pairs, qkv pairs) and the
+    # pool + pixel-norm / upsample + mp_silu pairs are one kernel each: the SAME values as the round-5 kernel sequence
+    from tinyedm_amd import networks as N
+    assert N.F32_FUSE_OUT
+    N.F32_FUSE_OUT = False
+    try:
+        with torch.no_grad():
+            D_seq = model(noisy.to(DEV), sigma.to(DEV), None)
+    finally:
+        N.F32_FUSE_OUT = True
+    # (not bit for bit: hipcc contracts / schedules the fp32 mp_silu differently inside a conv epilogue and inside the
+    # elementwise kernel -- one-ulp differences of single activations, 1e-6 after 21 blocks)
+    e_seq = rel(D.cpu(), D_seq.cpu())
+    record("evalf32/f32x3_fused_outputs_vs_round5_sequence", e_seq, 5e-6)
+    assert e_seq <= 5e-6, e_seq
     x0 = torch.randn(2, 3, 32, 32, generator=g).to(DEV)
     solver = T.DeterministicSolver(num_steps=32)
     with torch.no_grad():
@@ -331,3 +354,57 @@ def test_cifar10_forward_and_trajectory_f32x3():
     if _runtime_env.GRAPH_REPLAY_SAFE:
         with torch.no_grad():
             assert torch.equal(solver.solve(model, x0, None, graph=True).cpu(), xs)
+
+
+def test_f32_fused_elementwise_and_output_descriptor(ops):
+    """Round 6, the eval-shaped forward of the split path, kernel by kernel -- every fused form against the sequence it
+    replaces, bit for bit: pool + pixel-norm + mp_silu, upsample + mp_silu, the skip half of the concatenated operands,
+    and ops.split_conv's output forms (fp32 + pairs, fp32 + mp_silu pairs, the input halves of the next block's cat / sil)"""
+    g = torch.Generator().manual_seed(17)
+    B, H, W, C = 3, 8, 8, 64
+    x = torch.randn(B, H, W, C, generator=g).to(DEV)
+    for pairs in (False, True):
+        xn, s = ops.f32_pool_pixelnorm_silu(x, pairs=pairs)
+        xn0, s0 = ops.f32_pixelnorm_silu(ops.f32_pool2(x), pairs=pairs)
+        assert torch.equal(xn, xn0) and torch.equal(s, s0)
+        y, s = ops.f32_up2_silu(x, pairs=pairs)
+        y0 = ops.f32_up2(x)
+        assert torch.equal(y, y0) and torch.equal(s, ops.f32_silu(y0, pairs=pairs))
+    # wide rows (several 256-channel passes per lane) and a ragged pixel count
+    x2 = torch.randn(2, 6, 10, 768, generator=g).to(DEV)
+    xn, s = ops.f32_pool_pixelnorm_silu(x2, pairs=True)
+    xn0, s0 = ops.f32_pixelnorm_silu(ops.f32_pool2(x2), pairs=True)
+    assert torch.equal(xn, xn0) and torch.equal(s, s0)
+    # conv output forms
+    Cin, Cout, Cs = 64, 96, 40
+    xin = torch.randn(B, H, W, Cin, generator=g).to(DEV)
+    res = torch.randn(B, H, W, Cout, generator=g).to(DEV)
+    skip = torch.randn(B, H, W, Cs, generator=g).to(DEV)
+    gate = torch.rand(B, Cs, generator=g).to(DEV)
+    for taps in (9, 1):
+        pk = ops.split_pack((torch.randn(Cout, Cin * taps, generator=g) / (Cin * taps) ** 0.5).to(DEV), taps)
+        xp = ops.f32_to_pairs(xin)
+        y = ops.split_conv(xp, pk, taps, residual=res, alpha=0.8, beta=0.6)
+        y1, yp = ops.split_conv(xp, pk, taps, residual=res, alpha=0.8, beta=0.6, also_pairs=True)
+        assert torch.equal(y1, y) and torch.equal(yp, ops.f32_to_pairs(y))
+        y2, ys = ops.split_conv(xp, pk, taps, residual=res, alpha=0.8, beta=0.6, silu_pairs=True)
+        ys0 = ops.f32_silu(y, pairs=True)
+
+        def val(p):     # pairs -> the fp32 value they stand for
+            return p[..., :p.shape[-1] // 2].float() + p[..., p.shape[-1] // 2:].float()
+        # (mp_silu inside the conv epilogue and inside k_silu_f32 are the same expression compiled in two places: equal to an
+        # ulp of the fp32 value -- which can move the lo half of a pair by one of ITS ulps, 2^-16 of the value -- not bit for bit)
+        assert torch.equal(y2, y) and (val(ys) - val(ys0)).abs().max().item() <= 2.0 ** -15 * val(ys0).abs().max().item()
+        Ct = Cout + Cs
+        cat = torch.full((B, H, W, 2 * Ct), float("nan"), device=DEV, dtype=torch.bfloat16)
+        sil = torch.full_like(cat, float("nan"))
+        out = ops.split_conv(xp, pk, taps, residual=res, alpha=0.8, beta=0.6, dest=(cat, sil))
+        assert out is cat
+        ops.f32_skip_half(skip, gate, cat, sil)
+        cat0, sil0 = ops.f32_concat_gate(y, skip, gate, True, pairs=True)
+        # (the input halves of cat are the conv result's pairs, bit for bit; the gated skip is a product whose lo half hipcc may
+        # form with or without rounding the product first (-ffp-contract=fast): equal to the pairs' own resolution)
+        assert torch.equal(cat[..., :Cout], cat0[..., :Cout]) and torch.equal(cat[..., Ct:Ct + Cout], cat0[..., Ct:Ct + Cout])
+        assert (val(cat) - val(cat0)).abs().max().item() <= 2.0 ** -15 * val(cat0).abs().max().item()
+        assert (val(sil) - val(sil0)).abs().max().item() <= 2.0 ** -15 * val(sil0).abs().max().item()
+        assert not torch.isnan(cat.float()).any() and not torch.isnan(sil.float()).any()

@@ -364,3 +364,41 @@ def test_standalone_module_call_after_a_fragment_major_forward():
         assert rel(y.cpu().float(), ref) < 1e-2
         D2 = model(x, sigma, None)
     assert torch.equal(D1, D2)
+
+
+def test_resample_fusions_leave_the_cifar10_step_unchanged():
+    """FUSE_RESAMPLE (round 6; the CIFAR-10 net has two EncD blocks without a 1x1 conv and two DecU blocks): the evaluation
+    forward bit for bit, the training loss and every parameter gradient up to the order of the fp32 atomics both
+    paths share -- against the round-5 sequence with the standalone pool / upsample / mp_silu kernels."""
+    import tinyedm_amd as T
+    from tinyedm_amd import networks as N
+    from tinyedm_amd.ema import FusedAdam
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    g = torch.Generator().manual_seed(12)
+    x = (0.5 * torch.randn(8, 3, 32, 32, generator=g)).to(DEV)
+    sigma = torch.randn(8, generator=g).exp().to(DEV)
+    res = {}
+    old = N.FUSE_RESAMPLE
+    try:
+        for mode in (False, True):
+            N.FUSE_RESAMPLE = mode
+            N._rng_sub_counter[0] = 0           # the same dropout sub-streams for both models
+            model, den = _cifar_model(T, seed=4)
+            opt = FusedAdam(model.parameters(), lr=1e-3)
+            opt.zero_grad()
+            model.eval()
+            with torch.no_grad():
+                D = model(x, sigma, None).clone()
+            model.train()
+            T.manual_seed(5)
+            loss = model.training_step((x, None), 0)
+            loss.backward()
+            torch.cuda.synchronize()
+            res[mode] = (D, float(loss), opt.arena.grad.clone())
+    finally:
+        N.FUSE_RESAMPLE = old
+    assert torch.equal(res[True][0], res[False][0])
+    assert abs(res[True][1] - res[False][1]) <= 1e-6 * abs(res[False][1])      # (the loss is a sum of fp32 atomics)
+    e = rel(res[True][2], res[False][2])
+    assert e <= 1e-5, e

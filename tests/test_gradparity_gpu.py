@@ -8,7 +8,7 @@ tests/test_oracle_golden.py) on the SAME inputs, the SAME noise draws and the ke
 (ops.dropout_mask regenerates each block's mask from (seed, block stream, step), injected through the oracle's
 `dropout_masks=`), twice: with the bf16 rounding points of the HIP path (limit 3e-2 relative L2 per tensor) and in plain
 fp32 (what the reference's fp32 autograd would give; recorded, limit 6e-2).  Reference: networks.py:32-37, 246-329,
-edm.py:205-236.  Every per-tensor figure goes to gpurun_out/grad_parity_r05.json (copied to profiles/)."""
+edm.py:205-236.  Every per-tensor figure goes to gpurun_out/grad_parity_r06.json (copied to profiles/)."""
 import json
 import os
 
@@ -137,7 +137,7 @@ def _grad_parity(tag, ecfg, dcfg, shape, P_mean, P_std, seed_params, seed_data, 
 
 
 def _dump(tag, entry):
-    path = os.path.join(ROOT, "gpurun_out", "grad_parity_r05.json")
+    path = os.path.join(ROOT, "gpurun_out", "grad_parity_r06.json")
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         old = {}

@@ -739,3 +739,26 @@ def test_conv_wgrad_wide_images(ops, B, H, W, Cin, Cout):
     slabs = ops.conv_wgrad(nhwc(x), nhwc(gy), 9)
     got = slabs.double().sum(0).cpu()
     assert rel(got, ref) <= 1e-5, f"wide wgrad rel {rel(got, ref):.3e}"
+
+
+@pytest.mark.parametrize("B,H,W,C", [(3, 8, 8, 64), (2, 6, 10, 256), (5, 4, 4, 768), (1, 16, 16, 40)])
+def test_resample_fused_into_neighbours_is_bit_identical(ops, B, H, W, C):
+    """Round 6: the 2x2 average pool of an EncD block inside the pixel-norm kernels (forward AND backward) and a DecU block's
+    upsample that also emits mp_silu of its result -- against the separate kernels they replace, bit for bit."""
+    g = torch.Generator().manual_seed(B + H + C)
+    x = torch.randn(B, 2 * H, 2 * W, C, generator=g).to(torch.bfloat16).to(DEV)
+    xn, a, d = ops.pool_pixelnorm_silu_fwd(x)
+    xn0, a0, d0 = ops.pixelnorm_silu_fwd(ops.pool2(x, 0.25))
+    assert torch.equal(xn, xn0) and torch.equal(a, a0) and torch.equal(d, d0)
+    gxn = torch.randn(B, H, W, C, generator=g).to(torch.bfloat16).to(DEV)
+    ga = torch.randn(B, H, W, C, generator=g).to(torch.bfloat16).to(DEV)
+    gadd = torch.randn(B, 2 * H, 2 * W, C, generator=g).to(torch.bfloat16).to(DEV)
+    for add in (None, gadd):
+        for gx_in in (gxn, None):
+            gx = ops.pool_pixelnorm_silu_bwd(xn, d, gx_in, 0.7, ga, gadd=add)
+            gx0 = ops.up2(ops.pixelnorm_silu_bwd(xn0, d0, gx_in, 0.7, ga), 0.25, add=add)
+            assert torch.equal(gx, gx0)
+    xs = torch.randn(B, H, W, C, generator=g).to(torch.bfloat16).to(DEV)
+    y, s = ops.up2_silu(xs)
+    y0 = ops.up2(xs)
+    assert torch.equal(y, y0) and torch.equal(s, ops.silu_fwd(y0))

@@ -22,6 +22,9 @@ SIGNATURES = {
     # elementwise.hip
     "edm_pixelnorm_silu_fwd": [P, P, P, P, L, I, P],
     "edm_pixelnorm_silu_bwd": [P, P, P, F, P, P, P, L, I, P],
+    "edm_pool_pixelnorm_silu_fwd": [P, P, P, P, I, I, I, I, P],
+    "edm_pool_pixelnorm_silu_bwd": [P, P, P, F, P, P, P, I, I, I, I, P],
+    "edm_up2_silu": [P, P, P, I, I, I, I, P],
     "edm_silu_fwd": [P, P, L, P],
     "edm_silu_bwd": [P, P, P, F, P, L, P],
     "edm_axpby": [P, F, P, F, P, L, P],
@@ -102,6 +105,10 @@ SIGNATURES = {
     "edm_f32_to_pairs": [P, P, L, I, P],
     "edm_split_pack": [P, P, I, I, I, I, P],
     "edm_split_conv": [P, P, P, P, P, F, F, P, L, P, I, I, I, I, I, I, P],
+    "edm_split_conv_o": [P, P, P, P, L, L, P, P, F, F, P, L, P, I, I, I, I, I, I, P],
+    "edm_f32_skip_half": [P, P, P, P, I, I, I, I, P],
+    "edm_f32_pool_pixelnorm_silu": [P, P, P, I, I, I, I, I, P],
+    "edm_f32_up2_silu": [P, P, P, I, I, I, I, I, P],
     "edm_f32_pixelnorm_silu": [P, P, P, L, I, I, P],
     "edm_f32_silu": [P, P, L, I, P],
     "edm_f32_pool2": [P, P, I, I, I, I, P],

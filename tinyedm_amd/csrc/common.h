@@ -537,15 +537,33 @@ __device__ __forceinline__ void f32_out4(float* __restrict__ Y, const float* __r
     for (int k = 0; k < 4; ++k) v[k] = mp_silu_f(v[k] * (l[k] * gain + 1.0f));
   }
   if (Y) *reinterpret_cast<f32x4*>(Y + e) = v;
-  if (mod.Y2) {   // the same values as a (hi, lo) bf16 pair, rows [hi(Cout) | lo(Cout)]: the next conv's operand format
+  if (mod.Y2 || mod.Yb) {
+    // the same values as (hi, lo) bf16 pairs: the next conv's operand format.  Rows of ldY elements (0 = 2 Cout), the lo
+    // halves ldYb elements behind the hi halves (0 = Cout): plain [hi(Cout) | lo(Cout)] rows, or -- round 6, the decoder's
+    // torch.cat((input, skip * gate)) of the split evaluation without a copy -- the left column blocks of the next block's
+    // concatenated operand [hi(Ci + Cs) | lo(Ci + Cs)].  mod.Yb: mp_silu of the result as pairs, same addressing (the
+    // operand of the consumer's first 3x3 conv, networks.py:316)
+    const long ld = mod.ldY ? mod.ldY : 2L * Cout, lo_off = mod.ldYb ? mod.ldYb : (long)Cout;
     bf16x4 hi, lo;
+    if (mod.Y2) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      hi[k] = (bf16)v[k];
-      lo[k] = (bf16)(v[k] - (float)hi[k]);
+      for (int k = 0; k < 4; ++k) {
+        hi[k] = (bf16)v[k];
+        lo[k] = (bf16)(v[k] - (float)hi[k]);
+      }
+      *reinterpret_cast<bf16x4*>(mod.Y2 + px * ld + co) = hi;
+      *reinterpret_cast<bf16x4*>(mod.Y2 + px * ld + lo_off + co) = lo;
     }
-    *reinterpret_cast<bf16x4*>(mod.Y2 + px * 2 * Cout + co) = hi;
-    *reinterpret_cast<bf16x4*>(mod.Y2 + px * 2 * Cout + Cout + co) = lo;
+    if (mod.Yb) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float sv = mp_silu_f(v[k]);
+        hi[k] = (bf16)sv;
+        lo[k] = (bf16)(sv - (float)hi[k]);
+      }
+      *reinterpret_cast<bf16x4*>(mod.Yb + px * ld + co) = hi;
+      *reinterpret_cast<bf16x4*>(mod.Yb + px * ld + lo_off + co) = lo;
+    }
   }
 }
 // v_mfma_f32_32x32x16 accumulators (k_conv_igemm): rows = channels 32 i + 8 g + 4 lhi + r, columns = pixels 32 j + l31

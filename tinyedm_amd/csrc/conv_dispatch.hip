@@ -3,6 +3,7 @@
 // decoder's torch.cat((input, skip * gate)) (networks.py:311) copy-free.  The kernels themselves live in conv_igemm*.hip;
 // every one ends in common.h's store_tile_core, which is where the descriptor (ModEpilogue) is interpreted.
 #include "common.h"
+#include <stdlib.h>
 
 int edm_conv_igemm_v1_ex(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
                          int W, int Cin, int Cout, int taps, const ModEpilogue& mod, hipStream_t st);
@@ -67,16 +68,40 @@ extern "C" int edm_conv_igemm_o(const void* X, const void* Wp, void* Y, long ldY
 // Y = alpha * conv + beta * R, or Y = mp_silu(conv * (lin[b,:] * gain + 1)) when lin is given -- Y, R FLOATS; Ypairs
 // (optional, Y may then be NULL): the same result as [pixels][2 Cout] bf16 pairs, ready to be the next conv's Xp.
 // C % 32 == 0 (3x3 on the static-schedule kernel: C % 64 == 0, W <= 64; anything else on k_conv_igemm).
+// edm_split_conv_o: the same with an OUTPUT DESCRIPTOR for the pairs (round 6): rows of ld_pairs elements (0 = 2 Cout) with
+// the lo halves lo_off elements behind the hi halves (0 = Cout) -- the left column blocks of the next decoder block's
+// concatenated operand [hi(Ci + Cs) | lo(Ci + Cs)] -- and Ysilu_pairs (optional): mp_silu of the result as pairs at the same
+// offsets of a second buffer (that block's first 3x3 conv reads it).  Any of Y / Ypairs / Ysilu_pairs may be NULL, not all.
+static int split_conv_impl(const void* Xp, const void* Wp3, float* Y, void* Ypairs, long ld_pairs, long lo_off,
+                           void* Ysilu_pairs, const float* R, float alpha, float beta, const float* lin, long lin_stride,
+                           const float* gain, int B, int H, int W, int C, int Cout, int taps, hipStream_t st);
 extern "C" int edm_split_conv(const void* Xp, const void* Wp3, float* Y, void* Ypairs, const float* R, float alpha, float beta,
                               const float* lin, long lin_stride, const float* gain, int B, int H, int W, int C, int Cout,
                               int taps, hipStream_t st) {
-  EDM_REQUIRE(Xp && Wp3 && (Y || Ypairs), "split_conv: null pointer");
+  return split_conv_impl(Xp, Wp3, Y, Ypairs, 0, 0, nullptr, R, alpha, beta, lin, lin_stride, gain, B, H, W, C, Cout, taps, st);
+}
+extern "C" int edm_split_conv_o(const void* Xp, const void* Wp3, float* Y, void* Ypairs, long ld_pairs, long lo_off,
+                                void* Ysilu_pairs, const float* R, float alpha, float beta, const float* lin,
+                                long lin_stride, const float* gain, int B, int H, int W, int C, int Cout, int taps,
+                                hipStream_t st) {
+  EDM_REQUIRE((ld_pairs == 0 && lo_off == 0) || (lo_off >= Cout && ld_pairs >= lo_off + Cout && ld_pairs % 4 == 0 && lo_off % 4 == 0),
+              "split_conv_o: pairs rows need lo_off >= Cout, ld_pairs >= lo_off + Cout, both multiples of 4");
+  return split_conv_impl(Xp, Wp3, Y, Ypairs, ld_pairs, lo_off, Ysilu_pairs, R, alpha, beta, lin, lin_stride, gain, B, H, W, C,
+                         Cout, taps, st);
+}
+static int split_conv_impl(const void* Xp, const void* Wp3, float* Y, void* Ypairs, long ld_pairs, long lo_off,
+                           void* Ysilu_pairs, const float* R, float alpha, float beta, const float* lin, long lin_stride,
+                           const float* gain, int B, int H, int W, int C, int Cout, int taps, hipStream_t st) {
+  EDM_REQUIRE(Xp && Wp3 && (Y || Ypairs || Ysilu_pairs), "split_conv: null pointer");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 32 == 0 && Cout > 0 && Cout % 8 == 0 && (taps == 1 || taps == 9),
               "split_conv: bad args (C %% 32, Cout %% 8, taps 1 or 9)");
   EDM_REQUIRE(!lin || (gain && lin_stride >= Cout), "split_conv: the modulation epilogue needs gain and lin_stride >= Cout");
   ModEpilogue mod{};
   mod.mode = 4;
   mod.Y2 = (bf16*)Ypairs;
+  mod.Yb = (bf16*)Ysilu_pairs;
+  mod.ldY = ld_pairs;
+  mod.ldYb = lo_off;
   mod.lin = lin;
   mod.gain = gain;
   mod.lin_stride = lin_stride;
@@ -84,10 +109,20 @@ extern "C" int edm_split_conv(const void* Xp, const void* Wp3, float* Y, void* Y
   mod.ldX = 2 * C;
   mod.kwrap = C / 32;
   const int K = 3 * C;
-  if (taps == 9 && C % 64 == 0 && W <= 64 && edm_conv_tall_worthwhile((long)B * H * W, Cout)) {
+  const long npix = (long)B * H * W;
+  if (taps == 9 && C % 64 == 0 && W <= 64 && edm_conv_tall_worthwhile(npix, Cout)) {
     const int rc = edm_conv_igemm_v6_ex(Xp, Wp3, Y, R, alpha, beta, B, H, W, K, Cout, 9, mod, st);
     if (rc != EDM_ERR_UNSUPPORTED) return rc;
   }
+  // round 6: the small-map kernel for the 8x8-class 3x3 layers and the LDS-DMA 256x128 kernel for the 1x1 layers (both were
+  // on the register-staged 128x128 kernel: 9.4 % and 11.1 % of a split-bf16 solve).  EDM_SPLIT_FAST=0: the old dispatch (A/B)
+  static const bool fast = !(getenv("EDM_SPLIT_FAST") && getenv("EDM_SPLIT_FAST")[0] == '0');
+  if (fast && taps == 9 && edm_conv_s_worthwhile(npix, W, K, Cout)) {
+    const int rc = edm_conv_igemm_s_ex(Xp, Wp3, Y, R, alpha, beta, B, H, W, K, Cout, 9, mod, st);
+    if (rc != EDM_ERR_UNSUPPORTED) return rc;
+  }
+  if (fast && taps == 1 && ((npix + 255) / 256) * ((Cout + 127) / 128) >= 512)
+    return edm_conv_igemm_v2_ex(Xp, Wp3, Y, R, alpha, beta, B, H, W, K, Cout, 1, mod, st);
   return edm_conv_igemm_v1_ex(Xp, Wp3, Y, R, alpha, beta, B, H, W, K, Cout, taps, mod, st);
 }
 

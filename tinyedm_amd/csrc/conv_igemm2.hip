@@ -44,8 +44,10 @@ __device__ __forceinline__ unsigned long long stamp() {
   return t;
 }
 
-template <int TAPS, int NX, bool STAMP = false, int ABL = 0>
-__global__ __launch_bounds__(512, 4) void k_conv_igemm2(const bf16* __restrict__ X, const bf16* __restrict__ Wp,
+// EPI 4 (round 6, 1x1 only): the split-bf16 evaluation's operands and fp32 epilogue (common.h, mode 4) -- X rows are [hi | lo]
+// pairs of ldX elements, K chunk c reads X chunk (c < kwrap ? c : c - kwrap), the result leaves as floats / pairs.
+template <int TAPS, int NX, bool STAMP = false, int ABL = 0, int EPI = 0>
+__global__ __launch_bounds__(512, EPI == 4 ? 2 : 4) void k_conv_igemm2(const bf16* __restrict__ X, const bf16* __restrict__ Wp,
                                                           bf16* __restrict__ Y, const bf16* __restrict__ R,
                                                           const bf16* __restrict__ zeros, float alpha, float beta,
                                                           int Npix, int H, int W, int Cin, int Cout, int tiles_m,
@@ -71,9 +73,12 @@ __global__ __launch_bounds__(512, 4) void k_conv_igemm2(const bf16* __restrict__
   const int wm = wave & 1, wn = wave >> 1;  // 2 channel halves x 4 pixel quarters
   const int l31 = lane & 31, lhi = lane >> 5;
   const int drow = lane >> 2, dp = lane & 3;  // DMA lane -> (row in 16-row slot, physical 16-B chunk)
+  const long ldX = (EPI == 4 && mod.ldX) ? mod.ldX : Cin;
+  const int kwrap = (EPI == 4 && mod.kwrap) ? mod.kwrap : (1 << 30);
 
   // ---- DMA issue helpers (one wave-instruction = 16 rows x 64 B = 1 KiB, lane-linear in LDS)
   auto issue_x = [&](int chunk, int buf) {
+    const int xc = chunk >= kwrap ? chunk - kwrap : chunk;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int slot = wave + 8 * i;
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(512, 4) void k_conv_igemm2(const bf16* __restrict__
       const long pix = (long)m0 - HALO + row;
       const int c = dp ^ ((row >> 2) & 3);
       const bool ok = row < xrows && pix >= 0 && pix < Npix;
-      const bf16* src = ok ? X + pix * Cin + chunk * KC + c * 8 : zeros;
+      const bf16* src = ok ? X + pix * ldX + xc * KC + c * 8 : zeros;
       dma16(src, Xb + buf * XBYTES + slot * 1024);
     }
   };
@@ -228,18 +233,22 @@ __global__ __launch_bounds__(512, 4) void k_conv_igemm2(const bf16* __restrict__
 
   // ---- epilogue: transposed through wave-private LDS (common.h: store_tile_transposed)
   __syncthreads();  // every wave is done with the staged tiles
+  if constexpr (EPI == 4)
+    store_tile_f32<2, 2>(acc, reinterpret_cast<float*>(Y), reinterpret_cast<const float*>(R), alpha, beta,
+                         (long)m0 + wn * 64, Npix, n0 + wm * 64, Cout, mod);
+  else
   store_tile_transposed<2, 2>(acc, smem + (wm * 4 + wn) * (32 * (2 * 64 + 16)), Y, R, alpha, beta, (long)m0 + wn * 64, Npix,
                               n0 + wm * 64, Cout, mod);
 }
 
-template <int TAPS, int NX>
+template <int TAPS, int NX, int EPI = 0>
 void launch2(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int Npix, int H, int W,
              int Cin, int Cout, hipStream_t st, const ModEpilogue& mod) {
   constexpr int XBUFS = (TAPS == 9) ? 2 : 3;
   const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + BN - 1) / BN;
   const size_t lds = (size_t)XBUFS * NX * 8 * 16 * ROWB + WRING * WTILE;
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
-  auto kern = k_conv_igemm2<TAPS, NX>;
+  auto kern = k_conv_igemm2<TAPS, NX, false, 0, EPI>;
   EDM_MAX_LDS(kern, 160 * 1024);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const bf16*)X, (const bf16*)Wp, (bf16*)Y, (const bf16*)R,
                      (const bf16*)edm_zero_page(), alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n,
@@ -299,9 +308,10 @@ extern "C" int edm_conv_igemm_v2_ablate(const void* X, const void* Wp, void* Y, 
 // dispatcher can fall back to generation 1.
 int edm_conv_igemm_v2_ex(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
                          int W, int Cin, int Cout, int taps, const ModEpilogue& mod, hipStream_t st) {
-  EDM_REQUIRE(X && Wp && Y, "conv_igemm_v2: null pointer");
+  EDM_REQUIRE(X && Wp && (Y || (mod.mode == 4 && mod.Y2)), "conv_igemm_v2: null pointer");
   EDM_REQUIRE(!mod.wfrag, "conv_igemm_v2: fragment-major weight packs are read by k_conv3x3_s only");
-  EDM_REQUIRE(mod.mode == 0 || mod.mode == 3, "conv_igemm_v2: plain / strided-output epilogues only");
+  EDM_REQUIRE(mod.mode == 0 || mod.mode == 3 || (mod.mode == 4 && taps == 1),
+              "conv_igemm_v2: plain / strided-output epilogues (and the split-bf16 form of the 1x1 kernel) only");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && (long)B * H * W < (1L << 31), "conv_igemm_v2: bad B/H/W");
   EDM_REQUIRE(taps == 1 || taps == 9, "conv_igemm_v2: taps must be 1 or 9");
   EDM_REQUIRE(Cin > 0 && Cin % 32 == 0 && Cout > 0 && Cout % 8 == 0, "conv_igemm_v2: Cin %% 32, Cout %% 8 required");
@@ -310,7 +320,8 @@ int edm_conv_igemm_v2_ex(const void* X, const void* Wp, void* Y, const void* R, 
   (void)zero_page_;
   const int Npix = B * H * W;
   if (taps == 1) {
-    launch2<1, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod);
+    if (mod.mode == 4) launch2<1, 2, 4>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod);
+    else launch2<1, 2>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, st, mod);
   } else {
     const int xrows = BM + 2 * (W + 1);
     const int need = (xrows + 127) / 128;

@@ -108,10 +108,13 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_s(const bf16* __restrict__ X
   // (branch-free and in 32-bit arithmetic: this code is on the critical path of a workgroup that has the CU to itself; its
   // first form -- 64-bit clamps and multiplies inside per-lane branches -- was 1 700 instructions, 5 us, before the first
   // load was even issued; host-checked: the activation tensor is < 4 GiB)
+  // (EPI 4, the split-bf16 evaluation: X rows are [hi | lo] pairs of ldX elements and K round r reads the X channels of
+  // round (r < kw4 ? r : r - kw4), kw4 = kwrap / 4 rounds -- common.h, mode 4)
+  const int kw4 = (EPI == 4 && mod.kwrap) ? mod.kwrap >> 2 : (1 << 30);
   const char* xsrc[NXI];
   {
     const unsigned cbyte = (unsigned)(wave * KC * 2);
-    const unsigned rowb = (unsigned)Cin * 2u;
+    const unsigned rowb = (unsigned)((EPI == 4 && mod.ldX) ? mod.ldX : Cin) * 2u;
     const char* const xbase = reinterpret_cast<const char*>(X);
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_s(const bf16* __restrict__ X
       if (v == 9 && r2 == 0) { S_STAMP(5); }
 #endif
       // ---- k-step 0 (written out per pixel block: nested generic lambdas push the fragment arrays into scratch)
-      const long xoff = (long)(round + 1) * (4 * KC * 2);
+      const long xoff = (long)(round + 1 >= kw4 ? round + 1 - kw4 : round + 1) * (4 * KC * 2);
 #define SLAB_DMA(i) if constexpr (tap == 0 && next_round && (i) < NXI) dma16(xsrc[i] + xoff, Xb + (xpar ^ 1) * XBYTES + (i) * 1024);
 #define KSTEP0(j)                                                   \
       MFMA_PAIR(slot, 0, 0, j);                                     \
@@ -362,6 +365,10 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_s(const bf16* __restrict__ X
   }
   __syncthreads();                              // the epilogue stage overlays the reduction buffer
   S_STAMP(3);
+  if constexpr (EPI == 4)
+    store_tile_f32<2, 1>(out, reinterpret_cast<float*>(Y), reinterpret_cast<const float*>(R), alpha, beta,
+                         (long)m0 + wave * 32, Npix, n0, Cout, mod);
+  else
   store_tile_transposed<2, 1, EPI>(out, smem + wave * ESTAGE, Y, R, alpha, beta, (long)m0 + wave * 32, Npix, n0, Cout, mod);
 #ifdef EDM_S_TIMELINE
   __builtin_amdgcn_s_waitcnt(0);   // stores retired
@@ -397,17 +404,20 @@ int edm_conv_igemm_s_ex(const void* X, const void* Wp, void* Y, const void* R, f
   EDM_REQUIRE(Cout > 0 && Cout % 8 == 0, "conv_igemm_s: Cout %% 8 required");
   if (taps != 9 || Cin <= 0 || Cin % 256 != 0 || W > 16 || Cin * 2 + 64 > 4096) return EDM_ERR_UNSUPPORTED;
   if (mod.mode == 1 && (H * W) % 32 != 0) return EDM_ERR_UNSUPPORTED;
+  // split-bf16 form: the hi / lo halves of X must be whole rounds of 4 chunks (C % 128 == 0)
+  if (mod.mode == 4 && (mod.wfrag || mod.kwrap % 4 != 0)) return EDM_ERR_UNSUPPORTED;
   EDM_ZERO_PAGE(zero_page_, "conv_igemm_s");
   (void)zero_page_;
   const int Npix = B * H * W;
   static_assert(4 * WAVE_LDS <= 160 * 1024 && RED_BYTES <= 160 * 1024 && 4 * ESTAGE <= RED_BYTES, "LDS budget");
-  EDM_REQUIRE((long)9 * Cout * Cin * 2 < (1L << 32) && (long)B * H * W * Cin * 2 < (1L << 32),
+  EDM_REQUIRE((long)9 * Cout * Cin * 2 < (1L << 32) && (long)B * H * W * (mod.ldX ? mod.ldX : Cin) * 2 < (1L << 32),
               "conv_igemm_s: packed weights and the input tensor must be < 4 GiB each (32-bit lane offsets)");
   EDM_REQUIRE(!mod.wfrag || Cout % 64 == 0, "conv_igemm_s: a fragment-major pack needs Cout %% 64 == 0");
 #define L5(EPIV) (mod.wfrag ? launch5<EPIV, true>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st) \
                             : launch5<EPIV, false>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st))
   if (mod.mode == 1) L5(1);
   else if (mod.mode == 2) L5(2);
+  else if (mod.mode == 4) launch5<4, false>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st);
   else L5(0);
 #undef L5
   EDM_CHECK_LAUNCH("conv_igemm_s");

@@ -28,10 +28,13 @@ static inline int grid_for(long work, int block, int cap = 256 * 16) {
 // ------------------------------------------------------------------ pixel_norm + mp_silu
 // networks.py:9-14 (pixel_norm over C), :83-84 (mp_silu), used at :249-252.
 // xn = x / (eps + ||x||/sqrt(C));  a = mp_silu(xn);  dsave = eps + ||x||/sqrt(C)
-template <int LPP>
+// POOL (round 6, EncD blocks without a 1x1 conv, networks.py:246-252): x is the tensor BEFORE the 2x2 average pool ((B, 2 Hp,
+// 2 Wp, C); P = B Hp Wp pooled pixels): a pixel's row is the bf16-rounded mean of its four source rows -- k_pool2's values
+// -- and the pooled tensor is never written (one launch, one HBM round trip less per EncD block; bit-identical)
+template <int LPP, bool POOL = false>
 __global__ __launch_bounds__(256) void k_pnorm_silu_fwd(const bf16* __restrict__ x, bf16* __restrict__ xn,
                                                           bf16* __restrict__ a, float* __restrict__ dsave, int P,
-                                                          int C) {
+                                                          int C, int Hp = 0, int Wp = 0) {
   constexpr int GPW = 64 / LPP;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lig = lane % LPP, grp = lane / LPP;
@@ -47,7 +50,23 @@ __global__ __launch_bounds__(256) void k_pnorm_silu_fwd(const bf16* __restrict__
     for (int it = 0; it < 2; ++it) {
       const int c8 = lig + it * LPP;
       if (pv && c8 < CL) {
-        load8(x + p * C + c8 * 8, v[it]);
+        if constexpr (POOL) {
+          const int w = (int)(p % Wp);
+          const long t = p / Wp;
+          const int h = (int)(t % Hp);
+          const long b = t / Hp;
+          const bf16* src = x + ((b * 2 * Hp + 2 * h) * 2 * Wp + 2 * w) * C + c8 * 8;
+          const long row = (long)2 * Wp * C;
+          float a1[8], a2[8], a3[8];
+          load8(src, v[it]);
+          load8(src + C, a1);
+          load8(src + row, a2);
+          load8(src + row + C, a3);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[it][i] = (float)(bf16)(0.25f * (v[it][i] + a1[i] + a2[i] + a3[i]));
+        } else {
+          load8(x + p * C + c8 * 8, v[it]);
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) ss += v[it][i] * v[it][i];
       }
@@ -75,11 +94,14 @@ __global__ __launch_bounds__(256) void k_pnorm_silu_fwd(const bf16* __restrict__
 
 // backward of the pair above.  g = gs*gxn + mp_silu'(xn)*ga ;  dx = (g - xn*<g,xn>*d/(C*(d-eps)))/d  (+ gadd: the
 // gradient that reaches the same tensor along another path -- the U-Net skip -- summed here instead of by autograd)
-template <int LPP>
+// UP (the backward of the POOL forward): the gradient leaves at the resolution BEFORE the pool -- gx (B, 2 Hp, 2 Wp, C), each
+// of a pooled pixel's four source pixels receives 0.25 * (the bf16-rounded pooled-resolution gradient) + gadd (gadd: at
+// that resolution too, the U-Net skip's gradient): k_pnorm_silu_bwd followed by k_up2(0.25, add), bit for bit
+template <int LPP, bool UP = false>
 __global__ __launch_bounds__(256) void k_pnorm_silu_bwd(const bf16* __restrict__ xn, const float* __restrict__ dsave,
                                                           const bf16* __restrict__ gxn, float gs,
                                                           const bf16* __restrict__ ga, const bf16* __restrict__ gadd,
-                                                          bf16* __restrict__ gx, int P, int C) {
+                                                          bf16* __restrict__ gx, int P, int C, int Hp = 0, int Wp = 0) {
   constexpr int GPW = 64 / LPP;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lig = lane % LPP, grp = lane / LPP;
@@ -125,6 +147,31 @@ __global__ __launch_bounds__(256) void k_pnorm_silu_bwd(const bf16* __restrict__
         float o[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = (g[it][i] - y[it][i] * coef) * inv;
+        if constexpr (UP) {
+          const int w = (int)(p % Wp);
+          const long t2 = p / Wp;
+          const int h = (int)(t2 % Hp);
+          const long b = t2 / Hp;
+          const long e0 = ((b * 2 * Hp + 2 * h) * 2 * Wp + 2 * w) * C + c8 * 8;
+          const long row = (long)2 * Wp * C;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = 0.25f * (float)(bf16)o[i];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const long e = e0 + (q >> 1) * row + (q & 1) * C;
+            float r[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = o[i];
+            if (gadd) {
+              float t[8];
+              load8(gadd + e, t);
+#pragma unroll
+              for (int i = 0; i < 8; ++i) r[i] += t[i];
+            }
+            store8(gx + e, r);
+          }
+          continue;
+        }
         if (gadd) {
           float t[8];
           load8(gadd + p * C + c8 * 8, t);
@@ -152,6 +199,38 @@ extern "C" int edm_pixelnorm_silu_fwd(const void* x, void* xn, void* a, float* d
   if (lpp == 16) L(16); else if (lpp == 32) L(32); else L(64);
 #undef L
   EDM_CHECK_LAUNCH("pixelnorm_silu_fwd");
+  return EDM_OK;
+}
+
+// pooled forms (see the POOL / UP template parameters): x / gx and gadd live at (B, 2 Hp, 2 Wp, C), xn / a / dsave / gxn / ga
+// at (B, Hp, Wp, C)
+extern "C" int edm_pool_pixelnorm_silu_fwd(const void* x, void* xn, void* a, float* dsave, int B, int Hp, int Wp, int C,
+                                           hipStream_t st) {
+  EDM_REQUIRE(x && xn && a && dsave && B > 0 && Hp > 0 && Wp > 0 && C > 0 && C % 8 == 0 && C <= 1024 &&
+                  (long)B * Hp * Wp < (1L << 31), "pool_pixelnorm_silu_fwd: bad args");
+  const long P = (long)B * Hp * Wp;
+  int lpp = pick_lpp(C);
+  int gpw = 64 / lpp;
+  int grid = grid_for(P, 4 * gpw);
+#define L(N) hipLaunchKernelGGL((k_pnorm_silu_fwd<N, true>), dim3(grid), dim3(256), 0, st, (const bf16*)x, (bf16*)xn, (bf16*)a, dsave, (int)P, C, Hp, Wp)
+  if (lpp == 16) L(16); else if (lpp == 32) L(32); else L(64);
+#undef L
+  EDM_CHECK_LAUNCH("pool_pixelnorm_silu_fwd");
+  return EDM_OK;
+}
+extern "C" int edm_pool_pixelnorm_silu_bwd(const void* xn, const float* dsave, const void* gxn, float gxn_scale,
+                                           const void* ga, const void* gadd, void* gx, int B, int Hp, int Wp, int C,
+                                           hipStream_t st) {
+  EDM_REQUIRE(xn && dsave && gx && B > 0 && Hp > 0 && Wp > 0 && C > 0 && C % 8 == 0 && C <= 1024 &&
+                  (long)B * Hp * Wp < (1L << 31), "pool_pixelnorm_silu_bwd: bad args");
+  const long P = (long)B * Hp * Wp;
+  int lpp = pick_lpp(C);
+  int gpw = 64 / lpp;
+  int grid = grid_for(P, 4 * gpw);
+#define L(N) hipLaunchKernelGGL((k_pnorm_silu_bwd<N, true>), dim3(grid), dim3(256), 0, st, (const bf16*)xn, dsave, (const bf16*)gxn, gxn_scale, (const bf16*)ga, (const bf16*)gadd, (bf16*)gx, (int)P, C, Hp, Wp)
+  if (lpp == 16) L(16); else if (lpp == 32) L(32); else L(64);
+#undef L
+  EDM_CHECK_LAUNCH("pool_pixelnorm_silu_bwd");
   return EDM_OK;
 }
 
@@ -472,6 +551,33 @@ __global__ void k_up2(const bf16* __restrict__ x, const bf16* __restrict__ add, 
     }
     store8(y + i * 8, a0);
   }
+}
+// DecU blocks (networks.py:312-316): y = nearest-exact x2 of x and a = mp_silu(y), one pass (k_up2 then k_silu_fwd, bit for bit)
+__global__ void k_up2_silu(const bf16* __restrict__ x, bf16* __restrict__ y, bf16* __restrict__ a, int H, int W, int CL,
+                           long n8) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    int c8 = (int)(i % CL);
+    long pix = i / CL;
+    int w = (int)(pix % W);
+    long t = pix / W;
+    int h = (int)(t % H);
+    long b = t / H;
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(x + (((b * (H / 2) + h / 2) * (W / 2) + w / 2) * CL + c8) * 8);
+    *reinterpret_cast<u32x4*>(y + i * 8) = raw;
+    const bf16x8 v = __builtin_bit_cast(bf16x8, raw);
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = mp_silu_b((float)v[j]);
+    store8(a + i * 8, f);
+  }
+}
+extern "C" int edm_up2_silu(const void* x, void* y, void* a, int B, int Hout, int Wout, int C, hipStream_t st) {
+  EDM_REQUIRE(x && y && a && B > 0 && Hout > 0 && Wout > 0 && Hout % 2 == 0 && Wout % 2 == 0 && C % 8 == 0, "up2_silu: bad args");
+  long n8 = (long)B * Hout * Wout * C / 8;
+  hipLaunchKernelGGL(k_up2_silu, dim3(grid_for(n8, 256)), dim3(256), 0, st, (const bf16*)x, (bf16*)y, (bf16*)a, Hout, Wout,
+                     C / 8, n8);
+  EDM_CHECK_LAUNCH("up2_silu");
+  return EDM_OK;
 }
 extern "C" int edm_pool2(const void* x, void* y, int B, int Hout, int Wout, int C, float scale, hipStream_t st) {
   EDM_REQUIRE(B > 0 && Hout > 0 && Wout > 0 && C % 8 == 0, "pool2: bad args");

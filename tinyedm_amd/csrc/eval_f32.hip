@@ -409,6 +409,91 @@ __global__ void k_up2_f32(const float* __restrict__ x, float* __restrict__ y, in
     st4(y + i * 4, ld4(x + (((b * (H / 2) + h / 2) * (W / 2) + w / 2) * C4 + c4) * 4));
   }
 }
+// ---- round 6: the launches that only existed because of where a tensor was materialised (the eval-shaped fusions) ----
+// EncD blocks without a 1x1 conv (networks.py:246-252): 2x2 average pool -> pixel norm -> mp_silu in ONE pass; the pooled
+// tensor is never written.  One wave per OUTPUT pixel; same arithmetic, in the same order, as k_pool2_f32 followed by
+// k_pnorm_silu_f32 (bit-identical).  H, W = output dims; C <= 1024.
+__global__ __launch_bounds__(256) void k_pool_pnorm_silu_f32(const float* __restrict__ x, float* __restrict__ xn,
+                                                               float* __restrict__ s, long P, int H, int W, int C,
+                                                               int s_pairs) {
+  const int lane = threadIdx.x & 63;
+  for (long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6); p < P; p += (long)gridDim.x * 4) {
+    const int w = (int)(p % W);
+    const long t = p / W;
+    const int h = (int)(t % H);
+    const long b = t / H;
+    const float* r0 = x + ((b * 2 * H + 2 * h) * 2 * W + 2 * w) * C;
+    const long rs = (long)2 * W * C;
+    f32x4 v[4];
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = lane * 4 + k * 256;
+      if (c < C) {
+        const f32x4 a = ld4(r0 + c), b1 = ld4(r0 + C + c), cc = ld4(r0 + rs + c), d = ld4(r0 + rs + C + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[k][e] = 0.25f * (a[e] + b1[e] + cc[e] + d[e]);
+        ss += v[k][0] * v[k][0] + v[k][1] * v[k][1] + v[k][2] * v[k][2] + v[k][3] * v[k][3];
+      }
+    }
+    ss = wave_sum(ss);
+    const float inv = 1.0f / (NORM_EPS + sqrtf(ss) / sqrtf((float)C));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = lane * 4 + k * 256;
+      if (c < C) {
+        f32x4 o = v[k], a;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] *= inv;
+          a[e] = mp_silu_f(o[e]);
+        }
+        st4(xn + p * C + c, o);
+        if (s_pairs) st4_pairs(reinterpret_cast<bf16*>(s) + p * 2 * C, C, c, a);
+        else st4(s + p * C + c, a);
+      }
+    }
+  }
+}
+// DecU blocks (networks.py:312-316): y = nearest-exact x2 of x, s = mp_silu(y) (fp32, or pairs with rows of Cp) in one pass
+__global__ void k_up2_silu_f32(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ s, int H, int W,
+                               int C4, long n4, int Cp) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long p = i / C4;
+    const long pix = p;
+    const int w = (int)(p % W);
+    p /= W;
+    const int h = (int)(p % H);
+    const long b = p / H;
+    f32x4 v = ld4(x + (((b * (H / 2) + h / 2) * (W / 2) + w / 2) * C4 + c4) * 4);
+    st4(y + i * 4, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = mp_silu_f(v[e]);
+    if (Cp) st4_pairs(reinterpret_cast<bf16*>(s) + pix * 2 * Cp, Cp, c4 * 4, v);
+    else st4(s + i * 4, v);
+  }
+}
+// the skip half of the decoder's concatenated operands, pairs form (the input half was written by the producer of `input`:
+// edm_split_conv_o): cat[p, Ci + c] = skip[p, c] * gate[b, c], sil[p, Ci + c] = mp_silu of it; rows [hi(Ct) | lo(Ct)]
+__global__ void k_skip_half_f32(const float* __restrict__ skip, const float* __restrict__ gate, bf16* __restrict__ catp,
+                                bf16* __restrict__ silp, int HW, int Ci, int Cs, long n4) {
+  const int CLs = Cs >> 2, Ct = Ci + Cs;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int cs = (int)(i % CLs) * 4;
+    const long pix = i / CLs;
+    f32x4 v = ld4(skip + pix * Cs + cs);
+    const f32x4 gp = ld4(gate + (pix / HW) * Cs + cs);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= gp[e];
+    st4_pairs(catp + pix * 2 * Ct, Ct, Ci + cs, v);
+    if (silp) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = mp_silu_f(v[e]);
+      st4_pairs(silp + pix * 2 * Ct, Ct, Ci + cs, v);
+    }
+  }
+}
 // per-sample mean over H*W (fixed order) + the ScaleLong gate MLP, one workgroup per sample (as k_skip_gate_fwd)
 __global__ __launch_bounds__(1024) void k_skip_gate_f32(const float* __restrict__ skip, const float* __restrict__ W1,
                                                           const float* __restrict__ W2, float* __restrict__ gate, int HW,
@@ -668,6 +753,34 @@ extern "C" int edm_f32_up2(const float* x, float* y, int B, int Hout, int Wout, 
   const long n4 = (long)B * Hout * Wout * C / 4;
   hipLaunchKernelGGL(k_up2_f32, dim3(gridf(n4, 256)), dim3(256), 0, st, x, y, Hout, Wout, C / 4, n4);
   EDM_CHECK_LAUNCH("f32_up2");
+  return EDM_OK;
+}
+extern "C" int edm_f32_pool_pixelnorm_silu(const float* x, float* xn, float* s, int B, int Hout, int Wout, int C,
+                                           int s_pairs, hipStream_t st) {
+  EDM_REQUIRE(x && xn && s && B > 0 && Hout > 0 && Wout > 0 && C > 0 && C % 4 == 0 && C <= 1024,
+              "f32_pool_pixelnorm_silu: bad args (C %% 4, C <= 1024)");
+  const long P = (long)B * Hout * Wout;
+  hipLaunchKernelGGL(k_pool_pnorm_silu_f32, dim3(gridf(P, 4)), dim3(256), 0, st, x, xn, s, P, Hout, Wout, C, s_pairs);
+  EDM_CHECK_LAUNCH("f32_pool_pixelnorm_silu");
+  return EDM_OK;
+}
+extern "C" int edm_f32_up2_silu(const float* x, float* y, float* s, int B, int Hout, int Wout, int C, int s_pairs,
+                                hipStream_t st) {
+  EDM_REQUIRE(x && y && s && B > 0 && Hout > 0 && Wout > 0 && Hout % 2 == 0 && Wout % 2 == 0 && C > 0 && C % 4 == 0,
+              "f32_up2_silu: bad args");
+  const long n4 = (long)B * Hout * Wout * C / 4;
+  hipLaunchKernelGGL(k_up2_silu_f32, dim3(gridf(n4, 256)), dim3(256), 0, st, x, y, s, Hout, Wout, C / 4, n4, s_pairs ? C : 0);
+  EDM_CHECK_LAUNCH("f32_up2_silu");
+  return EDM_OK;
+}
+extern "C" int edm_f32_skip_half(const float* skip, const float* gate, void* cat_pairs, void* silu_pairs, int B, int HW,
+                                 int Ci, int Cs, hipStream_t st) {
+  EDM_REQUIRE(skip && gate && cat_pairs && B > 0 && HW > 0 && Ci > 0 && Cs > 0 && Ci % 4 == 0 && Cs % 4 == 0,
+              "f32_skip_half: bad args");
+  const long n4 = (long)B * HW * Cs / 4;
+  hipLaunchKernelGGL(k_skip_half_f32, dim3(gridf(n4, 256)), dim3(256), 0, st, skip, gate, (bf16*)cat_pairs,
+                     (bf16*)silu_pairs, HW, Ci, Cs, n4);
+  EDM_CHECK_LAUNCH("f32_skip_half");
   return EDM_OK;
 }
 extern "C" int edm_f32_skip_gate(const float* skip, const float* W1h, const float* W2h, float* gate, int B, int HW, int C,

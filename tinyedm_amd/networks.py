@@ -538,26 +538,33 @@ class DownSample(nn.Module):
 
 class _ResampleFn(torch.autograd.Function):
     """alias=True (downsample only): the input is handed back as a second output for the U-Net skip, so that the skip's
-    gradient arrives HERE and is added inside the backward kernel instead of by an autograd `add` (see _ResBlockFn)."""
+    gradient arrives HERE and is added inside the backward kernel instead of by an autograd `add` (see _ResBlockFn).
+    want_silu=True (upsample only, round 6): the second output is mp_silu of the upsampled tensor -- the operand of the DecU
+    block's first conv (networks.py:313-316) -- written by the same pass (ops.up2_silu); not differentiable: the block's
+    backward applies mp_silu' itself."""
 
     @staticmethod
-    def forward(ctx, x, up: bool, alias: bool = False):
+    def forward(ctx, x, up: bool, alias: bool = False, want_silu: bool = False):
         ctx.up = up
         ctx.set_materialize_grads(False)
+        if up and want_silu:
+            y, s = ops.up2_silu(x)
+            ctx.mark_non_differentiable(s)
+            return y, s
         y = ops.up2(x) if up else ops.pool2(x, 0.25)
         return (y, x) if alias else y
 
     @staticmethod
     def backward(ctx, g, g_alias=None):
         if g is None:
-            return g_alias, None, None
+            return g_alias, None, None, None
         g = g.contiguous()
         if ctx.up:
             gx = ops.pool2(g, 1.0)
             if g_alias is not None:
                 gx = ops.axpby(gx, 1.0, g_alias.contiguous(), 1.0)
-            return gx, None, None
-        return ops.up2(g, 0.25, add=None if g_alias is None else g_alias.contiguous()), None, None
+            return gx, None, None, None
+        return ops.up2(g, 0.25, add=None if g_alias is None else g_alias.contiguous()), None, None, None
 
 
 class UncertaintyNet(nn.Module):
@@ -609,6 +616,11 @@ U_MARKS = os.environ.get("EDM_U_MARKS", "1") != "0"
 # produces d loss / d cat writes its two halves to the tensors their consumers read (ops.conv_igemm(split=)).
 # EDM_FUSE_CAT=0 keeps the standalone concat kernels (A/B runs).
 FUSE_CAT = os.environ.get("EDM_FUSE_CAT", "1") != "0"
+# round 6: launches that only existed because of where a tensor was materialised -- the 2x2 average pool of an EncD block
+# without a 1x1 conv rides in the pixel-norm kernels (forward: ops.pool_pixelnorm_silu_fwd, the pooled tensor is never
+# written; backward: the pixel-norm backward writes the gradient at the resolution before the pool), and a DecU block's
+# upsample also emits mp_silu of its result (ops.up2_silu).  Bit-identical; EDM_FUSE_RESAMPLE=0 keeps the separate kernels.
+FUSE_RESAMPLE = os.environ.get("EDM_FUSE_RESAMPLE", "1") != "0"
 # fragment-major weight packs for the layers k_conv3x3_s runs (Denoiser._frag_flags); EDM_FRAG_PACKS=0: plain packs (A/B runs)
 FRAG_PACKS = os.environ.get("EDM_FRAG_PACKS", "1") != "0"
 
@@ -790,9 +802,10 @@ class CosineAttention(nn.Module):
         y = self.forward_nhwc(ops.nchw_to_nhwc_bf16(x.float().contiguous()))
         return ops.nhwc_bf16_to_nchw(y).to(x.dtype)
 
-    def forward_f32(self, x: Tensor) -> Tensor:
-        """reference-precision evaluation (NHWC fp32 in / out): qkv conv in the master row order, exact-fp32 attention"""
-        qkv = _conv_f32(self.qkv_conv, x, 1)
+    def forward_f32(self, x: Tensor, xp: Tensor | None = None, want=None):
+        """reference-precision evaluation (NHWC fp32 in / out): qkv conv in the master row order, exact-fp32 attention.
+        xp: x as split-bf16 pairs when the producer of x wrote them in the same launch; want: see _res_f32"""
+        qkv = _conv_f32(self.qkv_conv, xp if (xp is not None and _split_ok(self.qkv_conv)) else x, 1)
         B, H, W, _ = qkv.shape
         if _split_ok(self.out_conv) and ops.split_attention_ok(self.embedding_dim, self.num_heads, H * W):
             # split back end: the attention runs on the bf16 matrix cores too (three passes over hi/lo pairs) and hands its
@@ -801,7 +814,7 @@ class CosineAttention(nn.Module):
         else:
             y = ops.f32_attention(qkv, self.num_heads)
         a, b = _mp_coeffs(0.5)
-        return _conv_f32(self.out_conv, y, 1, residual=x, alpha=b, beta=a)
+        return _conv_f32(self.out_conv, y, 1, residual=x, alpha=b, beta=a, want=want)
 
 
 class _AttnFn(torch.autograd.Function):
@@ -867,11 +880,13 @@ class _ResBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, u, emb, w1x1, w1, w2, wemb, gain, blk, lin_view, glin_view, token, s_pre=None, alias=False,
-                gm_view=None, skip=None, w_sl1=None, w_sl2=None, pre=None, dest=None):
+                gm_view=None, skip=None, w_sl1=None, w_sl2=None, pre=None, dest=None, pool=False):
         # skip (decoder blocks with a U-Net skip and no upsample, FUSE_CAT): the concatenation of networks.py:311 happens
         # HERE.  pre = (cat, sil) whose left halves the producer of u already wrote (u is that half of cat): only the gated
         # skip half is filled in; otherwise the standalone concat kernel builds both.  dest = the (cat, sil) buffers of the
         # NEXT block: this block's last kernel writes its output (and mp_silu of it) into their left halves.
+        # pool=True (encoder blocks with a downsample and no 1x1 conv, FUSE_RESAMPLE): u is the tensor BEFORE the 2x2 average
+        # pool; the pool happens inside the pixel-norm kernels of both directions.
         # alias=True: the block input u is handed back as a second output.  The Denoiser takes the U-Net skip from that
         # output, so the skip's gradient arrives in THIS backward (g_alias) and is added by the kernel that writes the
         # input gradient -- not by an autograd `add` launch per skip (9-16 ATen kernels, 0.8 GB per step, round 1).
@@ -897,7 +912,11 @@ class _ResBlockFn(torch.autograd.Function):
                 cat, s_pre = ops.concat_gate_fwd(u.contiguous(), skip, gate, True)
             u = cat
             ctx.skip_saved = (skip, mean, gate, z1, w1h, w2h)
-        if enc:
+        ctx.pool = bool(pool)
+        if enc and pool:
+            assert not has1
+            xres, s, dsave = ops.pool_pixelnorm_silu_fwd(u)
+        elif enc:
             x = u
             if has1:
                 wf11, wd11, _ = blk.conv_1x1.packs()
@@ -934,8 +953,9 @@ class _ResBlockFn(torch.autograd.Function):
         ctx.u_marked = U_MARKS and ops.FUSE_MOD and ops.IGEMM_VERSION == 0
         ctx.batched, ctx.glin_view, ctx.gm_view = batched, glin_view, gm_view
         ctx.has_token = token is not None
-        ctx.save_for_backward(u, xres if enc else None, dsave, s, r1, lin, a2, None if batched else emb, gain, wd1, wd2,
-                              wd11, weh)
+        # (an encoder block without a 1x1 conv never reads u again: not kept -- with pool=True it is the 4x larger tensor)
+        ctx.save_for_backward(u if (not enc or has1) else None, xres if enc else None, dsave, s, r1, lin, a2,
+                              None if batched else emb, gain, wd1, wd2, wd11, weh)
         return (out, u) if alias else out
 
     @staticmethod
@@ -987,7 +1007,11 @@ class _ResBlockFn(torch.autograd.Function):
         gs = None if fuse else ops.conv_igemm(gr1, wd1, 9)      # decoder: mp_silu backward rides in the dgrad epilogue
         gw1 = _wgrad(blk.conv_3x3_1, s, gr1, 9)
         gw11 = None
-        if enc:
+        if enc and ctx.pool:
+            # pixel-norm backward + the pool's backward (4 pixels per pooled pixel, 1/4 each) + the skip gradient: one pass
+            gu = ops.pool_pixelnorm_silu_bwd(xn, dsave, gout, a, gs, gadd=g_alias)
+            g_alias = None
+        elif enc:
             gx = ops.pixelnorm_silu_bwd(xn, dsave, gout, a, gs, gadd=None if has1 else g_alias)
             if has1:
                 gw11 = _wgrad(blk.conv_1x1, u, gx, 1)
@@ -1030,7 +1054,7 @@ class _ResBlockFn(torch.autograd.Function):
         if g_alias is not None:         # decoder blocks are never asked for an alias; kept for completeness
             gu = ops.axpby(gu, 1.0, g_alias, 1.0)
         return (gu, gemb, gw11, gw1, gw2, gwemb, ggain, None, None, None, gtoken, None, None, None, gskip, gwsl1, gwsl2,
-                None, None)
+                None, None, None)
 
 
 _rng_sub_counter = [0]
@@ -1049,15 +1073,16 @@ class _BlockBase(nn.Module):
         _rng_sub_counter[0] += 1
         self.rng_sub = _rng_sub_counter[0]
 
-    def _res(self, u: Tensor, embedding: Tensor, lin=None, s_pre=None, alias=False, skip=None, dest=None):
-        """alias=True: returns (out, alias of u) -- see _ResBlockFn.forward.  skip / dest: FUSE_CAT (decoder blocks)"""
+    def _res(self, u: Tensor, embedding: Tensor, lin=None, s_pre=None, alias=False, skip=None, dest=None, pool=False):
+        """alias=True: returns (out, alias of u) -- see _ResBlockFn.forward.  skip / dest: FUSE_CAT (decoder blocks);
+        pool: u is the block input BEFORE its 2x2 average pool (FUSE_RESAMPLE, encoder blocks)"""
         w11 = self.conv_1x1.weight if isinstance(self.conv_1x1, Conv2d) else None
         has_attn = isinstance(self.attention, CosineAttention)
         sk = ()
-        if skip is not None or dest is not None:
+        if skip is not None or dest is not None or pool:
             cf = self.cat_factor if skip is not None else None
             sk = (skip, cf.layer1.weight if cf is not None else None, cf.layer2.weight if cf is not None else None,
-                  getattr(u, "_edm_cat", None) if skip is not None else None, None if has_attn else dest)
+                  getattr(u, "_edm_cat", None) if skip is not None else None, None if has_attn else dest, bool(pool))
         if lin is None:
             out = _ResBlockFn.apply(u, embedding, w11, self.conv_3x3_1.weight, self.conv_3x3_2.weight,
                                     self.embed.weight, self.gain, self, None, None, None, s_pre, alias, None, *sk)
@@ -1081,6 +1106,10 @@ class _BlockBase(nn.Module):
 # kernels (ops.split_conv) -- 2^-17 per operand instead of exact, a third of the bf16 rate instead of a sixteenth.  Everything
 # between the convs (fp32 activations, elementwise kernels, attention) is shared.
 _SPLIT_EVAL = [False]
+# round 6: in the split evaluation a block's last conv writes what its CONSUMER reads (the input halves of the next block's
+# concatenated operands, mp_silu pairs, pairs for the attention's qkv conv) instead of fp32 + a copy / elementwise kernel per
+# consumer; EDM_F32_FUSE_OUT=0 keeps the round-5 sequence (A/B runs)
+F32_FUSE_OUT = os.environ.get("EDM_F32_FUSE_OUT", "1") != "0"
 
 
 def _split_ok(mod) -> bool:
@@ -1088,9 +1117,22 @@ def _split_ok(mod) -> bool:
     return bool(_SPLIT_EVAL[0]) and isinstance(mod, _WNBase) and mod.weight.shape[1] % 32 == 0 and mod.weight.shape[0] % 8 == 0
 
 
-def _conv_f32(mod: "_WNBase", x: Tensor, taps: int, pairs_out: bool = False, **kw) -> Tensor:
+class _CatPre:
+    """what a decoder block of the split evaluation hands to a successor that concatenates its output with a U-Net skip:
+    the pairs buffers of torch.cat((input, skip * gate)) and of mp_silu of it (networks.py:311, 316) with their LEFT column
+    blocks already written by the producer's last kernel (ops.split_conv(dest=)); the successor fills the skip halves"""
+    __slots__ = ("cat", "sil")
+
+    def __init__(self, cat, sil):
+        self.cat, self.sil = cat, sil
+
+
+def _conv_f32(mod: "_WNBase", x: Tensor, taps: int, pairs_out: bool = False, want=None, **kw):
     """x: fp32 NHWC, or -- split back end only -- bf16 (hi, lo) pairs written by the producer (ops.f32_pixelnorm_silu /
-    f32_silu / f32_concat_gate / split_conv with pairs=True).  pairs_out: hand the result on as pairs (split back end only)."""
+    f32_silu / f32_concat_gate / split_conv with pairs=True).  pairs_out: hand the result on as pairs (split back end only).
+    want (split back end only; round 6: what the CONSUMER of this conv's output reads, written by this launch instead of by
+    a copy / elementwise kernel of its own): "pairs" -> (fp32, pairs); "silu" -> (fp32, mp_silu as pairs);
+    ("dest", cat, sil) -> _CatPre(cat, sil), the left column blocks of the next block's concatenated operands"""
     w_hat = mod.packs()[2]
     if _split_ok(mod):
         key = (mod.weight.data_ptr(), mod.weight._version, _WEIGHT_EPOCH)
@@ -1101,23 +1143,41 @@ def _conv_f32(mod: "_WNBase", x: Tensor, taps: int, pairs_out: bool = False, **k
                                    "it before the capture: Denoiser._prep_all)")
             mod._split_pack, mod._split_key = ops.split_pack(w_hat, taps), key
         xp = x if x.dtype == bf16 else ops.f32_to_pairs(x)
+        if want == "pairs":
+            return ops.split_conv(xp, mod._split_pack, taps, also_pairs=True, **kw)
+        if want == "silu":
+            return ops.split_conv(xp, mod._split_pack, taps, silu_pairs=True, **kw)
+        if want is not None:
+            _, cat, sil = want
+            ops.split_conv(xp, mod._split_pack, taps, dest=(cat, sil), **kw)
+            return _CatPre(cat, sil)
         return ops.split_conv(xp, mod._split_pack, taps, pairs_out=pairs_out, **kw)
-    if x.dtype == bf16 or pairs_out:
+    if x.dtype == bf16 or pairs_out or want is not None:
         raise RuntimeError("tinyedm_amd: split-bf16 pairs reached a conv that runs on the exact-fp32 kernel")
     return ops.f32_conv(x, w_hat, taps, **kw)
 
 
-def _res_f32(blk, xres: Tensor, s: Tensor, lin: Tensor) -> Tensor:
+def _res_f32(blk, xres: Tensor, s: Tensor, lin: Tensor, want=None):
     """the residual branch of a block in the reference-precision evaluation path: conv3x3 -> modulation + mp_silu (fused
-    epilogue; eval: no dropout) -> conv3x3 + mp_add with the skip path (networks.py:253-263 / 317-327)"""
+    epilogue; eval: no dropout) -> conv3x3 + mp_add with the skip path (networks.py:253-263 / 317-327).
+    want: what the block's output must come as (see _conv_f32; decided by Denoiser._forward_f32 from the NEXT block)"""
     # (split back end: a2 only feeds conv2 -- it travels as pairs, written by conv1's epilogue)
     a2 = _conv_f32(blk.conv_3x3_1, s, 9, lin=lin, gain=blk.gain.detach(),
                    pairs_out=_split_ok(blk.conv_3x3_1) and _split_ok(blk.conv_3x3_2))
     a, b = _mp_coeffs(blk.add_factor)
-    out = _conv_f32(blk.conv_3x3_2, a2, 9, residual=xres, alpha=b, beta=a)
     if isinstance(blk.attention, CosineAttention):
-        out = blk.attention.forward_f32(out)
-    return out
+        # (the attention reads the block's output twice: as the qkv conv's operand -- pairs, from the same launch -- and as
+        # the fp32 residual of its out conv)
+        both = _split_ok(blk.conv_3x3_2) and _split_ok(blk.attention.qkv_conv)
+        out = _conv_f32(blk.conv_3x3_2, a2, 9, residual=xres, alpha=b, beta=a, want="pairs" if both else None)
+        out, outp = out if both else (out, None)
+        return blk.attention.forward_f32(out, outp, want)
+    return _conv_f32(blk.conv_3x3_2, a2, 9, residual=xres, alpha=b, beta=a, want=want)
+
+
+def _out_conv_split(blk) -> bool:
+    """the conv that writes this block's output runs on the split back end (so it can write what the consumer reads)"""
+    return _split_ok(blk.attention.out_conv if isinstance(blk.attention, CosineAttention) else blk.conv_3x3_2)
 
 
 def _as_nhwc(x: Tensor):
@@ -1151,27 +1211,39 @@ class EncoderBlock(_BlockBase):
         be taken from, so that the skip gradient is summed inside this block's backward kernels."""
         x, conv = _as_nhwc(input)
         ualias = None
-        if isinstance(self.resample, DownSample):
-            if _alias:
-                x, ualias = _ResampleFn.apply(x, False, True)
-            else:
-                x = _ResampleFn.apply(x, False)
         emb = None if _lin is not None else _emb32(embedding, x.shape[0])
-        if _alias and ualias is None:
-            out, ualias = self._res(x, emb, _lin, alias=True)
+        if (isinstance(self.resample, DownSample) and FUSE_RESAMPLE and not isinstance(self.conv_1x1, Conv2d)
+                and x.shape[-1] <= 1024 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0):
+            # the pool rides in the block's pixel-norm kernels (forward and backward); the alias is the tensor before it
+            out = self._res(x, emb, _lin, alias=_alias, pool=True)
+            if _alias:
+                out, ualias = out
         else:
-            out = self._res(x, emb, _lin)
+            if isinstance(self.resample, DownSample):
+                if _alias:
+                    x, ualias = _ResampleFn.apply(x, False, True)
+                else:
+                    x = _ResampleFn.apply(x, False)
+            if _alias and ualias is None:
+                out, ualias = self._res(x, emb, _lin, alias=True)
+            else:
+                out = self._res(x, emb, _lin)
         out = ops.nhwc_bf16_to_nchw(out).to(input.dtype) if conv else _tag(out)
         return (out, _tag(ualias)) if _alias else out
 
-    def forward_f32(self, x: Tensor, lin: Tensor) -> Tensor:
+    def forward_f32(self, x: Tensor, lin: Tensor, want=None):
         """networks.py:246-265 on NHWC fp32 activations (evaluation only); lin = this block's embed Linear output (B, C)"""
-        if isinstance(self.resample, DownSample):
-            x = ops.f32_pool2(x)
-        if isinstance(self.conv_1x1, Conv2d):
-            x = _conv_f32(self.conv_1x1, x, 1)
-        xn, s = ops.f32_pixelnorm_silu(x, pairs=_split_ok(self.conv_3x3_1))
-        return _res_f32(self, xn, s, lin)
+        pairs = _split_ok(self.conv_3x3_1)
+        if (F32_FUSE_OUT and isinstance(self.resample, DownSample) and not isinstance(self.conv_1x1, Conv2d)
+                and x.shape[-1] <= 1024):
+            xn, s = ops.f32_pool_pixelnorm_silu(x, pairs=pairs)     # the pooled tensor is never written
+        else:
+            if isinstance(self.resample, DownSample):
+                x = ops.f32_pool2(x)
+            if isinstance(self.conv_1x1, Conv2d):
+                x = _conv_f32(self.conv_1x1, x, 1)
+            xn, s = ops.f32_pixelnorm_silu(x, pairs=pairs)
+        return _res_f32(self, xn, s, lin, want)
 
 
 class DecoderBlock(_BlockBase):
@@ -1209,28 +1281,43 @@ class DecoderBlock(_BlockBase):
             if fuse_silu:
                 x, s_pre = x
         if isinstance(self.resample, UpSample):
-            x = _ResampleFn.apply(x, True)
-            s_pre = None
+            if FUSE_RESAMPLE:
+                x, s_pre = _ResampleFn.apply(x, True, False, True)      # mp_silu of the upsampled tensor from the same pass
+            else:
+                x = _ResampleFn.apply(x, True)
+                s_pre = None
         out = self._res(x, None if _lin is not None else _emb32(embedding, x.shape[0]), _lin, s_pre, dest=_dest)
         return ops.nhwc_bf16_to_nchw(out).to(input.dtype) if conv else _tag(out)
 
-    def forward_f32(self, x: Tensor, lin: Tensor, skip: Tensor | None = None) -> Tensor:
-        """networks.py:306-329 on NHWC fp32 activations (evaluation only)"""
-        s = None
+    def forward_f32(self, x, lin: Tensor, skip: Tensor | None = None, want=None):
+        """networks.py:306-329 on NHWC fp32 activations (evaluation only).  x: fp32, or what the producer wrote for THIS
+        block (split back end, _conv_f32(want=)): (fp32, mp_silu pairs), or a _CatPre whose left halves hold x"""
+        s = silp = pre = None
+        if isinstance(x, _CatPre):
+            pre = x
+        elif isinstance(x, tuple):
+            x, silp = x
+        up = isinstance(self.resample, UpSample)
         if skip is not None:
             cf = self.cat_factor
             gate = ops.f32_skip_gate(skip, cf.layer1.packs()[2], cf.layer2.packs()[2])
-            up = isinstance(self.resample, UpSample)
-            # (split back end, no upsample behind the concat: cat and mp_silu(cat) only feed convs -- pairs)
-            pairs = (not up) and isinstance(self.conv_1x1, Conv2d) and _split_ok(self.conv_1x1) and _split_ok(self.conv_3x3_1)
-            x, s = ops.f32_concat_gate(x, skip, gate, not up, pairs=pairs)
-        if isinstance(self.resample, UpSample):
-            x = ops.f32_up2(x)
-            s = None
+            if pre is not None:
+                ops.f32_skip_half(skip, gate, pre.cat, pre.sil)    # the input halves are there already: no concat copy
+                x, s = pre.cat, pre.sil
+            else:
+                # (split back end, no upsample behind the concat: cat and mp_silu(cat) only feed convs -- pairs)
+                pairs = (not up) and isinstance(self.conv_1x1, Conv2d) and _split_ok(self.conv_1x1) and _split_ok(self.conv_3x3_1)
+                x, s = ops.f32_concat_gate(x, skip, gate, not up, pairs=pairs)
+        elif pre is not None:
+            raise RuntimeError("tinyedm_amd: a pre-concatenated input reached a decoder block without a skip")
+        if up and F32_FUSE_OUT:
+            x, s = ops.f32_up2_silu(x, pairs=_split_ok(self.conv_3x3_1))   # upsample + mp_silu of it: one pass
+        elif up:
+            x, s = ops.f32_up2(x), None
         xres = _conv_f32(self.conv_1x1, x, 1) if isinstance(self.conv_1x1, Conv2d) else x
         if s is None:
-            s = ops.f32_silu(x, pairs=_split_ok(self.conv_3x3_1))
-        return _res_f32(self, xres, s, lin)
+            s = silp if (silp is not None and _split_ok(self.conv_3x3_1)) else ops.f32_silu(x, pairs=_split_ok(self.conv_3x3_1))
+        return _res_f32(self, xres, s, lin, want)
 
 
 def _emb32(embedding: Tensor, B: int) -> Tensor:
@@ -1590,11 +1677,41 @@ class Denoiser(nn.Module):
         cp = 8 * ((self.in_channels + 1 + 7) // 8)
         x = ops.f32_conv(ops.f32_precond_in(noisy, sig, self.sigma_data, cp), self.conv_in.packs()[2], 9)
         skips = [x]
-        for block in self.encoder_blocks:
-            x = block.forward_f32(x, lins[block])
-            skips.append(x)
-        for block, has_skip in zip(self.decoder_blocks, self.skip_connections):
-            x = block.forward_f32(x, lins[block], skips.pop() if has_skip else None)
+        dec = list(zip(self.decoder_blocks, self.skip_connections))
+        split = bool(_SPLIT_EVAL[0]) and F32_FUSE_OUT
+
+        def want_of(block, nxt, n_skip, hw, skip_c):
+            """what `block`'s last conv writes for its consumer `nxt` (round 6: the eval-shaped forward of the split back
+            end): the input halves of nxt's concatenated operands / fp32 + mp_silu pairs / plain fp32"""
+            if not split or nxt is None or isinstance(nxt.resample, UpSample) or not _out_conv_split(block):
+                return None
+            if not _split_ok(nxt.conv_3x3_1):
+                return None
+            if n_skip:
+                if not (isinstance(nxt.conv_1x1, Conv2d) and _split_ok(nxt.conv_1x1)):
+                    return None
+                Ct = block.conv_3x3_2.weight.shape[0] + skip_c
+                shape = (noisy.shape[0], hw[0], hw[1], 2 * Ct)
+                return ("dest", torch.empty(shape, device=noisy.device, dtype=bf16),
+                        torch.empty(shape, device=noisy.device, dtype=bf16))
+            return None if isinstance(nxt.conv_1x1, Conv2d) else "silu"
+
+        enc = list(self.encoder_blocks)
+        h, w = x.shape[1], x.shape[2]
+        for i, block in enumerate(enc):
+            if isinstance(block.resample, DownSample):
+                h, w = h // 2, w // 2
+            # (only the LAST encoder output has a consumer besides the skip stack: the first decoder block, which has no skip)
+            want = want_of(block, dec[0][0], dec[0][1], (h, w), 0) if (i + 1 == len(enc) and dec and not dec[0][1]) else None
+            x = block.forward_f32(x, lins[block], want)
+            skips.append(x[0] if isinstance(x, tuple) else x)
+        for i, (block, has_skip) in enumerate(dec):
+            skip = skips.pop() if has_skip else None
+            if isinstance(block.resample, UpSample):
+                h, w = 2 * h, 2 * w
+            nxt, n_skip = dec[i + 1] if i + 1 < len(dec) else (None, False)
+            want = want_of(block, nxt, n_skip, (h, w), skips[-1].shape[-1] if (n_skip and skips) else 0)
+            x = block.forward_f32(x, lins[block], skip, want)
         return ops.f32_conv_out(x, self.conv_out.packs()[2], self.gain_out.detach(), noisy, sig, self.sigma_data)
 
     def forward(self, noisy_image: Tensor, sigma: Tensor, embedding: Tensor):

@@ -345,6 +345,44 @@ def pixelnorm_silu_bwd(xn, d, gxn, gxn_scale, ga, gadd=None):
     return gx
 
 
+def pool_pixelnorm_silu_fwd(x):
+    """(xn, a, d) of the 2x2-average-pooled x, the pooled tensor never written (== pixelnorm_silu_fwd(pool2(x)), bit for bit)"""
+    B, H, W, C = _nhwc(x, "x")
+    if H % 2 or W % 2 or C > 1024:
+        raise ValueError("pool_pixelnorm_silu_fwd: H, W even and C <= 1024 required")
+    xn = torch.empty(B, H // 2, W // 2, C, device=x.device, dtype=bf16)
+    a = torch.empty_like(xn)
+    d = torch.empty(B * (H // 2) * (W // 2), device=x.device, dtype=f32)
+    _lib.call("edm_pool_pixelnorm_silu_fwd", _p(x), _p(xn), _p(a), _p(d), B, H // 2, W // 2, C, _stream())
+    return xn, a, d
+
+
+def pool_pixelnorm_silu_bwd(xn, d, gxn, gxn_scale, ga, gadd=None):
+    """backward of pool_pixelnorm_silu_fwd: the gradient w.r.t. the tensor BEFORE the pool, (B, 2H, 2W, C); gadd (optional, that
+    shape): a gradient of the same tensor from another consumer (the U-Net skip) (== up2(pixelnorm_silu_bwd(...), 0.25, add=gadd))"""
+    B, H, W, C = _nhwc(xn, "xn")
+    _chk(d, f32, "d", (B * H * W,))
+    if gxn is not None:
+        _chk(gxn, bf16, "gxn", xn.shape)
+    if ga is not None:
+        _chk(ga, bf16, "ga", xn.shape)
+    if gadd is not None:
+        _chk(gadd, bf16, "gadd", (B, 2 * H, 2 * W, C))
+    gx = torch.empty(B, 2 * H, 2 * W, C, device=xn.device, dtype=bf16)
+    _lib.call("edm_pool_pixelnorm_silu_bwd", _p(xn), _p(d), _p(gxn), float(gxn_scale), _p(ga), _p(gadd), _p(gx), B, H, W, C,
+              _stream())
+    return gx
+
+
+def up2_silu(x):
+    """(y, a): y = nearest-exact x2 upsample of x, a = mp_silu(y), one pass"""
+    B, H, W, C = _nhwc(x, "x")
+    y = torch.empty(B, 2 * H, 2 * W, C, device=x.device, dtype=bf16)
+    a = torch.empty_like(y)
+    _lib.call("edm_up2_silu", _p(x), _p(y), _p(a), B, 2 * H, 2 * W, C, _stream())
+    return y, a
+
+
 def silu_fwd(x):
     _chk(x, bf16, "x")
     a = torch.empty_like(x)
@@ -1322,10 +1360,16 @@ def split_pack(w_hat, taps, out=None):
     return pk
 
 
-def split_conv(xp, pack3, taps, residual=None, alpha=1.0, beta=0.0, lin=None, gain=None, pairs_out=False):
+def split_conv(xp, pack3, taps, residual=None, alpha=1.0, beta=0.0, lin=None, gain=None, pairs_out=False, also_pairs=False,
+               dest=None, silu_pairs=False):
     """fp32-accurate conv in three bf16 MFMA passes: xp (B,H,W,2C) bf16 pairs (f32_to_pairs), pack3 (taps,Cout,3C) bf16
     (split_pack) -> (B,H,W,Cout) fp32 = alpha*conv + beta*residual, or with lin/gain mp_silu(alpha*conv*(lin*gain+1));
-    pairs_out=True: the result comes back as (B,H,W,2Cout) bf16 pairs instead (it only feeds another split_conv)"""
+    pairs_out=True: the result comes back as (B,H,W,2Cout) bf16 pairs instead (it only feeds another split_conv);
+    also_pairs=True: (fp32 result, the same as pairs) from the one launch;
+    silu_pairs=True: (fp32 result, mp_silu of it as pairs): what a decoder block without a skip reads (networks.py:313-316);
+    dest=(cat, sil): (B,H,W,2 Ct) bf16 pairs buffers of the NEXT decoder block's concatenated operands, Ct > Cout: the result
+    and mp_silu of it are written into their left column blocks (hi at columns [0, Cout), lo at [Ct, Ct + Cout)) and nothing
+    else; returns cat (f32_skip_half fills the right blocks)."""
     B, H, W, C2 = _nhwc(xp, "xp")
     C = C2 // 2
     _chk(pack3, bf16, "pack3")
@@ -1338,13 +1382,70 @@ def split_conv(xp, pack3, taps, residual=None, alpha=1.0, beta=0.0, lin=None, ga
     if lin is not None:
         ls = _lin_view(lin, B, Cout, "lin")
         _chk(gain, f32, "gain")
+    if sum(map(bool, (pairs_out, also_pairs, dest is not None, silu_pairs))) > 1:
+        raise ValueError("split_conv: pairs_out / also_pairs / silu_pairs / dest exclude one another")
+    nb = 4.0 * B * H * W * (C + Cout * (2 if residual is not None else 1)) + 2.0 * pack3.numel()
+    pname = "split_conv3x3" if taps == 9 else "split_conv1x1"
+    if dest is not None or also_pairs or silu_pairs:
+        y = yp = ys = None
+        ld = lo = 0
+        if dest is not None:
+            cat, sil = dest
+            Ct = cat.shape[-1] // 2
+            _chk(cat, bf16, "dest[0]", (B, H, W, 2 * Ct))
+            if sil is not None:
+                _chk(sil, bf16, "dest[1]", (B, H, W, 2 * Ct))
+            if Ct <= Cout or Ct % 4:
+                raise ValueError("split_conv: dest must be wider than the result")
+            yp, ys, ld, lo = cat, sil, 2 * Ct, Ct
+        else:
+            y = torch.empty(B, H, W, Cout, device=xp.device, dtype=f32)
+            p2 = torch.empty(B, H, W, 2 * Cout, device=xp.device, dtype=bf16)
+            yp, ys = (p2, None) if also_pairs else (None, p2)
+        with _prof(pname, 2.0 * B * H * W * C * Cout * taps, nb):
+            _lib.call("edm_split_conv_o", _p(xp), _p(pack3), _p(y), _p(yp), ld, lo, _p(ys), _p(residual), float(alpha),
+                      float(beta), _p(lin), ls, _p(gain), B, H, W, C, Cout, taps, _stream())
+        return cat if dest is not None else (y, p2)
     y = None if pairs_out else torch.empty(B, H, W, Cout, device=xp.device, dtype=f32)
     yp = torch.empty(B, H, W, 2 * Cout, device=xp.device, dtype=bf16) if pairs_out else None
-    with _prof("split_conv3x3" if taps == 9 else "split_conv1x1", 2.0 * B * H * W * C * Cout * taps,
-               4.0 * B * H * W * (C + Cout * (2 if residual is not None else 1)) + 2.0 * pack3.numel()):
+    with _prof(pname, 2.0 * B * H * W * C * Cout * taps, nb):
         _lib.call("edm_split_conv", _p(xp), _p(pack3), _p(y), _p(yp), _p(residual), float(alpha), float(beta), _p(lin), ls,
                   _p(gain), B, H, W, C, Cout, taps, _stream())
     return yp if pairs_out else y
+
+
+def f32_skip_half(skip, gate, cat, sil=None):
+    """cat[..., Ci:Ct] (hi) / [Ct+Ci:2Ct] (lo) = pairs of skip*gate, sil likewise of mp_silu(skip*gate): the skip half of the
+    split evaluation's concatenated operands (the input half: split_conv(dest=))"""
+    B, H, W, Cs = _nhwc32(skip, "skip")
+    _chk(gate, f32, "gate", (B, Cs))
+    Ct = cat.shape[-1] // 2
+    _chk(cat, bf16, "cat", (B, H, W, 2 * Ct))
+    if sil is not None:
+        _chk(sil, bf16, "sil", (B, H, W, 2 * Ct))
+    if Ct <= Cs:
+        raise ValueError("f32_skip_half: cat must be wider than the skip")
+    _lib.call("edm_f32_skip_half", _p(skip), _p(gate), _p(cat), _p(sil), B, H * W, Ct - Cs, Cs, _stream())
+
+
+def f32_pool_pixelnorm_silu(x, pairs=False):
+    """(xn, s) of the 2x2-average-pooled x in one pass (== f32_pixelnorm_silu(f32_pool2(x)), bit for bit)"""
+    B, H, W, C = _nhwc32(x, "x")
+    if H % 2 or W % 2 or C > 1024:
+        raise ValueError("f32_pool_pixelnorm_silu: H, W even and C <= 1024 required")
+    xn = torch.empty(B, H // 2, W // 2, C, device=x.device, dtype=f32)
+    s = torch.empty(B, H // 2, W // 2, 2 * C, device=x.device, dtype=bf16) if pairs else torch.empty_like(xn)
+    _lib.call("edm_f32_pool_pixelnorm_silu", _p(x), _p(xn), _p(s), B, H // 2, W // 2, C, int(bool(pairs)), _stream())
+    return xn, s
+
+
+def f32_up2_silu(x, pairs=False):
+    """(y, s): y = nearest-exact x2 of x, s = mp_silu(y) as fp32 or pairs, one pass"""
+    B, H, W, C = _nhwc32(x, "x")
+    y = torch.empty(B, 2 * H, 2 * W, C, device=x.device, dtype=f32)
+    s = torch.empty(B, 2 * H, 2 * W, 2 * C, device=x.device, dtype=bf16) if pairs else torch.empty_like(y)
+    _lib.call("edm_f32_up2_silu", _p(x), _p(y), _p(s), B, 2 * H, 2 * W, C, int(bool(pairs)), _stream())
+    return y, s
 
 
 def f32_attention(qkv, heads):

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Everything the committed per-round profiles come from, in ONE gpurun call (run from the repo root on the GPU box):
-#   ROUND=r05 tools/refresh_profiles.sh  -> gpurun_out/r05_*; copy the summaries into profiles/ afterwards
+#   ROUND=r06 tools/refresh_profiles.sh  -> gpurun_out/r05_*; copy the summaries into profiles/ afterwards
 # Steps are joined so that a failed or timed-out GPU step stops the script.
 set -e
-RD=${ROUND:-r05}
+RD=${ROUND:-r06}
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 # under `rocprofv3 --pmc` the profiler initialises the GPU before python starts: the graph-safe runtime setting must be
