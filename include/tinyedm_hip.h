@@ -263,6 +263,19 @@ int edm_skip_gate_fwd(const void* skip, const float* W1h, const float* W2h, floa
 int edm_skip_gate_bwd(const void* gcat, long gcat_stride, int c_off, const void* skip, const float* mean,
                       const float* W1h, const float* W2h, const float* gate, const float* z1save, float* gmean,
                       float* gW1h, float* gW2h, float* ws, int B, int HW, int C, int R, edm_stream_t stream);
+/* round 6: gW1h == gW2h == NULL in edm_skip_gate_bwd skips its second launch (the batch sums of the weight gradients); the
+ * caller then runs it ONCE for all the gates of a backward pass (<= 32): items[k] = {ws, mean of gate k, gW1h, gW2h (written),
+ * B, C, R}.  Launch-table contract as edm_wgrad_finish_multi (table_host / table_dev / defer_upload). */
+typedef struct {
+  const float* ws;
+  const float* mean;
+  float* gW1h;
+  float* gW2h;
+  int B, C, R, pad;
+} edm_skip_gate_wgrad_item;
+long edm_skip_gate_wgrad_multi_table_bytes(void);
+int edm_skip_gate_wgrad_multi(const edm_skip_gate_wgrad_item* items, int n, void* table_host, void* table_dev,
+                              int defer_upload, edm_stream_t stream);
 /* cat = [inp, skip*gate] (networks.py:311) and backward */
 int edm_concat_gate_fwd(const void* inp, const void* skip, const float* gate, void* cat, void* silu_out, int B, int HW,
                         int Ci, int Cs, edm_stream_t stream);

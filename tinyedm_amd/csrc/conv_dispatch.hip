@@ -114,14 +114,21 @@ static int split_conv_impl(const void* Xp, const void* Wp3, float* Y, void* Ypai
     const int rc = edm_conv_igemm_v6_ex(Xp, Wp3, Y, R, alpha, beta, B, H, W, K, Cout, 9, mod, st);
     if (rc != EDM_ERR_UNSUPPORTED) return rc;
   }
-  // round 6: the small-map kernel for the 8x8-class 3x3 layers and the LDS-DMA 256x128 kernel for the 1x1 layers (both were
-  // on the register-staged 128x128 kernel: 9.4 % and 11.1 % of a split-bf16 solve).  EDM_SPLIT_FAST=0: the old dispatch (A/B)
-  static const bool fast = !(getenv("EDM_SPLIT_FAST") && getenv("EDM_SPLIT_FAST")[0] == '0');
+  // round 6: the small-map kernel for the 8x8-class 3x3 layers that are too small for the static-schedule kernel (batch 256:
+  // 82 vs 108 us per 256->256 layer; at batch 512 those layers give every CU a 512x64 tile and take the branch above).
+  // The LDS-DMA 256x128 kernel for the 1x1 layers (k_conv_igemm2, EPI 4) is built and parity-tested but NOT dispatched by
+  // default: in the solve it measured 5.33 vs 5.11 ms per evaluation for the 1x1 family (its fp32 epilogue with a residual
+  // is slower than the register-staged kernel's: profiles/r06_split_dispatch.txt).  EDM_SPLIT_V2=1 selects it (A/B runs);
+  // EDM_SPLIT_FAST=0: the round-5 dispatch.
+  // (read per call: tests switch them inside one process)
+  const char* const e_fast = getenv("EDM_SPLIT_FAST");
+  const char* const e_v2 = getenv("EDM_SPLIT_V2");
+  const bool fast = !(e_fast && e_fast[0] == '0'), v2 = e_v2 && e_v2[0] == '1';
   if (fast && taps == 9 && edm_conv_s_worthwhile(npix, W, K, Cout)) {
     const int rc = edm_conv_igemm_s_ex(Xp, Wp3, Y, R, alpha, beta, B, H, W, K, Cout, 9, mod, st);
     if (rc != EDM_ERR_UNSUPPORTED) return rc;
   }
-  if (fast && taps == 1 && ((npix + 255) / 256) * ((Cout + 127) / 128) >= 512)
+  if (v2 && taps == 1 && ((npix + 255) / 256) * ((Cout + 127) / 128) >= 512)
     return edm_conv_igemm_v2_ex(Xp, Wp3, Y, R, alpha, beta, B, H, W, K, Cout, 1, mod, st);
   return edm_conv_igemm_v1_ex(Xp, Wp3, Y, R, alpha, beta, B, H, W, K, Cout, taps, mod, st);
 }

@@ -873,15 +873,15 @@ __global__ __launch_bounds__(1024) void k_skip_gate_bwd(const bf16* __restrict__
 // The batch is walked in chunks of BC samples (what 64 KiB of LDS holds; one chunk up to B * (R + 4) = 16384), the
 // partial sums stay in registers across chunks, so any batch size works and the order of the sum (b ascending) does not
 // depend on the chunking.
-__global__ __launch_bounds__(256) void k_skip_gate_wgrad(const float* __restrict__ ws, const float* __restrict__ mean,
-                                                           float* __restrict__ gW1, float* __restrict__ gW2, int B, int C,
-                                                           int R, int CT, int BC) {
+__device__ __forceinline__ void skip_gate_wgrad_body(const float* __restrict__ ws, const float* __restrict__ mean,
+                                                     float* __restrict__ gW1, float* __restrict__ gW2, int B, int C, int R,
+                                                     int CT, int BC, int blk) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // A[BC][4] | Bm[BC][R]
   float* A = sm;
   float* Bm = sm + 4 * BC;
   const int W = C + 2 * R;
-  const bool second = blockIdx.x >= CT;
-  const int c0 = (second ? blockIdx.x - CT : blockIdx.x) * 4;
+  const bool second = blk >= CT;
+  const int c0 = (second ? blk - CT : blk) * 4;
   const int ncol = second ? C + 1 : C;
   const int boff = second ? C : C + R;     // Bm = dz1 (gW1) or h (gW2)
   constexpr int MAXO = 16;                 // 4 * R / 256 outputs per thread, R <= 1024
@@ -920,6 +920,35 @@ __global__ __launch_bounds__(256) void k_skip_gate_wgrad(const float* __restrict
     else gW2[(long)(c0 + cc) * R + r] = acc[k];
   }
 }
+__global__ __launch_bounds__(256) void k_skip_gate_wgrad(const float* __restrict__ ws, const float* __restrict__ mean,
+                                                           float* __restrict__ gW1, float* __restrict__ gW2, int B, int C,
+                                                           int R, int CT, int BC) {
+  skip_gate_wgrad_body(ws, mean, gW1, gW2, B, C, R, CT, BC, blockIdx.x);
+}
+// Round 6: the batch sums of ALL the ScaleLong gates of a backward pass in ONE launch behind it (nine launches of 129
+// workgroups each in the CIFAR-10 step, every one a kernel boundary on the backward's critical chain).  The table lives in
+// device memory (common.h "launch tables"); blk0 = first workgroup of a layer.
+constexpr int MAXSG = 32;
+struct SgItem {
+  const float* ws;
+  const float* mean;
+  float* gW1;
+  float* gW2;
+  int B, C, R, blk0;
+};
+struct SgGroup {
+  SgItem it[MAXSG];
+  int n, pad[3];
+};
+__global__ __launch_bounds__(256) void k_skip_gate_wgrad_multi(const SgGroup* __restrict__ g) {
+  int k = 0;
+  const int n = g->n;
+  while (k + 1 < n && (int)blockIdx.x >= g->it[k + 1].blk0) ++k;
+  const SgItem it = g->it[k];
+  const int CT = (it.C + 3) / 4;
+  const int BC = it.B < 16384 / (it.R + 4) ? it.B : 16384 / (it.R + 4);
+  skip_gate_wgrad_body(it.ws, it.mean, it.gW1, it.gW2, it.B, it.C, it.R, CT, BC, (int)blockIdx.x - it.blk0);
+}
 static inline int skip_gate_threads(int C) {   // a multiple of the C/8 lanes of a pixel row, <= 1024
   const int lpr = C / 8;
   int t = 1024 / lpr * lpr;
@@ -944,7 +973,7 @@ extern "C" int edm_skip_gate_fwd(const void* skip, const float* W1h, const float
 extern "C" int edm_skip_gate_bwd(const void* gcat, long gcat_stride, int c_off, const void* skip, const float* mean,
                                  const float* W1h, const float* W2h, const float* gate, const float* z1save, float* gmean,
                                  float* gW1h, float* gW2h, float* ws, int B, int HW, int C, int R, hipStream_t st) {
-  EDM_REQUIRE(gcat && skip && mean && W1h && W2h && gate && z1save && gmean && gW1h && gW2h && ws, "skip_gate_bwd: null pointer");
+  EDM_REQUIRE(gcat && skip && mean && W1h && W2h && gate && z1save && gmean && ws && (!gW1h == !gW2h), "skip_gate_bwd: null pointer");
   EDM_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 8 == 0 && C <= 4096 && R > 0 && R <= 1024 && c_off >= 0 && c_off % 8 == 0 &&
                   gcat_stride >= c_off + C && gcat_stride % 8 == 0, "skip_gate_bwd: bad args");
   const int threads = skip_gate_threads(C);
@@ -952,11 +981,48 @@ extern "C" int edm_skip_gate_bwd(const void* gcat, long gcat_stride, int c_off, 
   const size_t lds = ((size_t)(threads / (C / 8)) * C + C + R) * sizeof(float);
   hipLaunchKernelGGL(k_skip_gate_bwd, dim3(B), dim3(threads), lds, st, (const bf16*)gcat + c_off, gcat_stride,
                      (const bf16*)skip, W1h, W2h, gate, z1save, gmean, ws, HW, C, R);
-  const int CT = (C + 3) / 4, CT1 = (C + 4) / 4;
-  const int BC = B < 16384 / (R + 4) ? B : 16384 / (R + 4);      // samples per LDS chunk (64 KiB); R <= 1024 -> BC >= 15
-  const size_t lds2 = ((size_t)4 * BC + (size_t)BC * R) * sizeof(float);
-  hipLaunchKernelGGL(k_skip_gate_wgrad, dim3(CT + CT1), dim3(256), lds2, st, ws, mean, gW1h, gW2h, B, C, R, CT, BC);
+  if (gW1h) {   // (NULL, NULL: the caller sums the weight gradients of several gates later, edm_skip_gate_wgrad_multi)
+    const int CT = (C + 3) / 4, CT1 = (C + 4) / 4;
+    const int BC = B < 16384 / (R + 4) ? B : 16384 / (R + 4);      // samples per LDS chunk (64 KiB); R <= 1024 -> BC >= 15
+    const size_t lds2 = ((size_t)4 * BC + (size_t)BC * R) * sizeof(float);
+    hipLaunchKernelGGL(k_skip_gate_wgrad, dim3(CT + CT1), dim3(256), lds2, st, ws, mean, gW1h, gW2h, B, C, R, CT, BC);
+  }
   EDM_CHECK_LAUNCH("skip_gate_bwd");
+  return EDM_OK;
+}
+
+struct edm_skip_gate_wgrad_item_ {   // = edm_skip_gate_wgrad_item (include/tinyedm_hip.h)
+  const float* ws;
+  const float* mean;
+  float* gW1h;
+  float* gW2h;
+  int B, C, R, pad;
+};
+extern "C" long edm_skip_gate_wgrad_multi_table_bytes(void) { return (long)sizeof(SgGroup); }
+// the second launch of edm_skip_gate_bwd for up to 32 gates at once: items[k] = {ws, mean of gate k's forward, gW1h [R][C+1],
+// gW2h [C][R] (WRITTEN), B, C, R}; `items` is host memory read during the call, the table goes to device memory
+extern "C" int edm_skip_gate_wgrad_multi(const void* items_, int n, void* table_host, void* table_dev, int defer_upload,
+                                         hipStream_t st) {
+  const edm_skip_gate_wgrad_item_* items = (const edm_skip_gate_wgrad_item_*)items_;
+  EDM_REQUIRE(items && n > 0 && n <= MAXSG, "skip_gate_wgrad_multi: need 1..%d gates, got %d", MAXSG, n);
+  SgGroup g;
+  g.n = n;
+  int blk = 0;
+  size_t lds = 0;
+  for (int k = 0; k < n; ++k) {
+    const edm_skip_gate_wgrad_item_& a = items[k];
+    EDM_REQUIRE(a.ws && a.mean && a.gW1h && a.gW2h && a.B > 0 && a.C > 0 && a.C % 8 == 0 && a.C <= 4096 && a.R > 0 && a.R <= 1024,
+                "skip_gate_wgrad_multi: bad item %d", k);
+    g.it[k] = SgItem{a.ws, a.mean, a.gW1h, a.gW2h, a.B, a.C, a.R, blk};
+    blk += (a.C + 3) / 4 + (a.C + 4) / 4;
+    const int BC = a.B < 16384 / (a.R + 4) ? a.B : 16384 / (a.R + 4);
+    const size_t need = ((size_t)4 * BC + (size_t)BC * a.R) * sizeof(float);
+    if (need > lds) lds = need;
+  }
+  EDM_MAX_LDS(k_skip_gate_wgrad_multi, 128 * 1024);
+  EDM_UPLOAD_TABLE(table_dev, table_host, &g, sizeof(SgGroup), st, "skip_gate_wgrad_multi", defer_upload);
+  hipLaunchKernelGGL(k_skip_gate_wgrad_multi, dim3(blk), dim3(256), lds, st, (const SgGroup*)table_dev);
+  EDM_CHECK_LAUNCH("skip_gate_wgrad_multi");
   return EDM_OK;
 }
 

@@ -163,6 +163,11 @@ FIN_GROUP = 40              # small weight gradients per multi-tensor finish lau
 W1_GROUP = max(0, min(16, int(os.environ.get("EDM_W1_GROUP", "16"))))
 _w1_pending = {}            # device index -> [(mod, x, dy, scale)] 1x1 layers waiting for their grouped launch
 _bwd_end_queued = set()     # devices whose end-of-backward callback is queued for the running backward pass
+# ScaleLong gates: the batch sums that form the gate MLPs' weight gradients (the second launch of ops.skip_gate_bwd), for ALL
+# the gates of a backward pass in ONE launch behind it (round 6: nine launches less on the backward's chain); their finish
+# rides in the last multi-tensor finish.  Arena mode only; EDM_SG_DEFER=0: per gate, as round 5.
+SG_DEFER = os.environ.get("EDM_SG_DEFER", "1") != "0"
+_sg_pending = {}            # device index -> [(ScaleLong module, ws, mean, R)]
 _w3_pending = {}            # device index -> [(mod, x, dy, scale)] 3x3 layers waiting for their grouped launch
 _fin_pending = {}           # device index -> [(slabs, w, perm, taps, I, scale)] small weight gradients to finish
 
@@ -229,12 +234,25 @@ def _flush_fin(key):
             hook(w)
 
 
+def _flush_sg(key):
+    """the pending ScaleLong gates of device `key`: one launch for their weight-gradient batch sums; the projection through
+    the weight normalisation joins the multi-tensor finish queue"""
+    items = _sg_pending.pop(key, None)
+    if not items:
+        return
+    outs = ops.skip_gate_wgrad_multi([(ws, mean, R) for _, ws, mean, R in items])
+    for (sl, _, _, _), (gw1h, gw2h) in zip(items, outs):
+        sl.layer1.finish_grad(gw1h.view(1, 1, *gw1h.shape))
+        sl.layer2.finish_grad(gw2h.view(1, 1, *gw2h.shape))
+
+
 def _backward_end(key):
     """End of a backward pass on device `key`: flush the last partial group, then make the stream that ran the
     backward wait for the auxiliary stream (the optimizer reads what the weight-gradient kernels wrote)."""
     _bwd_end_queued.discard(key)
     if key in _w3_seen:
         _w3_total[key] = _w3_seen.pop(key)
+    _flush_sg(key)
     _flush_w3(key)
     _flush_fin(key)
     if WGRAD_STREAM:
@@ -255,8 +273,12 @@ def _queue_backward_end(device):
 def reset_backward_state():
     """Forget deferred work of a backward pass that did not complete (an exception inside autograd leaves its
     end-of-backward callback unrun).  Called at the start of every Denoiser forward."""
-    if _bwd_end_queued or _w3_pending or _fin_pending or _w1_pending:
+    if _bwd_end_queued or _w3_pending or _fin_pending or _w1_pending or _sg_pending:
         _bwd_end_queued.clear()
+        for items in _sg_pending.values():
+            for sl, *_rest in items:
+                sl.layer1.weight._edm_deferred = sl.layer2.weight._edm_deferred = False
+        _sg_pending.clear()
         for items in _w1_pending.values():
             for m, _, _, _ in items:
                 m.weight._edm_deferred = False
@@ -592,6 +614,9 @@ class ScaleLong(nn.Module):
         self.layer2 = Conv2d(int(dim // r), dim, 1)
         self.layer1._want = ("hat",)
         self.layer2._want = ("hat",)
+        if SG_DEFER:    # their gradients are written by ONE launch behind the backward pass (_flush_sg): late parameters
+            self.layer1.weight._edm_late = True         # of the flat arena (ema.FlatArena layout 3)
+            self.layer2.weight._edm_late = True
 
     def forward(self, inp: Tensor) -> Tensor:
         """NCHW in -> gate (B,C,1,1), as the reference module."""
@@ -1042,15 +1067,23 @@ class _ResBlockFn(torch.autograd.Function):
         if ctx.has_skip:
             skip, mean, gate, z1, w1h, w2h = ctx.skip_saved
             Ci = ctx.Ci
+            sl = blk.cat_factor
+            wsl = (sl.layer1.weight, sl.layer2.weight)
+            defer = SG_DEFER and all(w.grad is not None and getattr(w, "_edm_direct", False) for w in wsl)
             if gcs is None:             # (no split form for this shape: the skip half is read out of gcat in place)
-                gmean, gw1h, gw2h = ops.skip_gate_bwd(gu, Ci, skip, mean, w1h, w2h, gate, z1)
+                gmean, *gws = ops.skip_gate_bwd(gu, Ci, skip, mean, w1h, w2h, gate, z1, defer_wgrad=defer)
                 gu, gskip = ops.concat_gate_bwd(gu, gate, gmean, Ci)
             else:
-                gmean, gw1h, gw2h = ops.skip_gate_bwd(gcs, 0, skip, mean, w1h, w2h, gate, z1)
+                gmean, *gws = ops.skip_gate_bwd(gcs, 0, skip, mean, w1h, w2h, gate, z1, defer_wgrad=defer)
                 gskip = ops.skip_half_bwd(gcs, gate, gmean)
-            sl = blk.cat_factor
-            gwsl1 = sl.layer1.finish_grad(gw1h.view(1, 1, *gw1h.shape))
-            gwsl2 = sl.layer2.finish_grad(gw2h.view(1, 1, *gw2h.shape))
+            if defer:       # the batch sums of every gate's weight gradients: one launch at the end of the pass (_flush_sg)
+                _sg_pending.setdefault(wsl[0].device.index, []).append((sl, gws[0], mean, w1h.shape[0]))
+                wsl[0]._edm_deferred = wsl[1]._edm_deferred = True
+                _queue_backward_end(wsl[0].device)
+            else:
+                gw1h, gw2h = gws
+                gwsl1 = sl.layer1.finish_grad(gw1h.view(1, 1, *gw1h.shape))
+                gwsl2 = sl.layer2.finish_grad(gw2h.view(1, 1, *gw2h.shape))
         if g_alias is not None:         # decoder blocks are never asked for an alias; kept for completeness
             gu = ops.axpby(gu, 1.0, g_alias, 1.0)
         return (gu, gemb, gw11, gw1, gw2, gwemb, ggain, None, None, None, gtoken, None, None, None, gskip, gwsl1, gwsl2,

@@ -163,7 +163,7 @@ class _LaunchTables:
                                    "created under stream capture (pinned + device allocations): run one eager step first, "
                                    "or bracket the capture with ops.capture_begin() / capture_end()")
             nb = max(int(_lib.call("edm_wgrad3_table_bytes")), int(_lib.call("edm_conv_wgrad_1x1_group_table_bytes")),
-                     int(_lib.call("edm_wgrad_finish_multi_table_bytes")))
+                     int(_lib.call("edm_wgrad_finish_multi_table_bytes")), int(_lib.call("edm_skip_gate_wgrad_multi_table_bytes")))
             nb = (nb + 255) // 256 * 256
             d = torch.device("cuda", key)
             st = self.dev[key] = {
@@ -534,9 +534,10 @@ def skip_gate_fwd(skip, w1h, w2h):
     return mean, gate, z1
 
 
-def skip_gate_bwd(gcat, Ci, skip, mean, w1h, w2h, gate, z1):
+def skip_gate_bwd(gcat, Ci, skip, mean, w1h, w2h, gate, z1, defer_wgrad=False):
     """backward of skip_gate_fwd given the gradient of cat = [inp, skip*gate]: (gmean, gw1h, gw2h) == reduce_hw(gcat[...,
-    Ci:] * skip) followed by scalelong_bwd."""
+    Ci:] * skip) followed by scalelong_bwd.  defer_wgrad=True: -> (gmean, ws): the batch sums that form gw1h / gw2h are left
+    to ONE skip_gate_wgrad_multi over every gate of the backward pass (ws = this gate's per-sample vectors)."""
     B, H, W, Ct = _nhwc(gcat, "gcat")
     Bs, Hs, Ws, C = _nhwc(skip, "skip")
     if (Bs, Hs, Ws) != (B, H, W) or Ci + C != Ct or Ci % 8:
@@ -548,12 +549,34 @@ def skip_gate_bwd(gcat, Ci, skip, mean, w1h, w2h, gate, z1):
     _chk(w1h, f32, "w1h", (R, C + 1))
     _chk(w2h, f32, "w2h", (C, R))
     gmean = torch.empty(B, C, device=skip.device, dtype=f32)
-    gw1 = torch.empty(w1h.shape, device=w1h.device, dtype=f32)
-    gw2 = torch.empty(w2h.shape, device=w2h.device, dtype=f32)
+    gw1 = None if defer_wgrad else torch.empty(w1h.shape, device=w1h.device, dtype=f32)
+    gw2 = None if defer_wgrad else torch.empty(w2h.shape, device=w2h.device, dtype=f32)
     ws = torch.empty(B, C + 2 * R, device=skip.device, dtype=f32)
     _lib.call("edm_skip_gate_bwd", _p(gcat), Ct, Ci, _p(skip), _p(mean), _p(w1h), _p(w2h), _p(gate), _p(z1), _p(gmean),
               _p(gw1), _p(gw2), _p(ws), B, H * W, C, R, _stream())
-    return gmean, gw1, gw2
+    return (gmean, ws) if defer_wgrad else (gmean, gw1, gw2)
+
+
+def skip_gate_wgrad_multi(items):
+    """items: sequence (<= 32) of (ws, mean, R) from skip_gate_bwd(defer_wgrad=True) and the gate's forward -> list of
+    (gw1h (R, C+1), gw2h (C, R)), all from ONE launch"""
+    n = len(items)
+    if not 0 < n <= 32:
+        raise ValueError("skip_gate_wgrad_multi: 1..32 gates per launch")
+    arr = (_lib.SkipGateWgradItem * n)()
+    out = []
+    for k, (ws, mean, R) in enumerate(items):
+        _chk(mean, f32, "mean")
+        B, C = mean.shape
+        _chk(ws, f32, "ws", (B, C + 2 * R))
+        gw1 = torch.empty(R, C + 1, device=ws.device, dtype=f32)
+        gw2 = torch.empty(C, R, device=ws.device, dtype=f32)
+        arr[k] = _lib.SkipGateWgradItem(ws.data_ptr(), mean.data_ptr(), gw1.data_ptr(), gw2.data_ptr(), B, C, R, 0)
+        out.append((gw1, gw2))
+    th, td, defer, release = _tables.take(items[0][0].device)
+    _lib.call("edm_skip_gate_wgrad_multi", ctypes.byref(arr), n, ctypes.c_void_p(th), ctypes.c_void_p(td), defer, _stream())
+    release()
+    return out
 
 
 def concat_gate_fwd(inp, skip, gate, want_silu):
