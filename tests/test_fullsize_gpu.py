@@ -367,9 +367,10 @@ def test_standalone_module_call_after_a_fragment_major_forward():
 
 
 def test_resample_fusions_leave_the_cifar10_step_unchanged():
-    """FUSE_RESAMPLE (round 6; the CIFAR-10 net has two EncD blocks without a 1x1 conv and two DecU blocks): the evaluation
+    """FUSE_RESAMPLE (round 6; the CIFAR-10 net has two EncD blocks without a 1x1 conv and two DecU blocks) and the
+    producer-written mp_silu of the decoder blocks without a skip (Denoiser._silu_dest, rides on FUSE_CAT): the evaluation
     forward bit for bit, the training loss and every parameter gradient up to the order of the fp32 atomics both
-    paths share -- against the round-5 sequence with the standalone pool / upsample / mp_silu kernels."""
+    paths share -- against the sequences with the standalone pool / upsample / mp_silu / concat kernels."""
     import tinyedm_amd as T
     from tinyedm_amd import networks as N
     from tinyedm_amd.ema import FusedAdam
@@ -379,10 +380,11 @@ def test_resample_fusions_leave_the_cifar10_step_unchanged():
     x = (0.5 * torch.randn(8, 3, 32, 32, generator=g)).to(DEV)
     sigma = torch.randn(8, generator=g).exp().to(DEV)
     res = {}
-    old = N.FUSE_RESAMPLE
+    old = (N.FUSE_RESAMPLE, N.FUSE_CAT)
+    modes = [(False, True), (True, True), (True, False)]
     try:
-        for mode in (False, True):
-            N.FUSE_RESAMPLE = mode
+        for mode in modes:
+            N.FUSE_RESAMPLE, N.FUSE_CAT = mode
             N._rng_sub_counter[0] = 0           # the same dropout sub-streams for both models
             model, den = _cifar_model(T, seed=4)
             opt = FusedAdam(model.parameters(), lr=1e-3)
@@ -397,8 +399,10 @@ def test_resample_fusions_leave_the_cifar10_step_unchanged():
             torch.cuda.synchronize()
             res[mode] = (D, float(loss), opt.arena.grad.clone())
     finally:
-        N.FUSE_RESAMPLE = old
-    assert torch.equal(res[True][0], res[False][0])
-    assert abs(res[True][1] - res[False][1]) <= 1e-6 * abs(res[False][1])      # (the loss is a sum of fp32 atomics)
-    e = rel(res[True][2], res[False][2])
-    assert e <= 1e-5, e
+        N.FUSE_RESAMPLE, N.FUSE_CAT = old
+    ref = res[modes[0]]
+    for mode in modes[1:]:
+        assert torch.equal(res[mode][0], ref[0]), mode
+        assert abs(res[mode][1] - ref[1]) <= 1e-6 * abs(ref[1]), mode      # (the loss is a sum of fp32 atomics)
+        e = rel(res[mode][2], ref[2])
+        assert e <= 1e-5, (mode, e)

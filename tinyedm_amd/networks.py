@@ -1239,16 +1239,16 @@ class EncoderBlock(_BlockBase):
         self.conv_3x3_1 = Conv2d(out_channels, out_channels, 3)
         self._common(out_channels, embedding_dim, attention, num_heads, dropout_rate)
 
-    def forward(self, input: Tensor, embedding: Tensor, _lin=None, _alias: bool = False):
+    def forward(self, input: Tensor, embedding: Tensor, _lin=None, _alias: bool = False, _dest=None):
         """_alias=True (Denoiser only, NHWC input): returns (out, alias of the input): the tensor the U-Net skip should
-        be taken from, so that the skip gradient is summed inside this block's backward kernels."""
+        be taken from, so that the skip gradient is summed inside this block's backward kernels.  _dest: see Denoiser._silu_dest"""
         x, conv = _as_nhwc(input)
         ualias = None
         emb = None if _lin is not None else _emb32(embedding, x.shape[0])
         if (isinstance(self.resample, DownSample) and FUSE_RESAMPLE and not isinstance(self.conv_1x1, Conv2d)
                 and x.shape[-1] <= 1024 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0):
             # the pool rides in the block's pixel-norm kernels (forward and backward); the alias is the tensor before it
-            out = self._res(x, emb, _lin, alias=_alias, pool=True)
+            out = self._res(x, emb, _lin, alias=_alias, pool=True, dest=_dest)
             if _alias:
                 out, ualias = out
         else:
@@ -1258,10 +1258,16 @@ class EncoderBlock(_BlockBase):
                 else:
                     x = _ResampleFn.apply(x, False)
             if _alias and ualias is None:
-                out, ualias = self._res(x, emb, _lin, alias=True)
+                out, ualias = self._res(x, emb, _lin, alias=True, dest=_dest)
             else:
-                out = self._res(x, emb, _lin)
-        out = ops.nhwc_bf16_to_nchw(out).to(input.dtype) if conv else _tag(out)
+                out = self._res(x, emb, _lin, dest=_dest)
+        if conv:
+            out = ops.nhwc_bf16_to_nchw(out).to(input.dtype)
+        else:
+            cat_pre = getattr(out, "_edm_cat", None)
+            out = _tag(out)
+            if cat_pre is not None:
+                out._edm_cat = cat_pre
         return (out, _tag(ualias)) if _alias else out
 
     def forward_f32(self, x: Tensor, lin: Tensor, want=None):
@@ -1313,6 +1319,10 @@ class DecoderBlock(_BlockBase):
                                     fuse_silu)
             if fuse_silu:
                 x, s_pre = x
+        if skip is None and not isinstance(self.resample, UpSample):
+            pre = getattr(x, "_edm_cat", None)       # (out, mp_silu(out)) written by the producer of x: Denoiser._silu_dest
+            if pre is not None and pre[0].data_ptr() == x.data_ptr() and pre[0].shape == x.shape:
+                s_pre = pre[1]
         if isinstance(self.resample, UpSample):
             if FUSE_RESAMPLE:
                 x, s_pre = _ResampleFn.apply(x, True, False, True)      # mp_silu of the upsampled tensor from the same pass
@@ -1595,6 +1605,20 @@ class Denoiser(nn.Module):
             cached = self._modfin = (key, torch.from_numpy(rec.view(np.uint8).copy()).to(gains[0].device))
         return cached[1]
 
+    @staticmethod
+    def _silu_dest(block, nxt, x, up, down=False):
+        """(out, sil) buffers for `block`'s output when its consumer `nxt` is a decoder block WITHOUT a skip, an upsample or
+        a 1x1 conv in front of its first 3x3 conv: that conv reads mp_silu(input) (networks.py:313-316), which the producer's
+        last kernel writes beside the output (mode 3 of the conv epilogue) instead of a k_silu_fwd launch (round 6)"""
+        if not FUSE_CAT or isinstance(nxt.resample, UpSample) or nxt.cat_factor is not None:
+            return None
+        Bx, Hx, Wx, _ = x.shape
+        if down:
+            Hx, Wx = Hx // 2, Wx // 2
+        Co = block.conv_3x3_2.weight.shape[0]
+        return (torch.empty(Bx, Hx * up, Wx * up, Co, device=x.device, dtype=bf16),
+                torch.empty(Bx, Hx * up, Wx * up, Co, device=x.device, dtype=bf16))
+
     def _frag_flags(self, B: int, H: int, W: int):
         """{conv module: (forward pack, dgrad pack) fragment-major?} for an input of this shape: the 3x3 convs that the
         default dispatch runs on k_conv3x3_s (the 8x8 layers at batch 128) get packs in the layout that kernel loads with
@@ -1795,13 +1819,17 @@ class Denoiser(nn.Module):
 
         x = _ConvInFn.apply(noisy, sig, self.conv_in.weight, self)
         skips = []
-        for block in self.encoder_blocks:
+        dec = list(zip(self.decoder_blocks, self.skip_connections))
+        enc = list(self.encoder_blocks)
+        for k, block in enumerate(enc):
             # the skip is taken from the block's alias of its own input: the decoder's skip gradient then lands in the
             # block's backward and is summed by a kernel that runs anyway, not by an autograd add
-            x, x_in = block(_tag(x), None, _lin=lins[block], _alias=True)
+            dest = None
+            if k + 1 == len(enc) and dec and not dec[0][1]:     # the last encoder output feeds a decoder block without a skip
+                dest = self._silu_dest(block, dec[0][0], x, 1, down=isinstance(block.resample, DownSample))
+            x, x_in = block(_tag(x), None, _lin=lins[block], _alias=True, _dest=dest)
             skips.append(x_in)
         skips.append(x)
-        dec = list(zip(self.decoder_blocks, self.skip_connections))
         for i, (block, has_skip) in enumerate(dec):
             skip = skips.pop() if has_skip else None
             dest = None
@@ -1815,6 +1843,8 @@ class Denoiser(nn.Module):
                     Ct = block.conv_3x3_2.weight.shape[0] + skips[-1].shape[-1]
                     dest = (torch.empty(Bx, Hx * up, Wx * up, Ct, device=x.device, dtype=bf16),
                             torch.empty(Bx, Hx * up, Wx * up, Ct, device=x.device, dtype=bf16))
+            elif i + 1 < len(dec):
+                dest = self._silu_dest(block, dec[i + 1][0], x, 2 if isinstance(block.resample, UpSample) else 1)
             xin = _tag(x)
             cat_pre = getattr(x, "_edm_cat", None)
             if cat_pre is not None:
