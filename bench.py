@@ -610,12 +610,18 @@ def main():
                 # training image) over 8 TB/s; 70 % of it would need 7 PFLOP/s of bf16 MFMA (not reachable)
                 "northstar_hbm3x3_frac": round(ips / world * 59.7e6 / 1e9 / HBM_PEAK_GBS, 4),
                 # the other chip-filling MFMA kernel of the step: the grouped stream-K weight gradient (conv_wgrad3.hip)
-                "wgrad3": (lambda w: {"kernel": f"k_wgrad3<1> (3x3 weight gradients, {w['launches']} grouped launches per step)",
-                                      "achieved": round(w["gflop"] / w["ms"], 2) if w["ms"] else 0.0,
-                                      "frac": round(w["gflop"] / w["ms"] / MFMA_PEAK_TFLOPS, 4) if w["ms"] else 0.0,
-                                      "avg_launch_ms": round(w["ms"] / max(1, w["launches"]), 4),
-                                      "algorithmic_gbytes_per_launch": round(w["gbytes"] / max(1, w["launches"]), 4),
-                                      "traffic": pmc_traffic("k_wgrad3")})(
+                # avg_launch_ms / achieved / frac: the k_wgrad3 LAUNCH alone (events recorded inside the grouped entry point,
+                # include/tinyedm_hip_diag.h edm_wgrad3_probe) -- what the rocprofv3 traces in profiles/ show for the kernel;
+                # call_ms: the whole edm_wgrad3_group call (launch-table upload + k_wgrad3 + k_wgrad3_finish), the figure
+                # rounds 2-5 reported as the kernel's
+                "wgrad3": (lambda w, c: {"kernel": f"k_wgrad3<1> (3x3 weight gradients, {w['launches']} grouped launches per step)",
+                                         "achieved": round(w["gflop"] / w["ms"], 2) if w["ms"] else 0.0,
+                                         "frac": round(w["gflop"] / w["ms"] / MFMA_PEAK_TFLOPS, 4) if w["ms"] else 0.0,
+                                         "avg_launch_ms": round(w["ms"] / max(1, w["launches"]), 4),
+                                         "call_ms_incl_table_upload_and_finish": round(c["ms"] / max(1, c["launches"]), 4),
+                                         "algorithmic_gbytes_per_launch": round(w["gbytes"] / max(1, w["launches"]), 4),
+                                         "traffic": pmc_traffic("k_wgrad3")})(
+                    roof.get("conv3x3_wgrad_kernel", roof.get("conv3x3_wgrad", {"launches": 0, "ms": 0.0, "gflop": 0.0, "gbytes": 0.0})),
                     roof.get("conv3x3_wgrad", {"launches": 0, "ms": 0.0, "gflop": 0.0, "gbytes": 0.0})),
                 "per_kernel": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in roof.items()},
             },

@@ -15,6 +15,10 @@ int edm_conv_igemm_v2_stamp(const void* X, const void* Wp, void* Y, int B, int H
 int edm_conv_igemm_v2_ablate(const void* X, const void* Wp, void* Y, int B, int H, int W, int Cin, int Cout, int mode,
                              edm_stream_t stream);
 
+/* measurement : the next edm_wgrad3_group call of this thread records the two HIP events (hipEvent_t handles) around its
+ * k_wgrad3 launch ONLY -- not around the launch-table upload before it and k_wgrad3_finish behind it.  One-shot. */
+int edm_wgrad3_probe(void* ev_start, void* ev_end);
+
 #ifdef __cplusplus
 }
 #endif

@@ -130,6 +130,7 @@ SIGNATURES = {
 DIAG_SIGNATURES = {
     "edm_conv_igemm_v2_stamp": [P, P, P, I, I, I, I, I, P, P],
     "edm_conv_igemm_v2_ablate": [P, P, P, I, I, I, I, I, I, P],
+    "edm_wgrad3_probe": [P, P],
 }
 _RET = {"edm_last_error": ctypes.c_char_p, "edm_wgrad3_workspace": ctypes.c_long, "edm_wgrad3_table_bytes": ctypes.c_long,
         "edm_skip_gate_wgrad_multi_table_bytes": ctypes.c_long,

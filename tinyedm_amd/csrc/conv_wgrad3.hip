@@ -655,6 +655,17 @@ extern "C" long edm_wgrad3_workspace(const edm_wgrad3_item* items, int n) {
 // during the call only); workspace is device memory of at least edm_wgrad3_workspace(items, n) bytes.
 extern "C" long edm_wgrad3_table_bytes(void) { return (long)(sizeof(W3Group) + sizeof(F3Group)); }
 
+// Measurement hook (bench.py's roofline leg; include/tinyedm_hip_diag.h): the NEXT edm_wgrad3_group call of this thread
+// records `ev_start` right before and `ev_end` right behind its k_wgrad3 launch -- the grouped entry point also uploads its
+// launch table and runs k_wgrad3_finish, so a pair of events around the CALL times three things (round 5: 888 us per call
+// against 813-831 us for the kernel in the rocprofv3 traces).  One-shot: cleared by that call.
+static thread_local hipEvent_t g_probe_start = nullptr, g_probe_end = nullptr;
+extern "C" int edm_wgrad3_probe(void* ev_start, void* ev_end) {
+  g_probe_start = (hipEvent_t)ev_start;
+  g_probe_end = (hipEvent_t)ev_end;
+  return EDM_OK;
+}
+
 extern "C" int edm_wgrad3_group(const edm_wgrad3_item* items, int n, void* workspace, long workspace_bytes,
                                 void* table_host, void* table_dev, int defer_upload, hipStream_t st) {
   Plan P;
@@ -679,6 +690,7 @@ extern "C" int edm_wgrad3_group(const edm_wgrad3_item* items, int n, void* works
   const F3Group* const fgp = (const F3Group*)((const char*)table_dev + sizeof(W3Group));
   static std::atomic<unsigned long long> set1{0}, set2{0};   // (a bit per device: common.h edm_max_lds_once)
   static const int abl = [] { const char* e = getenv("EDM_W3_ABLATE"); return e ? atoi(e) : 0; }();   // tools only
+  if (g_probe_start) (void)hipEventRecord(g_probe_start, st);
   if (P.leads == 1 && abl) {
     auto go = [&](auto kern) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -711,6 +723,8 @@ extern "C" int edm_wgrad3_group(const edm_wgrad3_item* items, int n, void* works
     if (P.leads == 1) { if (mf16) go(k_wgrad3<1, 0, true>, Ring<1>::LDS, set1m); else go(k_wgrad3<1>, Ring<1>::LDS, set1); }
     else { if (mf16) go(k_wgrad3<2, 0, true>, Ring<2>::LDS, set2m); else go(k_wgrad3<2>, Ring<2>::LDS, set2); }
   }
+  if (g_probe_end) (void)hipEventRecord(g_probe_end, st);
+  g_probe_start = g_probe_end = nullptr;
   EDM_CHECK_LAUNCH("wgrad3");
   EDM_MAX_LDS(k_wgrad3_finish, 64 * 1024);
   hipLaunchKernelGGL(k_wgrad3_finish, dim3(P.rows_total), dim3(256), (size_t)P.max_n * 4, st, fgp);

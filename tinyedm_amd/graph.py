@@ -71,7 +71,12 @@ class CapturedTrainStep:
     WARMUP = 2
     MAX_GRAPHS = 4      # captured batch shapes kept (least recently used beyond that are released)
 
-    def __init__(self, model, optimizer, grad_scale: float = 1.0, reducer=None):
+    def __init__(self, model, optimizer, grad_scale: float = 1.0, reducer=None, wgrad_fork=None):
+        # wgrad_fork: keep the weight-gradient side stream (networks.WGRAD_STREAM) as a BRANCH of the captured graph.  None:
+        # EDM_GRAPH_FORK (default off: the CIFAR-10 step replays 2.6 % slower with the branch; the 272 M ImageNet net is the
+        # other way round -- round 6 measurements in DESIGN 6).
+        import os
+        self.wgrad_fork = (os.environ.get("EDM_GRAPH_FORK", "0") == "1") if wgrad_fork is None else bool(wgrad_fork)
         self.model = model
         self.opt = optimizer
         self.base = optimizer.optimizer if isinstance(optimizer, EMAOptimizer) else optimizer
@@ -129,7 +134,7 @@ class CapturedTrainStep:
         snap = self._snapshot()
         cur = torch.cuda.current_stream()
         self.stream.wait_stream(cur)
-        side, networks.WGRAD_STREAM = networks.WGRAD_STREAM, False     # one chain, like the capture that follows
+        side, networks.WGRAD_STREAM = networks.WGRAD_STREAM, self.wgrad_fork   # the launch structure of the capture that follows
         try:
             with torch.cuda.stream(self.stream):
                 loss = self.model.training_step(batch, 0)
@@ -226,7 +231,7 @@ class CapturedTrainStep:
         graph = torch.cuda.CUDAGraph()
         # the step is captured as ONE chain: a weight-gradient side branch replays slower than the chain (CIFAR-10:
         # 15.5 vs 15.1 ms) -- hipGraph schedules the branch less favourably than the host's enqueue order does
-        side, networks.WGRAD_STREAM = networks.WGRAD_STREAM, False
+        side, networks.WGRAD_STREAM = networks.WGRAD_STREAM, self.wgrad_fork
         try:
             with torch.cuda.graph(graph, stream=self.stream, capture_error_mode=mode):
                 loss = self.model.training_step((sx, sy), 0)
