@@ -445,7 +445,13 @@ int edm_conv_igemm_v6_ex(const void* X, const void* Wp, void* Y, const void* R, 
   const bool nx5 = xrows <= 5 * 128 - 49;
   if (!nx5 && xrows > 6 * 128 - 49) return EDM_ERR_UNSUPPORTED;
   const long tiles4 = (long)((Npix + BM - 1) / BM) * ((Cout + 127) / 128);
-  const bool wide = tiles4 >= 512;
+  // 128-channel tiles when they fill the chip -- unless they would mostly multiply padding: Cout = 192 (the 64x64 layers of
+  // the default ImageNet Denoiser) is 1.5 tiles of 128 but 3 of 64, and the 64-channel form's lower matrix-pipe occupancy
+  // (69 % against 80 %, profiles/r05_v6_timeline_16x16.txt) costs less than a quarter of the MFMAs spent on zeros (round 6;
+  // EDM_V6_NARROW=0: the round-5 rule)
+  static const bool narrow_ok = !(getenv("EDM_V6_NARROW") && getenv("EDM_V6_NARROW")[0] == '0');
+  const int pad4 = (Cout + 127) / 128 * 128, pad2 = (Cout + 63) / 64 * 64;
+  const bool wide = tiles4 >= 512 && !(narrow_ok && pad2 * 80 < pad4 * 69);
   // images aligned to the 512-pixel tiles (W = 32 / 64), or 16x16 images (two per tile): border handling without
   // per-fragment instructions
   const int wb = ((H * W) % BM == 0 && (W == 32 || W == 64)) ? W / 16 : (H == 16 && W == 16) ? 1 : 0;

@@ -753,7 +753,9 @@ def _v4_suffix(entry, npix, Cout):
         return "_s"
     if entry != "edm_conv_igemm_v6":
         return entry[len("edm_conv_igemm"):]
-    return V46 if ((npix + 511) // 512) * ((Cout + 127) // 128) >= 512 else V46 + "s"
+    pad4, pad2 = (Cout + 127) // 128 * 128, (Cout + 63) // 64 * 64     # (conv_igemm6.hip: narrow tiles when 128 would mostly pad)
+    wide = ((npix + 511) // 512) * ((Cout + 127) // 128) >= 512 and not pad2 * 80 < pad4 * 69
+    return V46 if wide else V46 + "s"
 
 
 def conv_igemm(x, wp, taps, residual=None, alpha=1.0, beta=0.0, out=None, silu_out=None, split=None):
