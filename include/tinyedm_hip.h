@@ -73,6 +73,14 @@ int edm_conv_igemm_s(const void* X, const void* Wp, void* Y, const void* R, floa
 int edm_conv_igemm_o(const void* X, const void* Wp, void* Y, long ldY, void* Ysilu, void* Yb, long ldYb, int split,
                      const void* R, float alpha, float beta, int B, int H, int W, int Cin, int Cout, int taps, int kernel,
                      int wfrag, edm_stream_t stream);
+/* Folded skip projection (round 6): Y = alpha3 * conv3x3(X, Wp) + alpha1 * conv1x1(X2, W2p) in ONE launch of the
+ * static-schedule 3x3 kernel -- the decoder block's conv_1x1(cat) (networks.py:313) as a second reduction behind the nine taps
+ * of the block's second 3x3 conv (networks.py:325-327), whose residual it was.  X2 [pixels][ldX2] (first C2 channels read),
+ * W2p [Cout][C2] = the 1x1 conv's forward pack; Y / ldY / Ysilu as edm_conv_igemm_o.  edm_conv3x3_fold_supported() -> 1 / 0;
+ * the entry point returns -3 for shapes it does not cover (the caller keeps the two launches). */
+int edm_conv3x3_fold_supported(int B, int H, int W, int Cin, int Cout, int C2);
+int edm_conv3x3_fold(const void* X, const void* Wp, const void* X2, long ldX2, const void* W2p, int C2, void* Y, long ldY,
+                     void* Ysilu, float alpha3, float alpha1, int B, int H, int W, int Cin, int Cout, edm_stream_t stream);
 /* first 3x3 conv of a block with the embedding modulation fused into its epilogue (networks.py:253-260 / 317-324):
  * Y = conv3x3(X) (bf16, may be NULL in eval), Y2 = dropout(mp_silu(Y * (lin[b,:]*gain + 1))) -- bit-identical to
  * edm_mod_silu_drop_fwd applied to Y (same Philox counters), so edm_mod_silu_drop_bwd serves as its backward. */
@@ -370,6 +378,11 @@ int edm_split_conv(const void* Xp, const void* Wp3, float* Y, void* Ypairs, cons
 int edm_split_conv_o(const void* Xp, const void* Wp3, float* Y, void* Ypairs, long ld_pairs, long lo_off, void* Ysilu_pairs,
                      const float* R, float alpha, float beta, const float* lin, long lin_stride, const float* gain, int B,
                      int H, int W, int C, int Cout, int taps, edm_stream_t stream);
+/* edm_conv3x3_fold for the split evaluation: Y = alpha3 * conv3x3(Xp, Wp3) + alpha1 * conv1x1(X2p, W2p3); X2p [pixels][2 C2]
+ * pairs, W2p3 [Cout][3 C2]; outputs as edm_split_conv_o; -3 where the folded form is not built (the caller keeps two launches) */
+int edm_split_conv_fold(const void* Xp, const void* Wp3, const void* X2p, const void* W2p3, int C2, float* Y, void* Ypairs,
+                        long ld_pairs, long lo_off, void* Ysilu_pairs, float alpha3, float alpha1, int B, int H, int W, int C,
+                        int Cout, edm_stream_t stream);
 int edm_f32_skip_half(const float* skip, const float* gate, void* cat_pairs, void* silu_pairs, int B, int HW, int Ci, int Cs,
                       edm_stream_t stream);
 /* cosine attention (networks.py:194-202) on the qkv conv's own output order: channel head*3d + 3*dd + {q,k,v};

@@ -410,3 +410,37 @@ def test_f32_fused_elementwise_and_output_descriptor(ops):
         assert (val(cat) - val(cat0)).abs().max().item() <= 2.0 ** -15 * val(cat0).abs().max().item()
         assert (val(sil) - val(sil0)).abs().max().item() <= 2.0 ** -15 * val(sil0).abs().max().item()
         assert not torch.isnan(cat.float()).any() and not torch.isnan(sil.float()).any()
+
+
+@pytest.mark.parametrize("B,H,W,C,Cout,C2", [(128, 32, 32, 256, 256, 512), (130, 16, 16, 256, 256, 512), (512, 8, 8, 256, 256, 512)])
+def test_split_conv_folded_projection_vs_fp64(ops, B, H, W, C, Cout, C2):
+    """Round 6: the decoder block's skip projection as a second reduction of the split 3x3 conv (ops.split_conv(fold=)):
+    alpha * conv3x3(x) + beta * conv1x1(x2), every product in three bf16 passes, against fp64 on the fp32 operands (1e-5, as
+    the plain split conv) and against the two launches it replaces; the dest / pairs output forms carry the same values."""
+    assert ops.split_conv_fold_supported((B, H, W, 2 * C), Cout, C2)
+    g = torch.Generator().manual_seed(B + H + C2)
+    sel = [0, B // 2 - 1, B // 2, B - 1]
+    x = torch.randn(B, C, H, W, generator=g)
+    x2 = torch.randn(B, C2, H, W, generator=g)
+    w3 = torch.randn(Cout, C, 3, 3, generator=g) / math.sqrt(C * 9)
+    w1 = torch.randn(Cout, C2, 1, 1, generator=g) / math.sqrt(C2)
+    a3, a1 = 0.39, 0.92
+    ref = a3 * F.conv2d(x[sel].double(), w3.double(), padding=1) + a1 * F.conv2d(x2[sel].double(), w1.double())
+    pk3 = ops.split_pack(w3.reshape(Cout, -1).contiguous().to(DEV), 9)
+    pk1 = ops.split_pack(w1.reshape(Cout, -1).contiguous().to(DEV), 1)
+    xp, x2p = ops.f32_to_pairs(nhwc(x)), ops.f32_to_pairs(nhwc(x2))
+    y = ops.split_conv(xp, pk3, 9, alpha=a3, beta=a1, fold=(x2p, pk1))
+    e = rel(nchw(y)[sel], ref)
+    record(f"evalf32/split_conv_fold[{B}x{H}x{W} {C}+{C2}->{Cout}]", e, 1e-5)
+    assert e <= 1e-5, e
+    y0 = ops.split_conv(xp, pk3, 9, residual=ops.split_conv(x2p, pk1, 1), alpha=a3, beta=a1)
+    assert rel(y, y0) <= 2e-6
+    yb, ypb = ops.split_conv(xp, pk3, 9, alpha=a3, beta=a1, fold=(x2p, pk1), also_pairs=True)
+    assert torch.equal(yb, y) and torch.equal(ypb, ops.f32_to_pairs(y))
+    Ct = Cout + 64
+    cat = torch.zeros(B, H, W, 2 * Ct, device=DEV, dtype=torch.bfloat16)
+    sil = torch.zeros_like(cat)
+    ops.split_conv(xp, pk3, 9, alpha=a3, beta=a1, fold=(x2p, pk1), dest=(cat, sil))
+    yp = ops.f32_to_pairs(y)
+    assert torch.equal(cat[..., :Cout], yp[..., :Cout]) and torch.equal(cat[..., Ct:Ct + Cout], yp[..., Cout:])
+    assert float(cat[..., Cout:Ct].abs().max()) == 0.0 and float(sil[..., Cout:Ct].abs().max()) == 0.0

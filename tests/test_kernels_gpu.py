@@ -762,3 +762,41 @@ def test_resample_fused_into_neighbours_is_bit_identical(ops, B, H, W, C):
     y, s = ops.up2_silu(xs)
     y0 = ops.up2(xs)
     assert torch.equal(y, y0) and torch.equal(s, ops.silu_fwd(y0))
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,C2,imgs", [
+    (128, 32, 32, 256, 256, 512, [0, 63, 64, 127]),      # 512 x 128 tiles, images aligned to the tiles (static borders)
+    (128, 16, 16, 256, 256, 512, [0, 1, 126, 127]),      # 512 x 64 tiles, two images per tile
+    (99, 24, 24, 128, 192, 320, [0, 49, 98]),            # per-lane border bits, ragged last tile, Cout = 3 tiles of 64
+    (512, 8, 8, 256, 256, 768, [0, 255, 256, 511])])     # the sampler's 8x8 layers
+@pytest.mark.parametrize("dest", [False, True])
+def test_conv3x3_fold_skip_projection(ops, B, H, W, Cin, Cout, C2, imgs, dest):
+    """Round 6: Y = alpha3 * conv3x3(x, W3) + alpha1 * conv1x1(x2, W1) in one launch of the static-schedule kernel (the decoder
+    block's skip projection behind the nine taps of its second 3x3 conv, networks.py:313, 325-327) against fp64 on the same
+    bf16-rounded operands; with the strided output + mp_silu form of the copy-free concat; and against the unfused pair, which
+    differs only by the bf16 rounding of the projection's result."""
+    assert ops.conv3x3_fold_supported((B, H, W, Cin), Cout, C2)
+    g = torch.Generator().manual_seed(B + H + Cin + C2)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    x2 = torch.randn(B, C2, H, W, generator=g)
+    w3 = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    w1 = torch.randn(Cout, C2, 1, 1, generator=g) / math.sqrt(C2)
+    a3, a1 = 0.39, 0.92
+    xh, x2h = nhwc(x), nhwc(x2)
+    if dest:
+        Ct = Cout + 64
+        cat = torch.zeros(B, H, W, Ct, device=DEV, dtype=torch.bfloat16)
+        sil = torch.zeros_like(cat)
+        from tinyedm_amd.networks import _col_block
+        y = ops.conv3x3_fold(xh, pack_fwd(w3), x2h, pack_fwd(w1), a3, a1, out=_col_block(cat, Cout), silu_out=_col_block(sil, Cout))
+        assert y.data_ptr() == cat.data_ptr() and float(cat[..., Cout:].abs().max()) == 0.0 and float(sil[..., Cout:].abs().max()) == 0.0
+        ysil = sil[..., :Cout].contiguous()
+        assert torch.equal(ysil, ops.silu_fwd(cat[..., :Cout].contiguous()))
+        y = cat[..., :Cout].contiguous()
+    else:
+        y = ops.conv3x3_fold(xh, pack_fwd(w3), x2h, pack_fwd(w1), a3, a1)
+    ref = a3 * F.conv2d(q(x[imgs]).double(), q(w3).double(), padding=1) + a1 * F.conv2d(q(x2[imgs]).double(), q(w1).double())
+    close_bf16(nchw(y)[imgs], ref)
+    if not dest:
+        y0 = ops.conv_igemm(xh, pack_fwd(w3), 9, residual=ops.conv_igemm(x2h, pack_fwd(w1), 1), alpha=a3, beta=a1)
+        assert rel(y.float(), y0.float()) <= 4e-3

@@ -53,6 +53,8 @@ SIGNATURES = {
     "edm_conv_igemm": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_v2": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_o": [P, P, P, L, P, P, L, I, P, F, F, I, I, I, I, I, I, I, I, P],
+    "edm_conv3x3_fold_supported": [I, I, I, I, I, I],
+    "edm_conv3x3_fold": [P, P, P, L, P, I, P, L, P, F, F, I, I, I, I, I, P],
     "edm_conv_igemm_v6": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv_igemm_s": [P, P, P, P, F, F, I, I, I, I, I, I, P],
     "edm_conv3x3_mod": [P, P, P, P, P, L, P, F, U64, U, U, I, I, I, I, I, I, P, I, P],
@@ -108,6 +110,7 @@ SIGNATURES = {
     "edm_split_pack": [P, P, I, I, I, I, P],
     "edm_split_conv": [P, P, P, P, P, F, F, P, L, P, I, I, I, I, I, I, P],
     "edm_split_conv_o": [P, P, P, P, L, L, P, P, F, F, P, L, P, I, I, I, I, I, I, P],
+    "edm_split_conv_fold": [P, P, P, P, I, P, P, L, L, P, F, F, I, I, I, I, I, P],
     "edm_f32_skip_half": [P, P, P, P, I, I, I, I, P],
     "edm_f32_pool_pixelnorm_silu": [P, P, P, I, I, I, I, I, P],
     "edm_f32_up2_silu": [P, P, P, I, I, I, I, I, P],
@@ -135,7 +138,7 @@ DIAG_SIGNATURES = {
 _RET = {"edm_last_error": ctypes.c_char_p, "edm_wgrad3_workspace": ctypes.c_long, "edm_wgrad3_table_bytes": ctypes.c_long,
         "edm_skip_gate_wgrad_multi_table_bytes": ctypes.c_long,
         "edm_conv_wgrad_1x1_group_table_bytes": ctypes.c_long, "edm_wgrad_finish_multi_table_bytes": ctypes.c_long}
-_NO_STATUS = {"edm_skip_gate_wgrad_multi_table_bytes", "edm_version", "edm_graph_replay_safe", "edm_last_error", "edm_conv_wgrad_nsplit", "edm_conv_wgrad_1x1_nsplit", "edm_conv_wgrad_1x1_nsplit_grouped", "edm_wgrad3_workspace", "edm_wgrad3_table_bytes",
+_NO_STATUS = {"edm_conv3x3_fold_supported", "edm_skip_gate_wgrad_multi_table_bytes", "edm_version", "edm_graph_replay_safe", "edm_last_error", "edm_conv_wgrad_nsplit", "edm_conv_wgrad_1x1_nsplit", "edm_conv_wgrad_1x1_nsplit_grouped", "edm_wgrad3_workspace", "edm_wgrad3_table_bytes",
               "edm_conv_wgrad_1x1_group_table_bytes", "edm_wgrad_finish_multi_table_bytes", "edm_attention_qkv_supported"}
 
 _lib = None

@@ -224,6 +224,17 @@ struct ModEpilogue {
   // (c < kwrap ? c : c - kwrap): hi.w_hi, hi.w_lo, lo.w_hi -- three bf16 passes, an fp32-accurate sum; Y and R are FLOATS
   int ldX;                // 0 = Cin
   int kwrap;              // 0 = off; chunks of 32 channels
+  // ---- folded 1x1 projection (round 6; k_conv3x3_v6<..., FOLD = true> only): behind the nine taps the accumulators are
+  // multiplied by fold_scale and a SECOND reduction runs over X2 [pixels][ldX2] -- centre tap only -- with the pack
+  // W2 [Cout][C2] (C2 % 64 == 0): Y = alpha * (fold_scale * conv3x3(X, Wp) + conv1x1(X2, W2)).  The decoder block's skip
+  // projection conv_1x1(cat) (networks.py:313) rides in the block's second 3x3 conv and its result is never written, rounded
+  // to bf16 and read back as a residual.  kwrap2: as kwrap, for X2 (split-bf16 form).
+  const bf16* X2;
+  const bf16* W2;
+  int C2;
+  int ldX2;
+  float fold_scale;
+  int kwrap2;
 };
 constexpr uint32_t U_DROPPED = 0x7FFFu;   // the bf16 pattern of a dropped element in a marked U
 __device__ __forceinline__ void apply_dyn(ModEpilogue& m) {

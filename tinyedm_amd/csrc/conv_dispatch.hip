@@ -61,6 +61,40 @@ extern "C" int edm_conv_igemm_o(const void* X, const void* Wp, void* Y, long ldY
   }
 }
 
+// Folded skip projection (round 6; k_conv3x3_v6<..., FOLD>, common.h ModEpilogue::X2):
+//   Y = alpha3 * conv3x3(X, Wp) + alpha1 * conv1x1(X2, W2p)
+// X [pixels][Cin], Wp [9][Cout][Cin]; X2 [pixels][ldX2] of which the first C2 channels are read, W2p [Cout][C2] (the 1x1
+// conv's forward pack); Y / ldY / Ysilu: the output descriptor of edm_conv_igemm_o.  Replaces, in a decoder block with a
+// U-Net skip, conv_1x1(cat) + the second 3x3 conv with that result as its residual (networks.py:313, 325-327): one launch
+// instead of two and no [pixels][Cout] round trip; the projection's result is NOT rounded to bf16 on the way (the unfused
+// pair rounds it once more).  edm_conv3x3_fold_supported: 1 when the shape runs on the static-schedule kernel's 5-slot
+// forms (W <= 38, Cin % 64 == 0, C2 % 64 == 0, enough tiles to fill the chip); the entry point returns
+// EDM_ERR_UNSUPPORTED (-3) otherwise and the caller keeps the two launches.
+extern "C" int edm_conv3x3_fold_supported(int B, int H, int W, int Cin, int Cout, int C2) {
+  const long npix = (long)B * H * W;
+  return B > 0 && H > 0 && W > 0 && npix < (1L << 31) && Cin > 0 && Cin % 64 == 0 && Cin * 2 + 64 <= 4096 && Cout > 0 &&
+         Cout % 8 == 0 && C2 > 0 && C2 % 64 == 0 && 512 + 2 * (W + 1) <= 5 * 128 - 49 && edm_conv_tall_worthwhile(npix, Cout);
+}
+extern "C" int edm_conv3x3_fold(const void* X, const void* Wp, const void* X2, long ldX2, const void* W2p, int C2, void* Y,
+                                long ldY, void* Ysilu, float alpha3, float alpha1, int B, int H, int W, int Cin, int Cout,
+                                hipStream_t st) {
+  EDM_REQUIRE(X && Wp && X2 && W2p && Y, "conv3x3_fold: null pointer");
+  EDM_REQUIRE(alpha1 != 0.f && ldX2 >= C2 && ldX2 % 8 == 0 && ldX2 < (1L << 30), "conv3x3_fold: bad alpha1 / ldX2");
+  EDM_REQUIRE(ldY == 0 || (ldY >= Cout && ldY % 8 == 0), "conv3x3_fold: ldY must be 0 or a multiple of 8 >= Cout");
+  if (!edm_conv3x3_fold_supported(B, H, W, Cin, Cout, C2)) return EDM_ERR_UNSUPPORTED;
+  ModEpilogue mod{};
+  mod.Y2 = (bf16*)Ysilu;
+  mod.mode = Ysilu ? 3 : 0;
+  mod.HW = H * W;
+  mod.ldY = ldY ? ldY : (long)(Ysilu ? Cout : 0);
+  mod.X2 = (const bf16*)X2;
+  mod.W2 = (const bf16*)W2p;
+  mod.C2 = C2;
+  mod.ldX2 = (int)ldX2;
+  mod.fold_scale = alpha3 / alpha1;
+  return edm_conv_igemm_v6_ex(X, Wp, Y, nullptr, alpha1, 0.0f, B, H, W, Cin, Cout, 9, mod, st);
+}
+
 // Split-bf16 convolution of the reference-precision evaluation path (round 4; csrc/eval_f32.hip "split"): an fp32-accurate
 // conv at the rate of the bf16 kernels / 3.  Xp: [pixels][2 C] bf16 = [hi | lo] pairs of the fp32 activation
 // (edm_f32_to_pairs), Wp3: [taps][Cout][3 C] bf16 = [w_hi | w_lo | w_hi] of the fp32 effective weight (edm_split_pack);
@@ -131,6 +165,36 @@ static int split_conv_impl(const void* Xp, const void* Wp3, float* Y, void* Ypai
   if (v2 && taps == 1 && ((npix + 255) / 256) * ((Cout + 127) / 128) >= 512)
     return edm_conv_igemm_v2_ex(Xp, Wp3, Y, R, alpha, beta, B, H, W, K, Cout, 1, mod, st);
   return edm_conv_igemm_v1_ex(Xp, Wp3, Y, R, alpha, beta, B, H, W, K, Cout, taps, mod, st);
+}
+
+// The folded skip projection (edm_conv3x3_fold) for the split-bf16 evaluation: Y = alpha3 * conv3x3(Xp, Wp3) + alpha1 *
+// conv1x1(X2p, W2p3), every product in three bf16 passes.  X2p [pixels][2 C2] pairs, W2p3 [Cout][3 C2] (edm_split_pack of the
+// 1x1 conv); outputs as edm_split_conv_o.  -3 for shapes the static-schedule kernel's folded form does not cover.
+extern "C" int edm_split_conv_fold(const void* Xp, const void* Wp3, const void* X2p, const void* W2p3, int C2, float* Y,
+                                   void* Ypairs, long ld_pairs, long lo_off, void* Ysilu_pairs, float alpha3, float alpha1,
+                                   int B, int H, int W, int C, int Cout, hipStream_t st) {
+  EDM_REQUIRE(Xp && Wp3 && X2p && W2p3 && (Y || Ypairs || Ysilu_pairs), "split_conv_fold: null pointer");
+  EDM_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 32 == 0 && C2 > 0 && C2 % 32 == 0 && Cout > 0 && Cout % 8 == 0 && alpha1 != 0.f,
+              "split_conv_fold: bad args (C %% 32, C2 %% 32, Cout %% 8)");
+  EDM_REQUIRE((ld_pairs == 0 && lo_off == 0) || (lo_off >= Cout && ld_pairs >= lo_off + Cout && ld_pairs % 4 == 0 && lo_off % 4 == 0),
+              "split_conv_fold: pairs rows need lo_off >= Cout, ld_pairs >= lo_off + Cout, both multiples of 4");
+  if (C % 64 != 0 || !edm_conv3x3_fold_supported(B, H, W, 3 * C, Cout, 3 * C2)) return EDM_ERR_UNSUPPORTED;
+  ModEpilogue mod{};
+  mod.mode = 4;
+  mod.Y2 = (bf16*)Ypairs;
+  mod.Yb = (bf16*)Ysilu_pairs;
+  mod.ldY = ld_pairs;
+  mod.ldYb = lo_off;
+  mod.HW = H * W;
+  mod.ldX = 2 * C;
+  mod.kwrap = C / 32;
+  mod.X2 = (const bf16*)X2p;
+  mod.W2 = (const bf16*)W2p3;
+  mod.C2 = 3 * C2;
+  mod.ldX2 = 2 * C2;
+  mod.kwrap2 = C2 / 32;
+  mod.fold_scale = alpha3 / alpha1;
+  return edm_conv_igemm_v6_ex(Xp, Wp3, Y, nullptr, alpha1, 0.0f, B, H, W, 3 * C, Cout, 9, mod, st);
 }
 
 // 3x3 conv with the fused embedding modulation epilogue (networks.py:253-260 / 317-324):

@@ -71,7 +71,7 @@ __device__ unsigned long long* g_v6_timeline = nullptr;
 #define V6_CLK(slot)
 #endif
 
-template <int NX, int EPI = 0, int NI = 4, bool WPTR64 = true, int WB = 0, bool LATE_DMA = false>
+template <int NX, int EPI = 0, int NI = 4, bool WPTR64 = true, int WB = 0, bool LATE_DMA = false, bool FOLD = false>
 __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ X, const bf16* __restrict__ Wp,
                                                          bf16* __restrict__ Y, const bf16* __restrict__ R,
                                                          const char* __restrict__ zeros, float alpha, float beta,
@@ -368,6 +368,91 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
 #undef MFMA_BLOCK
 #undef MFMA1
 
+  // ---- FOLD (round 6): the decoder block's 512 -> 256 skip projection as a second reduction on the same accumulators
+  // (common.h, ModEpilogue::X2).  A chunk of it is ONE step (centre tap only): a fresh 512-row slab (32 KB, no halo) and a
+  // weight tile per 8 NI MFMAs -- nine times the staging traffic per MFMA of the 3x3 part -- so this phase runs at what the
+  // L2 -> LDS path delivers, not at the matrix pipe's rate (wait + barrier per chunk, two chunks in flight).  It still beats
+  // the separate launch it replaces (68 us at 32x32 x 128): no second kernel boundary, no [pixels][Cout] round trip through HBM.
+  if constexpr (FOLD) {
+    lgkm_wait<0>();                // the last step's (unused) prefetch
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // asm MFMA results -> first read by ordinary code
+    __builtin_amdgcn_s_barrier();  // every wave is done with the slab / weight ring of the nine taps
+    {
+      const float fs = mod.fold_scale;
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] *= fs;
+    }
+    const int n2 = mod.C2 / KC;                     // even (host-checked)
+    const int kw2 = mod.kwrap2 ? mod.kwrap2 : (1 << 30);
+    const char* x2src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave + 8 * i) * 16 + drow;
+      const int c = dp ^ ((row >> 2) & 3);
+      long pix = (long)m0 + row;
+      pix = pix >= Npix ? Npix - 1 : pix;           // rows behind the last pixel feed outputs that are never stored
+      x2src[i] = reinterpret_cast<const char*>(mod.X2 + pix * mod.ldX2 + c * 8);
+    }
+    unsigned woff2;
+    {
+      const int row = wave * WROWS + (drow & (WROWS - 1));
+      const int co = min(n0 + row, Cout - 1);
+      const int c = dp ^ ((row >> 2) & 3);
+      woff2 = (unsigned)(((long)co * mod.C2 + c * 8) * 2);
+    }
+    const char* const w2base = reinterpret_cast<const char*>(mod.W2);
+    // phase-2 LDS layout: three slots of [512-row slab (32 KB) | weight tile] carved out of the slab + ring regions, TWO
+    // chunks in flight behind the one being multiplied (with one, every chunk waited a whole L2 -> LDS round trip: the
+    // phase took as long as the launch it replaces)
+    constexpr int SLAB2 = BMW * ROWB, SLOT2 = SLAB2 + WTILE, NS2 = 3;
+    static_assert(NS2 * SLOT2 <= 160 * 1024, "phase-2 slots must fit LDS (launch6 asks for the larger of the two phases)");
+    const int q2 = wave * 64 + l15;
+    const unsigned bp2 = xb_off + q2 * ROWB + ((lq ^ ((q2 >> 2) & 3)) << 4);
+    const unsigned ap2 = xb_off + SLAB2 + l15 * ROWB + ((lq ^ ((l15 >> 2) & 3)) << 4);
+    auto issue2 = [&](int c) {
+      const int xc = c >= kw2 ? c - kw2 : c;
+      char* const slot = smem + (c % NS2) * SLOT2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma16(x2src[i] + (long)xc * (KC * 2), slot + (wave + 8 * i) * 1024);
+      if (w_lane) dma16(w2base + (long)c * (KC * 2) + woff2, slot + SLAB2 + wave * (WROWS * ROWB));
+    };
+    issue2(0);
+    if (n2 > 1) issue2(1);
+#pragma unroll 1
+    for (int c = 0; c < n2; ++c) {
+      if (c + 1 < n2) wait_vmcnt<5>();   // this wave's five pieces of chunk c (chunk c + 1 may still be in flight) ...
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();      // ... and everybody's; every wave has read its fragments of chunk c - 1
+      if (c + 2 < n2) issue2(c + 2);     // into the slot chunk c - 1 was read from
+      const unsigned so = (unsigned)((c % NS2) * SLOT2);
+      const unsigned aa = ap2 + so, bb = bp2 + so;
+      u32x4 fa2[NA], fb2[NB];
+#define RD2A(i) if constexpr (NA > (i)) LDS_RD128(fa2[i], aa, (i) * 16 * ROWB);
+#define RD2B(j) LDS_RD128(fb2[j], bb, (j) * 16 * ROWB);
+      RD2A(0) RD2A(1) RD2A(2) RD2A(3) RD2A(4) RD2A(5) RD2A(6) RD2A(7)
+      RD2B(0) RD2B(1) RD2B(2) RD2B(3)
+#undef RD2A
+#undef RD2B
+      static_assert(NA <= 8 && NB == 4, "fragment reads above are written out");
+      lgkm_wait<0>();
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          if constexpr (NI == 4)
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fa2[i]), "v"(fb2[j]));
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa2[i]),
+                                                                 __builtin_bit_cast(bf16x8, fb2[j]), acc[i][j], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
   // ---- epilogue: transposed through wave-private LDS (common.h: store_tile_transposed16)
   lgkm_wait<0>();                // the last step's (unused) prefetch
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // asm MFMA results -> first read by ordinary code
@@ -414,13 +499,14 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
 #endif
 }
 
-template <int NX, int EPI, int NI, int WB = 0>
+template <int NX, int EPI, int NI, int WB = 0, bool FOLD = false>
 void launch6(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int Npix, int H, int W,
              int Cin, int Cout, const ModEpilogue& mod, hipStream_t st) {
   const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + 32 * NI - 1) / (32 * NI);
-  const size_t lds = (size_t)2 * NX * 8 * 16 * ROWB + WRING * (32 * NI * ROWB) + (EPI == 1 ? 8 * 32 * NI * 4 : 0);
+  size_t lds = (size_t)2 * NX * 8 * 16 * ROWB + WRING * (32 * NI * ROWB) + (EPI == 1 ? 8 * 32 * NI * 4 : 0);
+  if (FOLD && lds < (size_t)3 * (BM * ROWB + 32 * NI * ROWB)) lds = (size_t)3 * (BM * ROWB + 32 * NI * ROWB);   // phase 2: three slots
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
-  auto kern = k_conv3x3_v6<NX, EPI, NI, true, WB>;
+  auto kern = k_conv3x3_v6<NX, EPI, NI, true, WB, false, FOLD>;
   EDM_MAX_LDS(kern, 160 * 1024);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const bf16*)X, (const bf16*)Wp, (bf16*)Y, (const bf16*)R,
                      (const char*)edm_zero_page(), alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n, mod);
@@ -464,6 +550,23 @@ int edm_conv_igemm_v6_ex(const void* X, const void* Wp, void* Y, const void* R, 
   (wb == 4 ? launch6<6, EPIV, NIV, 4>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)            \
            : launch6<6, EPIV, NIV, 0>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st))
 #define L6(EPIV) (nx5 ? (wide ? L6A(EPIV, 4) : L6A(EPIV, 2)) : (wide ? L6B(EPIV, 4) : L6B(EPIV, 2)))
+  if (mod.X2) {
+    // folded skip projection: the 5-slot slab forms only (W <= 32: every shipped decoder level), plain and split epilogues
+    if (!nx5 || (mod.mode != 0 && mod.mode != 3 && mod.mode != 4) || R) return EDM_ERR_UNSUPPORTED;
+    // (split-bf16 form: K wraps over the [hi | lo] halves of X2, so the reduction is longer than a row)
+    EDM_REQUIRE(mod.W2 && mod.C2 > 0 && mod.C2 % 64 == 0 && mod.ldX2 % 8 == 0 &&
+                    (mod.kwrap2 ? mod.ldX2 >= 64 * mod.kwrap2 : mod.ldX2 >= mod.C2),
+                "conv_igemm_v6: folded projection needs C2 %% 64 == 0 and rows that hold the reduction (C2 %d, ldX2 %d)", mod.C2, mod.ldX2);
+#define L6F(EPIV, NIV)                                                                                           \
+  (wb == 1   ? launch6<5, EPIV, NIV, 1, true>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)          \
+   : wb == 2 ? launch6<5, EPIV, NIV, 2, true>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)          \
+             : launch6<5, EPIV, NIV, 0, true>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st))
+    if (mod.mode == 4) { if (wide) L6F(4, 4); else L6F(4, 2); }
+    else { if (wide) L6F(0, 4); else L6F(0, 2); }
+#undef L6F
+    EDM_CHECK_LAUNCH("conv_igemm_v6 (folded projection)");
+    return EDM_OK;
+  }
   if (mod.mode == 1) L6(1);
   else if (mod.mode == 2) L6(2);
   else if (mod.mode == 4) L6(4);

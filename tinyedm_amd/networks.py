@@ -949,9 +949,15 @@ class _ResBlockFn(torch.autograd.Function):
             xres, s, dsave = ops.pixelnorm_silu_fwd(x)
         else:
             xres = u
+            fold = False
             if has1:
                 wf11, wd11, _ = blk.conv_1x1.packs()
-                xres = ops.conv_igemm(u, wf11, 1)
+                # round 6: the projection conv_1x1(cat) (networks.py:313) rides in the second 3x3 conv as a second reduction
+                # behind its nine taps (ops.conv3x3_fold) where that conv runs on the static-schedule kernel; elsewhere it
+                # stays a launch of its own whose result is the 3x3 conv's residual
+                fold = u.is_contiguous() and ops.conv3x3_fold_supported((*u.shape[:3], wf1.shape[1]), wf2.shape[1], u.shape[-1])
+                if not fold:
+                    xres = ops.conv_igemm(u, wf11, 1)
             s = s_pre if s_pre is not None else ops.silu_fwd(u)     # s_pre: emitted by the concat kernel
             dsave = None
         lin = lin_view if batched else ops.linear_fwd(emb, weh)
@@ -967,7 +973,13 @@ class _ResBlockFn(torch.autograd.Function):
             a2 = ops.mod_silu_drop_fwd(r1, lin, gain, pdrop, seed, sub, step, dyn=rng.dyn)
         a, b = _mp_coeffs(blk.add_factor)
         Co = wf2.shape[1]
-        if _dest_ok(dest, a2, taps, a2.shape[-1], Co):
+        if (not enc) and fold:
+            if _dest_ok(dest, a2, taps, a2.shape[-1], Co):
+                out = ops.conv3x3_fold(a2, wf2, u, wf11, b, a, out=_col_block(dest[0], Co), silu_out=_col_block(dest[1], Co))
+                out._edm_cat = dest
+            else:
+                out = ops.conv3x3_fold(a2, wf2, u, wf11, b, a)
+        elif _dest_ok(dest, a2, taps, a2.shape[-1], Co):
             out = ops.conv_igemm(a2, wf2, taps, residual=xres, alpha=b, beta=a, out=_col_block(dest[0], Co),
                                  silu_out=_col_block(dest[1], Co))
             out._edm_cat = dest
@@ -1190,7 +1202,7 @@ def _conv_f32(mod: "_WNBase", x: Tensor, taps: int, pairs_out: bool = False, wan
     return ops.f32_conv(x, w_hat, taps, **kw)
 
 
-def _res_f32(blk, xres: Tensor, s: Tensor, lin: Tensor, want=None):
+def _res_f32(blk, xres, s: Tensor, lin: Tensor, want=None):
     """the residual branch of a block in the reference-precision evaluation path: conv3x3 -> modulation + mp_silu (fused
     epilogue; eval: no dropout) -> conv3x3 + mp_add with the skip path (networks.py:253-263 / 317-327).
     want: what the block's output must come as (see _conv_f32; decided by Denoiser._forward_f32 from the NEXT block)"""
@@ -1198,14 +1210,19 @@ def _res_f32(blk, xres: Tensor, s: Tensor, lin: Tensor, want=None):
     a2 = _conv_f32(blk.conv_3x3_1, s, 9, lin=lin, gain=blk.gain.detach(),
                    pairs_out=_split_ok(blk.conv_3x3_1) and _split_ok(blk.conv_3x3_2))
     a, b = _mp_coeffs(blk.add_factor)
+    # xres = ("fold", x pairs): the block's skip projection conv_1x1(x) rides in the second conv (ops.split_conv(fold=))
+    kw = dict(residual=xres)
+    if isinstance(xres, tuple):
+        m1 = blk.conv_1x1
+        kw = dict(fold=(xres[1], m1._split_pack))
     if isinstance(blk.attention, CosineAttention):
         # (the attention reads the block's output twice: as the qkv conv's operand -- pairs, from the same launch -- and as
         # the fp32 residual of its out conv)
         both = _split_ok(blk.conv_3x3_2) and _split_ok(blk.attention.qkv_conv)
-        out = _conv_f32(blk.conv_3x3_2, a2, 9, residual=xres, alpha=b, beta=a, want="pairs" if both else None)
+        out = _conv_f32(blk.conv_3x3_2, a2, 9, alpha=b, beta=a, want="pairs" if both else None, **kw)
         out, outp = out if both else (out, None)
         return blk.attention.forward_f32(out, outp, want)
-    return _conv_f32(blk.conv_3x3_2, a2, 9, residual=xres, alpha=b, beta=a, want=want)
+    return _conv_f32(blk.conv_3x3_2, a2, 9, alpha=b, beta=a, want=want, **kw)
 
 
 def _out_conv_split(blk) -> bool:
@@ -1332,6 +1349,12 @@ class DecoderBlock(_BlockBase):
         out = self._res(x, None if _lin is not None else _emb32(embedding, x.shape[0]), _lin, s_pre, dest=_dest)
         return ops.nhwc_bf16_to_nchw(out).to(input.dtype) if conv else _tag(out)
 
+    @staticmethod
+    def _split_pack_ready(mod) -> bool:
+        """the module's persistent split-bf16 pack is current (written by the Denoiser's plan before this forward)"""
+        key = (mod.weight.data_ptr(), mod.weight._version, _WEIGHT_EPOCH)
+        return mod._split_pack is not None and mod._split_key == key
+
     def forward_f32(self, x, lin: Tensor, skip: Tensor | None = None, want=None):
         """networks.py:306-329 on NHWC fp32 activations (evaluation only).  x: fp32, or what the producer wrote for THIS
         block (split back end, _conv_f32(want=)): (fp32, mp_silu pairs), or a _CatPre whose left halves hold x"""
@@ -1357,7 +1380,13 @@ class DecoderBlock(_BlockBase):
             x, s = ops.f32_up2_silu(x, pairs=_split_ok(self.conv_3x3_1))   # upsample + mp_silu of it: one pass
         elif up:
             x, s = ops.f32_up2(x), None
-        xres = _conv_f32(self.conv_1x1, x, 1) if isinstance(self.conv_1x1, Conv2d) else x
+        if (isinstance(self.conv_1x1, Conv2d) and F32_FUSE_OUT and x.dtype == bf16 and _split_ok(self.conv_1x1)
+                and _split_ok(self.conv_3x3_1) and _split_ok(self.conv_3x3_2) and self._split_pack_ready(self.conv_1x1)
+                and ops.split_conv_fold_supported((*x.shape[:3], 2 * self.conv_3x3_2.weight.shape[1]),
+                                                  self.conv_3x3_2.weight.shape[0], x.shape[-1] // 2)):
+            xres = ("fold", x)          # the projection rides in the block's second 3x3 conv (ops.split_conv(fold=))
+        else:
+            xres = _conv_f32(self.conv_1x1, x, 1) if isinstance(self.conv_1x1, Conv2d) else x
         if s is None:
             s = silp if (silp is not None and _split_ok(self.conv_3x3_1)) else ops.f32_silu(x, pairs=_split_ok(self.conv_3x3_1))
         return _res_f32(self, xres, s, lin, want)

@@ -810,6 +810,43 @@ def conv_igemm(x, wp, taps, residual=None, alpha=1.0, beta=0.0, out=None, silu_o
     return (ya, yb) if split is not None else out
 
 
+FOLD_PROJ = os.environ.get("EDM_FOLD_PROJ", "1") != "0"
+
+
+def conv3x3_fold_supported(xshape, Cout, C2):
+    """the shape (B, H, W, Cin) -> Cout of a decoder block's second 3x3 conv lets its skip projection (C2 -> Cout) ride along
+    (conv3x3_fold)"""
+    B, H, W, Cin = xshape
+    return bool(FOLD_PROJ and IGEMM_VERSION == 0 and _lib.call("edm_conv3x3_fold_supported", B, H, W, Cin, Cout, C2))
+
+
+def conv3x3_fold(x, wp, x2, w2p, alpha3, alpha1, out=None, silu_out=None):
+    """Y = alpha3 * conv3x3(x, wp) + alpha1 * conv1x1(x2, w2p) in one launch (edm_conv3x3_fold): wp (9, Cout, Cin), x2
+    (B, H, W, C2) contiguous, w2p (1, Cout, C2).  out / silu_out: the output descriptor of conv_igemm."""
+    B, H, W, Cin = _nhwc(x, "x")
+    _chk(wp, bf16, "wp")
+    _chk(w2p, bf16, "w2p")
+    B2, H2, W2, C2 = _nhwc(x2, "x2")
+    Cout = wp.shape[1]
+    if wp.dim() != 3 or wp.shape[0] != 9 or wp.shape[2] != Cin or tuple(w2p.shape) != (1, Cout, C2) or (B2, H2, W2) != (B, H, W):
+        raise ValueError(f"conv3x3_fold: operands do not match (x {tuple(x.shape)}, wp {tuple(wp.shape)}, x2 {tuple(x2.shape)}, "
+                         f"w2p {tuple(w2p.shape)})")
+    if getattr(wp, "_edm_frag", False):
+        raise ValueError("conv3x3_fold: a fragment-major weight pack belongs to k_conv3x3_s")
+    if out is None:
+        out = torch.empty(B, H, W, Cout, device=x.device, dtype=bf16)
+    ld = _row_view(out, B, H, W, Cout, "out")
+    if silu_out is not None and _row_view(silu_out, B, H, W, Cout, "silu_out") != ld:
+        raise ValueError("conv3x3_fold: out and silu_out must have the same row stride")
+    npix = B * H * W
+    pname = "conv3x3_igemm" + _v4_suffix("edm_conv_igemm_v6", npix, Cout) + "_fold"
+    with _prof(pname, 2.0 * npix * Cout * (9 * Cin + C2),
+               2.0 * (npix * (Cin + C2 + Cout * (2 if silu_out is not None else 1)) + wp.numel() + w2p.numel())):
+        _lib.call("edm_conv3x3_fold", _p(x), _p(wp), _p(x2), C2, _p(w2p), C2, _p(out), ld, _p(silu_out), float(alpha3),
+                  float(alpha1), B, H, W, Cin, Cout, _stream())
+    return out
+
+
 def _row_view(t, B, H, W, C, name):
     """row stride (elements) of a (B, H, W, C) bf16 view whose pixels are rows of one flat [B*H*W][ld] buffer"""
     if t.dtype != bf16 or not t.is_cuda or tuple(t.shape) != (B, H, W, C):
@@ -1396,8 +1433,16 @@ def split_pack(w_hat, taps, out=None):
     return pk
 
 
+def split_conv_fold_supported(xp_shape, Cout, C2):
+    """split_conv(fold=) covers this 3x3 shape ((B, H, W, 2C) pairs -> Cout) with a C2-channel projection riding along"""
+    B, H, W, C2x = xp_shape
+    C = C2x // 2
+    return bool(FOLD_PROJ and C % 64 == 0 and C2 % 32 == 0 and
+                _lib.call("edm_conv3x3_fold_supported", B, H, W, 3 * C, Cout, 3 * C2))
+
+
 def split_conv(xp, pack3, taps, residual=None, alpha=1.0, beta=0.0, lin=None, gain=None, pairs_out=False, also_pairs=False,
-               dest=None, silu_pairs=False):
+               dest=None, silu_pairs=False, fold=None):
     """fp32-accurate conv in three bf16 MFMA passes: xp (B,H,W,2C) bf16 pairs (f32_to_pairs), pack3 (taps,Cout,3C) bf16
     (split_pack) -> (B,H,W,Cout) fp32 = alpha*conv + beta*residual, or with lin/gain mp_silu(alpha*conv*(lin*gain+1));
     pairs_out=True: the result comes back as (B,H,W,2Cout) bf16 pairs instead (it only feeds another split_conv);
@@ -1420,6 +1465,43 @@ def split_conv(xp, pack3, taps, residual=None, alpha=1.0, beta=0.0, lin=None, ga
         _chk(gain, f32, "gain")
     if sum(map(bool, (pairs_out, also_pairs, dest is not None, silu_pairs))) > 1:
         raise ValueError("split_conv: pairs_out / also_pairs / silu_pairs / dest exclude one another")
+    if fold is not None:
+        # fold = (x2p, pack3_1x1): alpha * conv3x3(xp) + beta * conv1x1(x2p) in one launch (the decoder's skip projection,
+        # edm_split_conv_fold); `beta` is the projection's coefficient, there is no residual
+        x2p, pk1 = fold
+        if residual is not None or lin is not None or taps != 9:
+            raise ValueError("split_conv: fold excludes residual / modulation and needs taps == 9")
+        B2, H2, W2, C22 = _nhwc(x2p, "fold[0]")
+        C2 = C22 // 2
+        _chk(pk1, bf16, "fold[1]", (1, Cout, 3 * C2))
+        if (B2, H2, W2) != (B, H, W):
+            raise ValueError("split_conv: fold operand shape mismatch")
+        y = yp = ys = None
+        ld = lo = 0
+        ret = None
+        if dest is not None:
+            cat, sil = dest
+            Ct = cat.shape[-1] // 2
+            _chk(cat, bf16, "dest[0]", (B, H, W, 2 * Ct))
+            if sil is not None:
+                _chk(sil, bf16, "dest[1]", (B, H, W, 2 * Ct))
+            if Ct <= Cout or Ct % 4:
+                raise ValueError("split_conv: dest must be wider than the result")
+            yp, ys, ld, lo, ret = cat, sil, 2 * Ct, Ct, cat
+        elif pairs_out:
+            ret = yp = torch.empty(B, H, W, 2 * Cout, device=xp.device, dtype=bf16)
+        else:
+            y = torch.empty(B, H, W, Cout, device=xp.device, dtype=f32)
+            if also_pairs or silu_pairs:
+                p2 = torch.empty(B, H, W, 2 * Cout, device=xp.device, dtype=bf16)
+                yp, ys = (p2, None) if also_pairs else (None, p2)
+                ret = (y, p2)
+            else:
+                ret = y
+        with _prof("split_conv3x3_fold", 2.0 * B * H * W * Cout * (9 * C + C2), 4.0 * B * H * W * (C + C2 + Cout) + 2.0 * pack3.numel()):
+            _lib.call("edm_split_conv_fold", _p(xp), _p(pack3), _p(x2p), _p(pk1), C2, _p(y), _p(yp), ld, lo, _p(ys), float(alpha),
+                      float(beta), B, H, W, C, Cout, _stream())
+        return ret
     nb = 4.0 * B * H * W * (C + Cout * (2 if residual is not None else 1)) + 2.0 * pack3.numel()
     pname = "split_conv3x3" if taps == 9 else "split_conv1x1"
     if dest is not None or also_pairs or silu_pairs:
