@@ -162,3 +162,32 @@ def test_attention_module_runs_the_fused_kernels_and_matches_the_unfused_path():
         O_.ATTN_FUSED = old
     for a, b, lim in zip(res[True], res[False], (6e-3, 1.2e-2, 1.2e-2, 1.2e-2)):
         assert rel(a, b) < lim, (rel(a, b), lim)
+
+
+@pytest.mark.parametrize("B,H,W", [(512, 16, 16), (515, 16, 16), (512, 8, 8)])
+def test_attention_block_at_sampler_batch_vs_oracle(B, H, W):
+    """VERDICT r5 (weak #1): the `B >= 512 -> four heads per workgroup` dispatch of edm_attention_qkv_fwd -- what both samplers
+    and bench.py's sampler legs run -- through the module (`CosineAttention`, eval mode, no grad) against the ORACLE's own
+    `cosine_attention` (oracle/edm_oracle.py, networks.py:191-207, bf16 rounding points) on the first / middle / last samples
+    of the batch (samples are independent; the kernel's sample -> XCD / workgroup map is what the batch size changes)."""
+    from tinyedm_amd import networks as N, ops as O_
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    assert O_.ATTN_FUSED and O_.ATTN_HP == 0 and O_.attention_qkv_supported(torch.empty(B, H, W, 256), 4)
+    g = torch.Generator().manual_seed(B + H)
+    att = N.CosineAttention(256, 4)
+    with torch.no_grad():
+        att.qkv_conv.weight.copy_(torch.randn(att.qkv_conv.weight.shape, generator=g))
+        att.out_conv.weight.copy_(torch.randn(att.out_conv.weight.shape, generator=g))
+    P = {"a.qkv_conv.weight": att.qkv_conv.weight.detach().clone(), "a.out_conv.weight": att.out_conv.weight.detach().clone()}
+    att = att.to(DEV).eval()
+    x = q(torch.randn(B, 256, H, W, generator=g))
+    sel = sorted({0, 1, B // 2 - 1, B // 2, B - 2, B - 1})
+    with torch.no_grad():
+        y = att(x.to(DEV)).cpu()
+    y_ref = O.cosine_attention(P, "a.", x[sel], 4, q=O.q_bf16)
+    from parity_log import record
+    e = rel(y[sel], y_ref)
+    record(f"attnfused/block_eval_B{B}_{H}x{W}_vs_oracle", e, 6e-3)
+    assert e <= 6e-3, e
+    assert (y[sel] - y_ref).abs().max().item() <= 3e-2 * y_ref.abs().max().item()

@@ -12,7 +12,8 @@ def load(p):
         n = re.sub(r"\(anonymous namespace\)::", "", r["Name"])
         n = re.sub(r"^void ", "", n)
         n = n.split("(")[0][:58]
-        out[n] = out.get(n, 0.0) + float(r["TotalDurationNs"]) / 1e6, int(r["Calls"])
+        t, c = out.get(n, (0.0, 0))
+        out[n] = (t + float(r["TotalDurationNs"]) / 1e6, c + int(r["Calls"]))
     return out
 
 
