@@ -20,6 +20,7 @@
 // y     [B*N, C]   bf16, channel = head*64 + d
 // stat  [B, heads, N] fp32: 1 / sum_j exp(s_ij - 8) (saved for the backward)
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -187,10 +188,35 @@ __device__ __forceinline__ void leave_ab(int ka, int kb, int wave) {
   }
 }
 
+// ---- round 6: the wave's 32 tokens x 256 channels as MFMA B fragments, fed ROW-CONTIGUOUSLY.  Loading a fragment straight
+// from global memory (lane = token: 32 rows x two 16-byte pieces per instruction) is bound by the texture addresser, not by
+// bytes -- 15.3 us for the backward's three operands where 5.5 us move the same bytes as whole rows
+// (tools/frag_load, profiles/r05_frag_load.txt).  Here a HALF row (128 channels = 256 bytes) of each of the wave's tokens is
+// brought into a wave-private 8 KB of LDS by LDS-DMA (1 KB per instruction = four whole half rows; the 16-byte pieces
+// XOR-swizzled with the token index on the DMA source so that the fragment reads are conflict-free) and the eight fragments
+// of that half are ds_read_b128s.  The staging bytes lie in regions the kernel writes only behind later workgroup barriers
+// (the K / V images).  No workgroup barrier: a wave stages and reads its OWN tokens.
+__device__ __forceinline__ void stage_issue(const bf16* rows /* token 0 of the sample */, const bf16* zeros, int N, int half,
+                                            char* stg, int wave, int lane) {
+  const int rr = lane >> 4, pp = lane & 15;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int r = 4 * s + rr;                       // token of the wave's block
+    const int tok = wave * 32 + r;
+    const int lp = pp ^ (r & 15);
+    const bf16* src = (tok < N ? rows + (long)tok * C + half * 128 : zeros) + lp * 8;
+    dma16(src, stg + s * 1024);
+  }
+}
+__device__ __forceinline__ void stage_read(const char* stg, int l31, int lhi, bf16x8* frag /* 8 fragments of the half */) {
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) frag[kk] = ld128(stg + l31 * 256 + (((2 * kk + lhi) ^ (l31 & 15)) << 4));
+}
+
 // RING: slots of the weight ring.  A chunk needs 12 MFMAs per wave (0.2 us) and an L2 -> LDS round trip of > 1 us: with two
 // chunks in flight the projection ran at 16 % of the MFMA rate (tools/af_timeline.py: 12 us for a head's 8 chunks); RING - 1
 // chunks are kept in flight -- with 7 slots nearly the whole head's 96 KB of weights.
-template <int NT, int RING>
+template <int NT, int RING, bool STAGE = true>
 __global__ __launch_bounds__(NT * 64) void k_attn_qkv_fwd(const bf16* __restrict__ x, const bf16* __restrict__ Wqkv,
                                                             bf16* __restrict__ y, float* __restrict__ stat,
                                                             const bf16* __restrict__ zeros, int B, int N, int heads,
@@ -214,16 +240,34 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_fwd(const bf16* __restrict
   AF_STAMP(0);
   // ---- the wave's token block as B fragments: bx[kk] = x[tok][16 kk + 8 lhi .. +8]
   bf16x8 bx[C / 16];
-  {
-    const bf16* xr = (tvalid ? x + ((long)b * N + tok) * C : zeros) + lhi * 8;      // (padding tokens read the zero page)
-#pragma unroll
-    for (int kk = 0; kk < C / 16; ++kk) bx[kk] = *reinterpret_cast<const bf16x8*>(xr + kk * 16);
-  }
   const int head0 = hg * HP;
   constexpr int AHEAD = RING - 1;                              // chunks in flight behind the one being consumed
   static_assert(AHEAD >= 2 && AHEAD < NCH, "ring depth");
+  if constexpr (STAGE) {
+    // row-contiguous feed (see stage_issue): half rows through the wave's 8 KB of the K | V image region, two rounds; the
+    // weight ring's first chunks are issued behind the first round and land under the second
+    static_assert(2 * NP * RS >= NT * 8192, "the staging area must fit the K | V image region");
+    char* const stg = smem + wave * 8192;
+    const bf16* const rows = x + (long)b * N * C;
+    stage_issue(rows, zeros, N, 0, stg, wave, lane);
 #pragma unroll
-  for (int j = 0; j < AHEAD; ++j) G::issue(Wqkv + (long)head0 * 3 * D * C, j, ring, j, wave, lane);
+    for (int j = 0; j < AHEAD; ++j) G::issue(Wqkv + (long)head0 * 3 * D * C, j, ring, j, wave, lane);
+    leave_in_flight<G, AHEAD>(wave);                           // the eight staging pieces are older than the ring's
+    stage_read(stg, l31, lhi, bx);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the fragments are in registers before the area is rewritten
+    stage_issue(rows, zeros, N, 1, stg, wave, lane);
+    wait_vmcnt<0>();
+    stage_read(stg, l31, lhi, bx + 8);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  } else {
+    {
+      const bf16* xr = (tvalid ? x + ((long)b * N + tok) * C : zeros) + lhi * 8;      // (padding tokens read the zero page)
+#pragma unroll
+      for (int kk = 0; kk < C / 16; ++kk) bx[kk] = *reinterpret_cast<const bf16x8*>(xr + kk * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < AHEAD; ++j) G::issue(Wqkv + (long)head0 * 3 * D * C, j, ring, j, wave, lane);
+  }
 
   const int a_off0 = G::frag_off(l31, lhi, 0), a_off1 = G::frag_off(l31, lhi, 1);
   const float sl2 = 0.125f * LOG2E, c0 = 8.0f * LOG2E;       // p = exp2(s * sl2 - c0) = exp(s / sqrt(d) - 8)
@@ -389,16 +433,38 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_fwd(const bf16* __restrict
 #endif
 }
 
+// EDM_ATTN_STAGE=0: the round-5 operand loads (fragments straight from global memory) in the BACKWARD kernel; A/B runs.
+// Measured (tools/microbench_attnblock.py, one call, profiles/r06_attn_stage_ab.txt): backward 77.6 -> 71.5 us at 16x16 x 128,
+// 20.8 -> 18.4 at 8x8, 282 -> 265 at batch 512; the training step 12.70 -> 12.66 ms.
+static bool attn_stage() {
+  static const bool on = !(getenv("EDM_ATTN_STAGE") && getenv("EDM_ATTN_STAGE")[0] == '0');
+  return on;
+}
+// The FORWARD kernel's staged form is built and parity-tested (EDM_ATTN_STAGE_FWD=1) but off: its single operand costs two
+// DMA round trips through the 8-KB staging area where the fragment-shaped loads cost about the same (37.5 vs 37.1 us at
+// 16x16 x 128, 120.3 vs 121.3 at batch 512) -- the addresser-bound pattern only hurts once three operands queue behind it.
+static bool attn_stage_fwd() {
+  static const bool on = getenv("EDM_ATTN_STAGE_FWD") && getenv("EDM_ATTN_STAGE_FWD")[0] == '1';
+  return on;
+}
+
 template <int NT, int RING>
 void launch_fwd(const void* x, const void* Wqkv, void* y, float* stat, int B, int N, int heads, int HP, hipStream_t st) {
-  auto kern = k_attn_qkv_fwd<NT, RING>;
-  EDM_MAX_LDS(kern, 160 * 1024);
   const size_t lds = (size_t)2 * NT * 32 * RS + (size_t)RING * QKV_SLOTB;
   static_assert((size_t)2 * NT * 32 * RS + (size_t)RING * QKV_SLOTB <= 160 * 1024, "LDS budget");
   const int groups = heads / HP;
   const int grid = ((B + 7) / 8) * 8 * groups;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT * 64), lds, st, (const bf16*)x, (const bf16*)Wqkv, (bf16*)y, stat,
-                     (const bf16*)edm_zero_page(), B, N, heads, HP);
+  if (attn_stage_fwd()) {
+    auto kern = k_attn_qkv_fwd<NT, RING, true>;
+    EDM_MAX_LDS(kern, 160 * 1024);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT * 64), lds, st, (const bf16*)x, (const bf16*)Wqkv, (bf16*)y, stat,
+                       (const bf16*)edm_zero_page(), B, N, heads, HP);
+  } else {
+    auto kern = k_attn_qkv_fwd<NT, RING, false>;
+    EDM_MAX_LDS(kern, 160 * 1024);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT * 64), lds, st, (const bf16*)x, (const bf16*)Wqkv, (bf16*)y, stat,
+                       (const bf16*)edm_zero_page(), B, N, heads, HP);
+  }
 }
 
 // ====================================================================================================================
@@ -456,7 +522,7 @@ __device__ __forceinline__ void image_store(char* img_row, int rb, int lhi, cons
 // RING slots of 12 KB; OVERLAY: the ring occupies the Q | K | V image regions (all three are written after the last chunk
 // has been consumed) instead of LDS of its own.  The 12 chunks of a head (4 of the out conv's dgrad rows, 64 channels each;
 // 8 of the qkv rows, 32 channels each) are one stream: RING - 1 of them are kept in flight.
-template <int NT, int RING, bool OVERLAY>
+template <int NT, int RING, bool OVERLAY, bool STAGE = true>
 __global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict__ x, const bf16* __restrict__ y,
                                                             const bf16* __restrict__ gout, const float* __restrict__ stat,
                                                             const bf16* __restrict__ Wqkv, const bf16* __restrict__ Wdo,
@@ -502,7 +568,50 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict
     // ---- operands of both projections as B fragments (token on the lane), the head's slice of y for delta: all loads first
     bf16x8 bg[C / 16], bx[C / 16];
     bf16x4 yv[2][4];
-    {
+    const bf16* wdo = Wdo + (long)head * D * C;
+    const bf16* wrows = Wqkv + (long)head * 3 * D * C;
+    // chunk j of the stream: j < NCHB -> rows of the out conv (64 channels), else chunk j - NCHB of the qkv rows; slot j % RING
+    auto issue = [&](int j) {
+      if (j < NCHB) GB::issue(wdo, j, ring, j % RING, wave, lane);
+      else GA::issue(wrows, j - NCHB, ring, j % RING, wave, lane);
+    };
+    if constexpr (STAGE) {
+      // row-contiguous feed of gout and x (stage_issue): a whole tensor's rows of the wave (two 8-KB halves) per round, in
+      // the image regions (written only behind later barriers).  The ring has LDS of its own for <= 128 tokens and is
+      // started first; for 256 tokens it lies over the Q | K | V regions -- over other waves' staging areas -- and starts
+      // when every wave has its fragments in registers (one barrier; its first chunk's latency is exposed: ~1.5 us against
+      // the ~9 us the fragment-shaped global loads cost).
+      static_assert(4 * NP * RS >= NT * 16384, "the staging areas must fit the image regions");
+      char* const stg = smem + wave * 16384;
+      if constexpr (!OVERLAY) {
+#pragma unroll
+        for (int j = 0; j < AHEAD; ++j) issue(j);
+      }
+      stage_issue(gout + (long)b * N * C, zeros, N, 0, stg, wave, lane);
+      stage_issue(gout + (long)b * N * C, zeros, N, 1, stg + 8192, wave, lane);
+      {
+        const bf16* yr = (tvalid ? y + trow * C + head * D : zeros) + 4 * lhi;         // (padding tokens read the zero page)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) yv[dt][g] = *reinterpret_cast<const bf16x4*>(yr + dt * 32 + 8 * g);
+      }
+      wait_vmcnt<0>();
+      stage_read(stg, l31, lhi, bg);
+      stage_read(stg + 8192, l31, lhi, bg + 8);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stage_issue(x + (long)b * N * C, zeros, N, 0, stg, wave, lane);
+      stage_issue(x + (long)b * N * C, zeros, N, 1, stg + 8192, wave, lane);
+      wait_vmcnt<0>();
+      stage_read(stg, l31, lhi, bx);
+      stage_read(stg + 8192, l31, lhi, bx + 8);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (OVERLAY) {
+        __builtin_amdgcn_s_barrier();      // the ring's slots cover the other waves' staging areas
+#pragma unroll
+        for (int j = 0; j < AHEAD; ++j) issue(j);
+      }
+    } else {
       const bf16* gr = (tvalid ? gout + trow * C : zeros) + lhi * 8;                  // (padding tokens read the zero page)
       const bf16* yr = (tvalid ? y + trow * C + head * D : zeros) + 4 * lhi;
       const bf16* xr = (tvalid ? x + trow * C : zeros) + lhi * 8;
@@ -515,13 +624,6 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict
 #pragma unroll
       for (int kk = 0; kk < C / 16; ++kk) bx[kk] = *reinterpret_cast<const bf16x8*>(xr + kk * 16);
     }
-    const bf16* wdo = Wdo + (long)head * D * C;
-    const bf16* wrows = Wqkv + (long)head * 3 * D * C;
-    // chunk j of the stream: j < NCHB -> rows of the out conv (64 channels), else chunk j - NCHB of the qkv rows; slot j % RING
-    auto issue = [&](int j) {
-      if (j < NCHB) GB::issue(wdo, j, ring, j % RING, wave, lane);
-      else GA::issue(wrows, j - NCHB, ring, j % RING, wave, lane);
-    };
     // The chunk loop is software-pipelined by half a chunk: the wait + barrier that make chunk j visible sit in the MIDDLE of
     // chunk j-1's MFMAs (which keep the matrix pipe busy while the wave waits), and chunk j's first fragments are read under
     // chunk j-1's last MFMAs.  (Per-chunk lockstep -- barrier, all waves read, all waves multiply -- ran both projections at
@@ -534,8 +636,10 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict
       const int nb = kb > 0 ? kb : 0;
       leave_ab<GA, GB, NCH, NCHB - 1>(last - j - nb, nb, wave);
     };
+    if constexpr (!STAGE) {
 #pragma unroll
-    for (int j = 0; j < AHEAD; ++j) issue(j);
+      for (int j = 0; j < AHEAD; ++j) issue(j);
+    }
 
     // ---- phase B: dO^T (64 channels x 32 tokens) = alpha * Wd_out rows . gout^T
     f32x16 ad[2];
@@ -810,15 +914,23 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_bwd(const bf16* __restrict
 template <int NT, int RING, bool OVERLAY>
 void launch_bwd(const void* x, const void* y, const void* gout, const void* stat, const void* Wqkv, const void* Wdo, void* gqkv,
                 float alpha, int B, int N, int heads, int HP, hipStream_t st) {
-  auto kern = k_attn_qkv_bwd<NT, RING, OVERLAY>;
-  EDM_MAX_LDS(kern, 160 * 1024);
   constexpr size_t lds = (size_t)4 * NT * 32 * RS + (size_t)5 * NT * 32 * sizeof(float) + (OVERLAY ? 0 : (size_t)RING * QKV_SLOTB);
   static_assert(lds <= 160 * 1024, "LDS budget");
   const int groups = heads / HP;
   const int grid = ((B + 7) / 8) * 8 * groups;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT * 64), lds, st, (const bf16*)x, (const bf16*)y, (const bf16*)gout,
-                     (const float*)stat, (const bf16*)Wqkv, (const bf16*)Wdo, (bf16*)gqkv, (const bf16*)edm_zero_page(), alpha, B,
-                     N, heads, HP);
+  if (attn_stage()) {
+    auto kern = k_attn_qkv_bwd<NT, RING, OVERLAY, true>;
+    EDM_MAX_LDS(kern, 160 * 1024);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT * 64), lds, st, (const bf16*)x, (const bf16*)y, (const bf16*)gout,
+                       (const float*)stat, (const bf16*)Wqkv, (const bf16*)Wdo, (bf16*)gqkv, (const bf16*)edm_zero_page(), alpha,
+                       B, N, heads, HP);
+  } else {
+    auto kern = k_attn_qkv_bwd<NT, RING, OVERLAY, false>;
+    EDM_MAX_LDS(kern, 160 * 1024);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT * 64), lds, st, (const bf16*)x, (const bf16*)y, (const bf16*)gout,
+                       (const float*)stat, (const bf16*)Wqkv, (const bf16*)Wdo, (bf16*)gqkv, (const bf16*)edm_zero_page(), alpha,
+                       B, N, heads, HP);
+  }
 }
 
 }  // namespace
