@@ -38,7 +38,10 @@ def _reference(x, w_qkv_hat, heads, gy=None):
 
 @pytest.mark.parametrize("B,H,W", [(2, 16, 16), (3, 8, 8), (9, 8, 8), (1, 14, 14), (2, 7, 7), (2, 6, 11), (17, 16, 16)])
 @pytest.mark.parametrize("hp", [0, 1, 2, 4])
-def test_attention_qkv_fwd(ops, B, H, W, hp):
+@pytest.mark.parametrize("stage", ["0", "1"])
+def test_attention_qkv_fwd(ops, B, H, W, hp, stage, monkeypatch):
+    """stage = EDM_ATTN_STAGE_FWD: the forward's row-contiguous operand feed (round 6; built, off by default)"""
+    monkeypatch.setenv("EDM_ATTN_STAGE_FWD", stage)
     heads, C = 4, 256
     if not ops._lib.call("edm_attention_qkv_supported", H * W, C, heads):
         pytest.skip("shape not covered by the fused kernel")
@@ -86,9 +89,13 @@ def pack_dgrad_1x1(w):
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 16, 16), (3, 8, 8), (9, 8, 8), (1, 14, 14), (2, 7, 7), (2, 6, 11), (17, 16, 16)])
-def test_attention_qkv_bwd(ops, B, H, W):
-    """gqkv of the fused backward (q, k, v recomputed from x; dO = alpha * gout . W_out formed inside) against autograd of
+@pytest.mark.parametrize("stage", ["1", "0"])
+def test_attention_qkv_bwd(ops, B, H, W, stage, monkeypatch):
+    """stage = EDM_ATTN_STAGE: gout and x reach the kernel as whole rows through LDS (round 6, default) or as fragment-shaped
+    global loads (round 5).
+    gqkv of the fused backward (q, k, v recomputed from x; dO = alpha * gout . W_out formed inside) against autograd of
     the restated algorithm with the same rounding points, and against the unfused kernel sequence on the same operands."""
+    monkeypatch.setenv("EDM_ATTN_STAGE", stage)
     heads, C, alpha = 4, 256, 0.7071
     if not ops._lib.call("edm_attention_qkv_supported", H * W, C, heads):
         pytest.skip("shape not covered by the fused kernel")

@@ -436,16 +436,16 @@ __global__ __launch_bounds__(NT * 64) void k_attn_qkv_fwd(const bf16* __restrict
 // EDM_ATTN_STAGE=0: the round-5 operand loads (fragments straight from global memory) in the BACKWARD kernel; A/B runs.
 // Measured (tools/microbench_attnblock.py, one call, profiles/r06_attn_stage_ab.txt): backward 77.6 -> 71.5 us at 16x16 x 128,
 // 20.8 -> 18.4 at 8x8, 282 -> 265 at batch 512; the training step 12.70 -> 12.66 ms.
-static bool attn_stage() {
-  static const bool on = !(getenv("EDM_ATTN_STAGE") && getenv("EDM_ATTN_STAGE")[0] == '0');
-  return on;
+static bool attn_stage() {       // (read per call: tests switch it inside one process)
+  const char* e = getenv("EDM_ATTN_STAGE");
+  return !(e && e[0] == '0');
 }
 // The FORWARD kernel's staged form is built and parity-tested (EDM_ATTN_STAGE_FWD=1) but off: its single operand costs two
 // DMA round trips through the 8-KB staging area where the fragment-shaped loads cost about the same (37.5 vs 37.1 us at
 // 16x16 x 128, 120.3 vs 121.3 at batch 512) -- the addresser-bound pattern only hurts once three operands queue behind it.
 static bool attn_stage_fwd() {
-  static const bool on = getenv("EDM_ATTN_STAGE_FWD") && getenv("EDM_ATTN_STAGE_FWD")[0] == '1';
-  return on;
+  const char* e = getenv("EDM_ATTN_STAGE_FWD");
+  return e && e[0] == '1';
 }
 
 template <int NT, int RING>
