@@ -108,11 +108,10 @@ int edm_mod_finish(const float* gm, const float* lin, long lin_stride, const flo
  * {const float* gain; float* ggain; int col0, C;}: glin[:, col0:col0+C] += gm * *gain, *ggain += sum gm * lin */
 int edm_mod_finish_multi(const float* gm_all, const float* lin_all, float* glin_all, long stride, const void* items_dev,
                          int n_items, int B, edm_stream_t stream);
-/* weight gradient: slabs[s,tap,co,ci] (fp32, nsplit = edm_conv_wgrad_nsplit(...)) partial sums over pixels. */
+/* weight gradient: slabs[s,tap,co,ci] (fp32, nsplit = edm_conv_wgrad_nsplit(...)) partial sums over pixels; LDS-DMA staging,
+ * rolling X window; Cin, Cout % 32 == 0; -3 = not covered (3x3 with W > 126).  (The first-generation edm_conv_wgrad was retired
+ * in round 6: no default dispatch reached it.) */
 int edm_conv_wgrad_nsplit(int B, int H, int W, int Cin, int Cout, int taps);
-int edm_conv_wgrad(const void* X, const void* dY, float* slabs, int B, int H, int W, int Cin, int Cout, int taps,
-                   int nsplit, edm_stream_t stream);
-/* second-generation weight-gradient kernel, same contract (LDS-DMA staging, rolling X window); -3 = not covered */
 int edm_conv_wgrad_v2(const void* X, const void* dY, float* slabs, int B, int H, int W, int Cin, int Cout, int taps,
                       int nsplit, edm_stream_t stream);
 /* 1x1 layers (networks.py:21-38 with kernel_size 1: skip projections, attention qkv/out): 256x128-output tiles,

@@ -86,13 +86,14 @@ def igemm_version(request, ops):
     ops.IGEMM_VERSION = old
 
 
-@pytest.fixture(params=[1, 2], ids=["wgrad-v1", "wgrad-v2"])
+@pytest.fixture(params=[False, True], ids=["wgrad-v2-all", "wgrad-v2+1x1"])
 def wgrad_version(request, ops):
-    old, old1 = ops.WGRAD_VERSION, ops.WGRAD_1X1
-    ops.WGRAD_VERSION = request.param
-    ops.WGRAD_1X1 = request.param == 2   # v1 also covers the 1x1 layers; v2 pairs with the dedicated 1x1 kernel
+    """the rolling-window kernel for every layer (its 1x1 form), or -- the default -- paired with the dedicated 1x1 kernel
+    (generation 1, the register-staged kernel, was retired in round 6)"""
+    old1 = ops.WGRAD_1X1
+    ops.WGRAD_1X1 = request.param
     yield request.param
-    ops.WGRAD_VERSION, ops.WGRAD_1X1 = old, old1
+    ops.WGRAD_1X1 = old1
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", CONV_SHAPES)
@@ -160,14 +161,9 @@ def test_conv_full_size_layer_properties(ops):
     assert rel(y12, ys[6] + y2) < 1e-2                     # linearity (bf16 rounding of the summed input)
     dy = torch.randn(B, H, W, C, generator=g).to(torch.bfloat16).to(DEV)
     lhs = (dy.float() * ys[6]).sum().item()
-    for wv in (1, 2):
-        oldw, ops.WGRAD_VERSION = ops.WGRAD_VERSION, wv
-        try:
-            slabs = ops.conv_wgrad(x1, dy, 9)
-        finally:
-            ops.WGRAD_VERSION = oldw
-        rhs = (slabs.sum(0) * wp.float()).sum().item()
-        assert abs(lhs - rhs) <= 2e-2 * abs(lhs) + 50.0, (wv, lhs, rhs)
+    slabs = ops.conv_wgrad(x1, dy, 9)
+    rhs = (slabs.sum(0) * wp.float()).sum().item()
+    assert abs(lhs - rhs) <= 2e-2 * abs(lhs) + 50.0, (lhs, rhs)
 
 
 def test_conv_igemm_residual_epilogue(ops, igemm_version):

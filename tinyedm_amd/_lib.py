@@ -63,7 +63,6 @@ SIGNATURES = {
     "edm_conv3x3_silubwd": [P, P, P, P, F, P, I, I, I, I, I, I, P],
     "edm_mod_finish": [P, P, L, P, P, L, P, I, I, P],
     "edm_conv_wgrad_nsplit": [I, I, I, I, I, I],
-    "edm_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, P],
     "edm_conv_wgrad_v2": [P, P, P, I, I, I, I, I, I, I, P],
     "edm_conv_wgrad_1x1_nsplit": [L, I, I],
     "edm_conv_wgrad_1x1_nsplit_grouped": [L, I, I],

@@ -307,9 +307,23 @@ Geo make_geo(int B, int H, int W, int taps, int leads) {
 
 }  // namespace
 
-// Same contract as edm_conv_wgrad (the same edm_conv_wgrad_nsplit value sizes the slab workspace); returns -3 for
-// shapes outside its coverage (3x3 with W > 62).
-extern "C" int edm_conv_wgrad_nsplit(int B, int H, int W, int Cin, int Cout, int taps);
+// How many K-splits edm_conv_wgrad_v2 uses for this shape (callers size the slab workspace as nsplit * taps * Cout * Cin floats).
+// (Round 6: the first-generation kernel k_conv_wgrad -- register-staged, 64 x 64 tiles, conv_wgrad.hip -- was retired: no
+// default dispatch reached it since round 2 and it had the same Cin / Cout % 32 contract as this one.)
+extern "C" int edm_conv_wgrad_nsplit(int B, int H, int W, int Cin, int Cout, int taps) {
+  const long PW = (taps == 9) ? W + 1 : W, PH = (taps == 9) ? H + 1 : H;
+  const long ktot = (taps == 9) ? (2 + (long)B * PH) * PW - (PW + 1) : (long)B * H * W;
+  const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
+  long S = (256 + tiles - 1) / tiles;
+  const long max_s = (ktot + 4 * KP - 1) / (4 * KP);  // at least ~4 stages per split
+  if (S > max_s) S = max_s;
+  if (S < 1) S = 1;
+  if (S > 128) S = 128;
+  return (int)S;
+}
+
+// X [B*H*W, Cin] bf16, dY [B*H*W, Cout] bf16 -> slabs [nsplit, taps, Cout, Cin] fp32 (fully overwritten); returns -3 for
+// shapes outside its coverage (3x3 with W > 126).
 extern "C" int edm_conv_wgrad_v2(const void* X, const void* dY, float* slabs, int B, int H, int W, int Cin, int Cout,
                                  int taps, int nsplit, hipStream_t st) {
   EDM_REQUIRE(X && dY && slabs, "conv_wgrad_v2: null pointer");

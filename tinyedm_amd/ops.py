@@ -962,7 +962,7 @@ def conv3x3_silubwd(g, wd, xpre, gextra=None, extra_scale=1.0):
 
 
 WGRAD_1X1 = os.environ.get("EDM_WGRAD_1X1", "1") != "0"
-WGRAD_VERSION = int(os.environ.get("EDM_WGRAD", "2"))   # 1 = register-staged kernel, 2 = LDS-DMA rolling-window kernel
+WGRAD_VERSION = 2       # (generation 1, the register-staged kernel, was retired in round 6; the name stays for the tests' asserts)
 
 
 def conv_wgrad(x, dy, taps):
@@ -983,9 +983,7 @@ def conv_wgrad(x, dy, taps):
     slabs = torch.empty(S, taps, Cout, Cin, device=x.device, dtype=f32)
     with _prof("conv3x3_wgrad" if taps == 9 else "conv1x1_wgrad", 2.0 * npix * Cin * Cout * taps,
                2.0 * npix * (Cin + Cout) + 4.0 * slabs.numel()):
-        # 3x3: LDS-DMA rolling-window kernel; 1x1: the register-staged kernel is (slightly) faster (r01 microbench)
-        fn = "edm_conv_wgrad_v2" if (WGRAD_VERSION == 2 and taps == 9 and W <= 126) else "edm_conv_wgrad"
-        _lib.call(fn, _p(x), _p(dy), _p(slabs), B, H, W, Cin, Cout, taps, S, _stream())
+        _lib.call("edm_conv_wgrad_v2", _p(x), _p(dy), _p(slabs), B, H, W, Cin, Cout, taps, S, _stream())
     return slabs
 
 
