@@ -35,7 +35,7 @@ cp $(ls $O/prof_${RD}s/*/*kernel_stats.csv | head -1) $O/${RD}_sampler_kernel_st
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${RD}sf -- python3 $R/tools/sampler_profile.py 256 f32 > $O/${RD}_sampler_f32.log 2>&1
 cp $(ls $O/prof_${RD}sf/*/*kernel_stats.csv | head -1) $O/${RD}_sampler_f32_kernel_stats.csv
 rm -rf $O/prof_${RD}sx
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${RD}sx -- python3 $R/tools/sampler_profile.py 256 f32x3 > $O/${RD}_sampler_f32x3.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${RD}sx -- python3 $R/tools/sampler_profile.py 512 f32x3 > $O/${RD}_sampler_f32x3.log 2>&1
 cp $(ls $O/prof_${RD}sx/*/*kernel_stats.csv | head -1) $O/${RD}_sampler_f32x3_kernel_stats.csv
 # the raw traces are large: only the summaries above travel back
 rm -rf $O/prof_${RD}b $O/prof_${RD}s $O/prof_${RD}sf $O/prof_${RD}sx $O/pmc_${RD}_fetch $O/pmc_${RD}_write
