@@ -11,7 +11,7 @@ namespace {
 // operation, as in csrc/eval_f32.hip).  k_sgemm_smallk staged the whole K extent of BOTH operands per 32x32 tile -- the
 // batched embed Linear of a sampler evaluation (512 x 256 -> 5 376: networks._EmbedAllFn) re-read 176 MB through L2 and took
 // 121 us; this kernel gives a wave a 32x32 output block, a workgroup WM x WN of them, and walks K in chunks of 32 through LDS
-// (operands of any stride: forward, dgrad and wgrad of the Linears share it).  Split-K over gridDim.z as k_sgemm.
+// (operands of any stride: forward, dgrad and wgrad of the Linears share it).  Split-K over gridDim.z, partial sums by atomics.
 template <int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void k_sgemm_mfma(const float* __restrict__ A, long asm_, long ask,
                                                                const float* __restrict__ Bm, long bsk, long bsn,
@@ -19,6 +19,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_sgemm_mfma(const float* __rest
                                                                float alpha, int accumulate) {
   constexpr int TM = 32 * WM, TN = 32 * WN, TK = 32, NT = 64 * WM * WN;
   constexpr int LDA = TM + 1, LDB = TN + 1;        // odd row pitch: the k-contiguous staging writes hit distinct banks
+  constexpr int NA_ = TM * TK / NT, NB_ = TN * TK / NT;   // elements of a chunk per thread (compile-time: 8 / 8 or 8 / 16)
   __shared__ float As[TK * LDA];
   __shared__ float Bs[TK * LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -31,34 +32,45 @@ __global__ __launch_bounds__(64 * WM * WN) void k_sgemm_mfma(const float* __rest
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // A chunk's elements go global -> registers -> LDS, ALL loads of a chunk issued before the first is stored (the first form
+  // of this kernel stored each element behind its own load: 24 serial round trips per chunk, 51 us per call whatever the
+  // problem size), and the NEXT chunk's loads are in flight while this chunk is multiplied.
+  float ra[NA_], rb[NB_];
+  auto load_chunk = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NA_; ++i) {
+      const int e = tid + i * NT;
+      const int kk = ask == 1 ? (e & 31) : e / TM, mm = ask == 1 ? (e >> 5) : e % TM;
+      const int m = m0 + mm, k = k0 + kk;
+      ra[i] = (m < M && k < kend) ? A[m * asm_ + k * ask] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NB_; ++i) {
+      const int e = tid + i * NT;
+      const int kk = bsk == 1 ? (e & 31) : e / TN, nn = bsk == 1 ? (e >> 5) : e % TN;
+      const int n = n0 + nn, k = k0 + kk;
+      rb[i] = (n < N && k < kend) ? Bm[k * bsk + n * bsn] : 0.f;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA_; ++i) {
+      const int e = tid + i * NT;
+      const int kk = ask == 1 ? (e & 31) : e / TM, mm = ask == 1 ? (e >> 5) : e % TM;
+      As[kk * LDA + mm] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB_; ++i) {
+      const int e = tid + i * NT;
+      const int kk = bsk == 1 ? (e & 31) : e / TN, nn = bsk == 1 ? (e >> 5) : e % TN;
+      Bs[kk * LDB + nn] = rb[i];
+    }
+  };
+  if (kbeg < kend) load_chunk(kbeg);
   for (int k0 = kbeg; k0 < kend; k0 += TK) {
-    if (ask == 1) {          // k contiguous: a wave's half reads 32 consecutive k of one row
-      for (int e = tid; e < TM * TK; e += NT) {
-        const int kk = e & 31, mm = e >> 5;
-        const int m = m0 + mm, k = k0 + kk;
-        As[kk * LDA + mm] = (m < M && k < kend) ? A[m * asm_ + k] : 0.f;
-      }
-    } else {                 // rows contiguous (or general strides)
-      for (int e = tid; e < TM * TK; e += NT) {
-        const int mm = e % TM, kk = e / TM;
-        const int m = m0 + mm, k = k0 + kk;
-        As[kk * LDA + mm] = (m < M && k < kend) ? A[m * asm_ + k * ask] : 0.f;
-      }
-    }
-    if (bsk == 1) {
-      for (int e = tid; e < TN * TK; e += NT) {
-        const int kk = e & 31, nn = e >> 5;
-        const int n = n0 + nn, k = k0 + kk;
-        Bs[kk * LDB + nn] = (n < N && k < kend) ? Bm[k + n * bsn] : 0.f;
-      }
-    } else {
-      for (int e = tid; e < TN * TK; e += NT) {
-        const int nn = e % TN, kk = e / TN;
-        const int n = n0 + nn, k = k0 + kk;
-        Bs[kk * LDB + nn] = (n < N && k < kend) ? Bm[k * bsk + n * bsn] : 0.f;
-      }
-    }
+    store_chunk();
     __syncthreads();
+    if (k0 + TK < kend) load_chunk(k0 + TK);
 #pragma unroll
     for (int kk = 0; kk < TK; kk += 2) {
       const float a = As[(kk + lhi) * LDA + wm * 32 + l31];

@@ -1237,8 +1237,10 @@ def linear_dgrad(dy, w):
     K = w.shape[1]
     if w.shape[0] != N:
         raise ValueError("linear_dgrad: shape mismatch")
-    dx = torch.empty(M, K, device=dy.device, dtype=f32)
-    _lib.call("edm_linear_dgrad", _p(dy), _p(w), _p(dx), M, N, K, 0, _stream())
+    # (a pre-zeroed piece of the scratch pool + accumulate: the split-K form of the GEMM adds its partial sums with atomics and
+    # would otherwise clear dx with a memset node of its own in every captured step)
+    dx = zeros_f32((M, K), dy.device)
+    _lib.call("edm_linear_dgrad", _p(dy), _p(w), _p(dx), M, N, K, 1, _stream())
     return dx
 
 
