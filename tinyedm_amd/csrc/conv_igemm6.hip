@@ -371,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
   // ---- FOLD (round 6): the decoder block's 512 -> 256 skip projection as a second reduction on the same accumulators
   // (common.h, ModEpilogue::X2).  A chunk of it is ONE step (centre tap only): a fresh 512-row slab (32 KB, no halo) and a
   // weight tile per 8 NI MFMAs -- nine times the staging traffic per MFMA of the 3x3 part -- so this phase runs at what the
-  // L2 -> LDS path delivers, not at the matrix pipe's rate (wait + barrier per chunk, two chunks in flight).  It still beats
+  // L2 -> LDS path delivers, not at the matrix pipe's rate (wait + barrier per chunk, three chunks in flight).  It still beats
   // the separate launch it replaces (68 us at 32x32 x 128): no second kernel boundary, no [pixels][Cout] round trip through HBM.
   if constexpr (FOLD) {
     lgkm_wait<0>();                // the last step's (unused) prefetch
@@ -405,10 +405,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
       woff2 = (unsigned)(((long)co * mod.C2 + c * 8) * 2);
     }
     const char* const w2base = reinterpret_cast<const char*>(mod.W2);
-    // phase-2 LDS layout: three slots of [512-row slab (32 KB) | weight tile] carved out of the slab + ring regions, TWO
-    // chunks in flight behind the one being multiplied (with one, every chunk waited a whole L2 -> LDS round trip: the
-    // phase took as long as the launch it replaces)
-    constexpr int SLAB2 = BMW * ROWB, SLOT2 = SLAB2 + WTILE, NS2 = 3;
+    // phase-2 LDS layout: four slots of [512-row slab (32 KB) | weight tile] over the slab + ring regions (the launch asks for
+    // the larger of the two phases' LDS), THREE chunks in flight behind the one being multiplied (with one, every chunk waited
+    // a whole L2 -> LDS round trip and the phase took as long as the launch it replaces; two: 1.4 us per chunk)
+    constexpr int SLAB2 = BMW * ROWB, SLOT2 = SLAB2 + WTILE, NS2 = 4;   // (four slots = all 160 KB of a CU's LDS at NI = 4)
     static_assert(NS2 * SLOT2 <= 160 * 1024, "phase-2 slots must fit LDS (launch6 asks for the larger of the two phases)");
     const int q2 = wave * 64 + l15;
     const unsigned bp2 = xb_off + q2 * ROWB + ((lq ^ ((q2 >> 2) & 3)) << 4);
@@ -422,12 +422,15 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
     };
     issue2(0);
     if (n2 > 1) issue2(1);
+    if (n2 > 2) issue2(2);
 #pragma unroll 1
     for (int c = 0; c < n2; ++c) {
-      if (c + 1 < n2) wait_vmcnt<5>();   // this wave's five pieces of chunk c (chunk c + 1 may still be in flight) ...
+      // this wave's five pieces of chunk c (chunks c + 1 and c + 2 may still be in flight) ...
+      if (c + 2 < n2) wait_vmcnt<10>();
+      else if (c + 1 < n2) wait_vmcnt<5>();
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();      // ... and everybody's; every wave has read its fragments of chunk c - 1
-      if (c + 2 < n2) issue2(c + 2);     // into the slot chunk c - 1 was read from
+      if (c + 3 < n2) issue2(c + 3);     // into the slot chunk c - 1 was read from
       const unsigned so = (unsigned)((c % NS2) * SLOT2);
       const unsigned aa = ap2 + so, bb = bp2 + so;
       u32x4 fa2[NA], fb2[NB];
@@ -504,7 +507,7 @@ void launch6(const void* X, const void* Wp, void* Y, const void* R, float alpha,
              int Cin, int Cout, const ModEpilogue& mod, hipStream_t st) {
   const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + 32 * NI - 1) / (32 * NI);
   size_t lds = (size_t)2 * NX * 8 * 16 * ROWB + WRING * (32 * NI * ROWB) + (EPI == 1 ? 8 * 32 * NI * 4 : 0);
-  if (FOLD && lds < (size_t)3 * (BM * ROWB + 32 * NI * ROWB)) lds = (size_t)3 * (BM * ROWB + 32 * NI * ROWB);   // phase 2: three slots
+  if (FOLD && lds < (size_t)4 * (BM * ROWB + 32 * NI * ROWB)) lds = (size_t)4 * (BM * ROWB + 32 * NI * ROWB);   // phase 2: four slots
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
   auto kern = k_conv3x3_v6<NX, EPI, NI, true, WB, false, FOLD>;
   EDM_MAX_LDS(kern, 160 * 1024);
