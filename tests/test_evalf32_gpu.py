@@ -444,3 +444,46 @@ def test_split_conv_folded_projection_vs_fp64(ops, B, H, W, C, Cout, C2):
     yp = ops.f32_to_pairs(y)
     assert torch.equal(cat[..., :Cout], yp[..., :Cout]) and torch.equal(cat[..., Ct:Ct + Cout], yp[..., Cout:])
     assert float(cat[..., Cout:Ct].abs().max()) == 0.0 and float(sil[..., Cout:Ct].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,H,W,Cout", [(128, 32, 32, 256), (130, 16, 16, 192)])
+def test_split_conv_staged_epilogue_matches_the_direct_one(ops, B, H, W, Cout, monkeypatch):
+    """Round 6: the fp32 epilogue of the split 3x3 conv staged through wave-private LDS (row-contiguous stores; default)
+    against the round-4 form straight from the accumulator layout (EDM_F32_EPI_STAGED=0), every output form: the same values
+    (to the last-bit freedom hipcc has in contracting alpha * acc + beta * r)."""
+    g = torch.Generator().manual_seed(B + W + Cout)
+    C = 256
+    xp = ops.f32_to_pairs(torch.randn(B, H, W, C, generator=g).to(DEV))
+    res = torch.randn(B, H, W, Cout, generator=g).to(DEV)
+    pk = ops.split_pack((torch.randn(Cout, C * 9, generator=g) / (C * 9) ** 0.5).to(DEV), 9)
+    lin = torch.randn(B, Cout, generator=g).to(DEV)
+    gain = torch.tensor(0.6, device=DEV)
+    Ct = Cout + 64
+
+    def forms():
+        out = {}
+        out["fp32+R"] = ops.split_conv(xp, pk, 9, residual=res, alpha=0.8, beta=0.6)
+        out["pairs+mod"] = ops.split_conv(xp, pk, 9, lin=lin, gain=gain, pairs_out=True)
+        y, yp = ops.split_conv(xp, pk, 9, residual=res, alpha=0.8, beta=0.6, also_pairs=True)
+        out["both.y"], out["both.p"] = y, yp
+        y, ys = ops.split_conv(xp, pk, 9, residual=res, alpha=0.8, beta=0.6, silu_pairs=True)
+        out["silu.y"], out["silu.p"] = y, ys
+        cat = torch.zeros(B, H, W, 2 * Ct, device=DEV, dtype=torch.bfloat16)
+        sil = torch.zeros_like(cat)
+        ops.split_conv(xp, pk, 9, residual=res, alpha=0.8, beta=0.6, dest=(cat, sil))
+        out["dest.cat"], out["dest.sil"] = cat, sil
+        return out
+
+    def val(t):
+        if t.dtype == torch.bfloat16:
+            h = t.shape[-1] // 2
+            return t[..., :h].float() + t[..., h:].float()
+        return t
+
+    staged = forms()
+    monkeypatch.setenv("EDM_F32_EPI_STAGED", "0")
+    direct = forms()
+    for k in staged:
+        a, b = val(staged[k]), val(direct[k])
+        assert (a - b).abs().max().item() <= 2.0 ** -15 * b.abs().max().item(), k
+    assert rel(staged["fp32+R"], direct["fp32+R"]) <= 1e-6

@@ -532,11 +532,17 @@ __device__ __forceinline__ void store_tile_transposed16(const f32x4 (&acc)[2 * N
 //                                               dropout) -- the exact functions, as k_conv_f32's epilogue.
 // Straight from the accumulator layout: a lane holds 4 consecutive channels of one pixel -> one 16-byte load / store per
 // block (64-byte row segments per instruction: an evaluation-path epilogue, not tuned).
+__device__ __forceinline__ void f32_out4v(float* __restrict__ Y, const float* __restrict__ R, float beta, long px, long Npix,
+                                          int co, int Cout, const ModEpilogue& mod, float gain, f32x4 v);
 __device__ __forceinline__ void f32_out4(float* __restrict__ Y, const float* __restrict__ R, float alpha, float beta,
                                          long px, long Npix, int co, int Cout, const ModEpilogue& mod, float gain,
                                          float v0, float v1, float v2, float v3) {
+  f32_out4v(Y, R, beta, px, Npix, co, Cout, mod, gain, f32x4{alpha * v0, alpha * v1, alpha * v2, alpha * v3});
+}
+// (v = alpha * acc already)
+__device__ __forceinline__ void f32_out4v(float* __restrict__ Y, const float* __restrict__ R, float beta, long px, long Npix,
+                                          int co, int Cout, const ModEpilogue& mod, float gain, f32x4 v) {
   if (px >= Npix || co >= Cout) return;
-  f32x4 v = {alpha * v0, alpha * v1, alpha * v2, alpha * v3};
   const long e = px * Cout + co;
   if (R) {
     const f32x4 r = *reinterpret_cast<const f32x4*>(R + e);
@@ -592,6 +598,36 @@ __device__ __forceinline__ void store_tile_f32(const f32x16 (&acc)[NI][NJ], floa
       for (int g = 0; g < 4; ++g)
         f32_out4(Y, R, alpha, beta, mb0 + 32 * j + l31, Npix, cw0 + 32 * i + 8 * g + 4 * lhi, Cout, mod, gain,
                  acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+}
+// The same epilogue STAGED through wave-private LDS (round 6): straight from the accumulator layout a store instruction
+// covers 16 pixels x 64 bytes (fp32) or x 32 bytes (a pairs half) -- and the `dest` form of the split evaluation's copy-free
+// concat issues four such 8-byte-per-lane stores per 16-byte fp32 store: +252 us per 32x32 launch at batch 512 where the
+// extra bytes alone are +107 (tools/microbench_split_epi.py).  Here a 16-pixel block goes to LDS as floats
+// [16 px][NI * 32 ch] (row pitch + 16 bytes) and leaves row-contiguously: a lane owns four consecutive channels of a pixel,
+// NI * 8 lanes cover a row -- 512-byte (256-byte: pairs) segments per row and instruction, R read the same way.
+// `stage`: 16 * (NI * 128 + 16) bytes per wave, behind a workgroup barrier after the main loop's last LDS read.
+template <int NI, int NJ>
+__device__ __forceinline__ void store_tile_f32_16_staged(const f32x4 (&acc)[2 * NI][2 * NJ], char* stage,
+                                                         float* __restrict__ Y, const float* __restrict__ R, float alpha,
+                                                         float beta, long mb0, long Npix, int cw0, int Cout,
+                                                         const ModEpilogue& mod) {
+  constexpr int SROW = NI * 128 + 16, LPR = NI * 8, RPP = 64 / LPR, NPASS = 16 / RPP;
+  const int lane = threadIdx.x & 63, l15 = lane & 15, lq = lane >> 4;
+  const int c4 = lane % LPR, prow = lane / LPR;
+  const float gain = mod.lin ? *mod.gain : 0.f;
+#pragma unroll
+  for (int j = 0; j < 2 * NJ; ++j) {
+#pragma unroll
+    for (int i = 0; i < 2 * NI; ++i)
+      *reinterpret_cast<f32x4*>(stage + l15 * SROW + (16 * i + 4 * lq) * 4) =
+          f32x4{alpha * acc[i][j][0], alpha * acc[i][j][1], alpha * acc[i][j][2], alpha * acc[i][j][3]};
+#pragma unroll
+    for (int it = 0; it < NPASS; ++it) {
+      const int px = it * RPP + prow;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(stage + px * SROW + c4 * 16);
+      f32_out4v(Y, R, beta, mb0 + 16 * j + px, Npix, cw0 + c4 * 4, Cout, mod, gain, v);
+    }
+  }
 }
 // v_mfma_f32_16x16x32 accumulators (k_conv3x3_v6): rows = channels 16 i + 4 (lane >> 4) + r, columns = pixels 16 j + (lane & 15)
 template <int NI, int NJ>

@@ -102,6 +102,12 @@ extern "C" int edm_conv3x3_fold(const void* X, const void* Wp, const void* X2, l
 // Y = alpha * conv + beta * R, or Y = mp_silu(conv * (lin[b,:] * gain + 1)) when lin is given -- Y, R FLOATS; Ypairs
 // (optional, Y may then be NULL): the same result as [pixels][2 Cout] bf16 pairs, ready to be the next conv's Xp.
 // C % 32 == 0 (3x3 on the static-schedule kernel: C % 64 == 0, W <= 64; anything else on k_conv_igemm).
+// EDM_F32_EPI_STAGED=0: the fp32 epilogue of k_conv3x3_v6 straight from the accumulator layout (round 4/5; A/B runs)
+static int split_epi_unstaged() {     // -> ModEpilogue.wfrag of an EPI-4 launch of k_conv3x3_v6: 1 = straight from the accumulators
+  const char* e = getenv("EDM_F32_EPI_STAGED");
+  return (e && e[0] == '0') ? 1 : 0;
+}
+
 // edm_split_conv_o: the same with an OUTPUT DESCRIPTOR for the pairs (round 6): rows of ld_pairs elements (0 = 2 Cout) with
 // the lo halves lo_off elements behind the hi halves (0 = Cout) -- the left column blocks of the next decoder block's
 // concatenated operand [hi(Ci + Cs) | lo(Ci + Cs)] -- and Ysilu_pairs (optional): mp_silu of the result as pairs at the same
@@ -145,7 +151,9 @@ static int split_conv_impl(const void* Xp, const void* Wp3, float* Y, void* Ypai
   const int K = 3 * C;
   const long npix = (long)B * H * W;
   if (taps == 9 && C % 64 == 0 && W <= 64 && edm_conv_tall_worthwhile(npix, Cout)) {
-    const int rc = edm_conv_igemm_v6_ex(Xp, Wp3, Y, R, alpha, beta, B, H, W, K, Cout, 9, mod, st);
+    ModEpilogue m6 = mod;
+    m6.wfrag = split_epi_unstaged();     // (A/B switch of the staged fp32 epilogue; not a weight-pack matter here)
+    const int rc = edm_conv_igemm_v6_ex(Xp, Wp3, Y, R, alpha, beta, B, H, W, K, Cout, 9, m6, st);
     if (rc != EDM_ERR_UNSUPPORTED) return rc;
   }
   // round 6: the small-map kernel for the 8x8-class 3x3 layers that are too small for the static-schedule kernel (batch 256:
@@ -194,6 +202,7 @@ extern "C" int edm_split_conv_fold(const void* Xp, const void* Wp3, const void* 
   mod.ldX2 = 2 * C2;
   mod.kwrap2 = C2 / 32;
   mod.fold_scale = alpha3 / alpha1;
+  mod.wfrag = split_epi_unstaged();
   return edm_conv_igemm_v6_ex(Xp, Wp3, Y, nullptr, alpha1, 0.0f, B, H, W, 3 * C, Cout, 9, mod, st);
 }
 

@@ -489,8 +489,18 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
       }
     }
   } else if constexpr (EPI == 4) {
-    store_tile_f32_16<NI, NJ>(acc, reinterpret_cast<float*>(Y), reinterpret_cast<const float*>(R), alpha, beta,
-                              (long)m0 + wave * (32 * NJ), Npix, n0, Cout, mod);
+    // (round 6: row-contiguous through wave-private LDS.  tools/microbench_split_epi.py, 32x32 x 512: the two pairs buffers of
+    // the copy-free concat 1 774 -> 1 522 us, fp32 + pairs 1 578 -> 1 494, a single fp32 stream 1 411 -> 1 446 in isolation --
+    // but in the solve staging EVERY form is the fastest policy (A/B/C in one call: 206.6 / 207.6 / 209.8 img/s for never /
+    // only multi-stream tiles / always; the modulation factors are read once per lane instead of once per accumulator block).
+    // mod.wfrag carries the A/B switch EDM_F32_EPI_STAGED=0, set by the dispatcher)
+    if (mod.wfrag)
+      store_tile_f32_16<NI, NJ>(acc, reinterpret_cast<float*>(Y), reinterpret_cast<const float*>(R), alpha, beta,
+                                (long)m0 + wave * (32 * NJ), Npix, n0, Cout, mod);
+    else
+      store_tile_f32_16_staged<NI, NJ>(acc, smem + wave * (16 * (NI * 128 + 16)), reinterpret_cast<float*>(Y),
+                                       reinterpret_cast<const float*>(R), alpha, beta, (long)m0 + wave * (32 * NJ), Npix, n0,
+                                       Cout, mod);
   } else {
     store_tile_transposed16<NI, NJ, EPI>(acc, smem + wave * (32 * (NI * 64 + 16)), Y, R, alpha, beta,
                                          (long)m0 + wave * (32 * NJ), Npix, n0, Cout, mod);
@@ -523,7 +533,7 @@ void launch6(const void* X, const void* Wp, void* Y, const void* R, float alpha,
 int edm_conv_igemm_v6_ex(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
                          int W, int Cin, int Cout, int taps, const ModEpilogue& mod, hipStream_t st) {
   EDM_REQUIRE(X && Wp && (Y || mod.Y2), "conv_igemm_v6: null pointer");
-  EDM_REQUIRE(!mod.wfrag, "conv_igemm_v6: fragment-major weight packs are read by k_conv3x3_s only");
+  EDM_REQUIRE(!mod.wfrag || mod.mode == 4, "conv_igemm_v6: fragment-major weight packs are read by k_conv3x3_s only");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && (long)B * H * W < (1L << 31), "conv_igemm_v6: bad B/H/W");
   EDM_REQUIRE(Cout > 0 && Cout % 8 == 0, "conv_igemm_v6: Cout %% 8 required");
   if (taps != 9 || Cin <= 0 || Cin % 64 != 0 || Cin * 2 + 64 > ZERO_PAGE || W > 64) return EDM_ERR_UNSUPPORTED;
