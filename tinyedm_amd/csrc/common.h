@@ -583,6 +583,32 @@ __device__ __forceinline__ void f32_out4v(float* __restrict__ Y, const float* __
     }
   }
 }
+// staged form for the v_mfma_f32_32x32x16 layout (k_conv_igemm's 1x1 / small-map split convs; see store_tile_f32_16_staged):
+// a 32-pixel block of the wave's NI * 32 channels through LDS as floats, out in rows.  stage: 32 * (NI * 128 + 16) bytes per wave.
+template <int NI, int NJ>
+__device__ __forceinline__ void store_tile_f32_staged(const f32x16 (&acc)[NI][NJ], char* stage, float* __restrict__ Y,
+                                                      const float* __restrict__ R, float alpha, float beta, long mb0, long Npix,
+                                                      int cw0, int Cout, const ModEpilogue& mod) {
+  constexpr int SROW = NI * 128 + 16, LPR = NI * 8, RPP = 64 / LPR, NPASS = 32 / RPP;
+  const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int c4 = lane % LPR, prow = lane / LPR;
+  const float gain = mod.lin ? *mod.gain : 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(stage + l31 * SROW + (32 * i + 8 * g + 4 * lhi) * 4) =
+            f32x4{alpha * acc[i][j][4 * g], alpha * acc[i][j][4 * g + 1], alpha * acc[i][j][4 * g + 2], alpha * acc[i][j][4 * g + 3]};
+#pragma unroll
+    for (int it = 0; it < NPASS; ++it) {
+      const int px = it * RPP + prow;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(stage + px * SROW + c4 * 16);
+      f32_out4v(Y, R, beta, mb0 + 32 * j + px, Npix, cw0 + c4 * 4, Cout, mod, gain, v);
+    }
+  }
+}
 // v_mfma_f32_32x32x16 accumulators (k_conv_igemm): rows = channels 32 i + 8 g + 4 lhi + r, columns = pixels 32 j + l31
 template <int NI, int NJ>
 __device__ __forceinline__ void store_tile_f32(const f32x16 (&acc)[NI][NJ], float* __restrict__ Y, const float* __restrict__ R,

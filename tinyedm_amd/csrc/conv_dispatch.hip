@@ -172,7 +172,9 @@ static int split_conv_impl(const void* Xp, const void* Wp3, float* Y, void* Ypai
   }
   if (v2 && taps == 1 && ((npix + 255) / 256) * ((Cout + 127) / 128) >= 512)
     return edm_conv_igemm_v2_ex(Xp, Wp3, Y, R, alpha, beta, B, H, W, K, Cout, 1, mod, st);
-  return edm_conv_igemm_v1_ex(Xp, Wp3, Y, R, alpha, beta, B, H, W, K, Cout, taps, mod, st);
+  ModEpilogue m1 = mod;
+  m1.wfrag = split_epi_unstaged();
+  return edm_conv_igemm_v1_ex(Xp, Wp3, Y, R, alpha, beta, B, H, W, K, Cout, taps, m1, st);
 }
 
 // The folded skip projection (edm_conv3x3_fold) for the split-bf16 evaluation: Y = alpha3 * conv3x3(Xp, Wp3) + alpha1 *

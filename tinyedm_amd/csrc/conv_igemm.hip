@@ -182,10 +182,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const bf16* __restrict__ 
 
   // ---- epilogue: transposed through wave-private LDS (common.h: store_tile_transposed)
   __syncthreads();  // every wave is done with the staged tiles
-  if constexpr (EPI == 4)
-    store_tile_f32<2, NJ>(acc, reinterpret_cast<float*>(Y), reinterpret_cast<const float*>(R), alpha, beta,
-                          (long)m0 + wn * (32 * NJ), Npix, n0 + wm * 64, Cout, mod);
-  else
+  if constexpr (EPI == 4) {
+    // (round 6: staged through wave-private LDS -- 4 waves x 8.7 KB of the slab / ring area -- like k_conv3x3_v6's;
+    // mod.wfrag = the A/B switch EDM_F32_EPI_STAGED=0)
+    if (mod.wfrag)
+      store_tile_f32<2, NJ>(acc, reinterpret_cast<float*>(Y), reinterpret_cast<const float*>(R), alpha, beta,
+                            (long)m0 + wn * (32 * NJ), Npix, n0 + wm * 64, Cout, mod);
+    else
+      store_tile_f32_staged<2, NJ>(acc, smem + (wm * 2 + wn) * (32 * (2 * 128 + 16)), reinterpret_cast<float*>(Y),
+                                   reinterpret_cast<const float*>(R), alpha, beta, (long)m0 + wn * (32 * NJ), Npix,
+                                   n0 + wm * 64, Cout, mod);
+  } else
   store_tile_transposed<2, NJ, EPI>(acc, smem + (wm * 2 + wn) * (32 * (2 * 64 + 16)), Y, R, alpha, beta,
                                (long)m0 + wn * (32 * NJ), Npix, n0 + wm * 64, Cout, mod);
 }
@@ -197,7 +204,8 @@ int launch(const void* X, const void* Wp, void* Y, const void* R, float alpha, f
   const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + BN - 1) / BN;
   const int HALO = (TAPS == 9) ? (W + 1) : 0;
   const int xrows = BM + 2 * HALO;
-  const size_t lds = ((xrows * Cfg<KC>::ROWB + 15) & ~15) + 2 * BN * Cfg<KC>::ROWB;
+  size_t lds = ((xrows * Cfg<KC>::ROWB + 15) & ~15) + 2 * BN * Cfg<KC>::ROWB;
+  if (EPI == 4 && lds < (size_t)4 * 32 * (2 * 128 + 16)) lds = (size_t)4 * 32 * (2 * 128 + 16);   // the staged fp32 epilogue's area
   const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
   auto kern = k_conv_igemm<TAPS, KC, XL, NJ, EPI>;
   EDM_MAX_LDS(kern, 160 * 1024);
@@ -223,7 +231,7 @@ int launch(const void* X, const void* Wp, void* Y, const void* R, float alpha, f
 int edm_conv_igemm_v1_ex(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int B, int H,
                          int W, int Cin, int Cout, int taps, const ModEpilogue& mod, hipStream_t st) {
   EDM_REQUIRE(X && Wp && (Y || mod.Y2), "conv_igemm: null pointer");
-  EDM_REQUIRE(!mod.wfrag, "conv_igemm: fragment-major weight packs are read by k_conv3x3_s only");
+  EDM_REQUIRE(!mod.wfrag || mod.mode == 4, "conv_igemm: fragment-major weight packs are read by k_conv3x3_s only");
   EDM_REQUIRE(mod.mode == 0 || mod.mode == 3 || mod.mode == 4 || taps == 9, "conv_igemm: the backward epilogues are 3x3 only");
   EDM_REQUIRE(B > 0 && H > 0 && W > 0 && (long)B * H * W < (1L << 31), "conv_igemm: bad B/H/W");
   EDM_REQUIRE(taps == 1 || taps == 9, "conv_igemm: taps must be 1 or 9 (got %d)", taps);
