@@ -295,3 +295,33 @@ def test_launch_probe_verdict_follows_the_timed_blocks_only():
         probe2 = TR._LaunchProbe(Clock())
         probe2.choose(Captured, batch)
         assert probe2.choose(Captured, (torch.zeros(2, 3, 8, 8), None)) is False and probe2.n == 1 - probe2.WARM_STEPS["eager"]
+
+
+def test_capture_token_releases_slots_and_plan_pins_once():
+    """what a captured graph holds on to -- launch-table slots and pinned weight-prep plans -- goes back when
+    ops.release_capture() gets its token, exactly once (host logic only: no GPU call)."""
+    from tinyedm_amd import ops
+
+    class Plan:
+        pins = 0
+
+    t = ops._LaunchTables()
+    t.dev[0] = {"free": [], "key": 0}
+    a, b = Plan(), Plan()
+    t.deferring, t.pins = True, []
+    saved = ops._tables
+    ops._tables = t
+    try:
+        assert ops.note_capture_pin(a) and ops.note_capture_pin(a) and ops.note_capture_pin(b)     # a plan is pinned once per capture
+        assert (a.pins, b.pins) == (1, 1)
+        tok = ops._CaptureToken(((0, 3), (0, 5)), tuple(t.pins))
+        t.deferring = False
+        assert not ops.note_capture_pin(a) and a.pins == 1          # outside a capture_begin() / capture_end() pair: not counted
+        assert list(tok) == [(0, 3), (0, 5)] and len(tok) == 2
+        ops.release_capture(tok)
+        assert (a.pins, b.pins) == (0, 0) and sorted(t.dev[0]["free"]) == [3, 5]
+        ops.release_capture(tok)                                    # a second release is a no-op
+        assert (a.pins, b.pins) == (0, 0) and sorted(t.dev[0]["free"]) == [3, 5]
+        ops.release_capture(None)
+    finally:
+        ops._tables = saved
