@@ -796,3 +796,58 @@ def test_conv3x3_fold_skip_projection(ops, B, H, W, Cin, Cout, C2, imgs, dest):
     if not dest:
         y0 = ops.conv_igemm(xh, pack_fwd(w3), 9, residual=ops.conv_igemm(x2h, pack_fwd(w1), 1), alpha=a3, beta=a1)
         assert rel(y.float(), y0.float()) <= 4e-3
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(128, 32, 32, 256, 256),     # training batch: two tiles per workgroup
+                                             (130, 32, 32, 64, 256),      # 260 pixel tiles: two or three per workgroup
+                                             (512, 16, 16, 256, 256),     # the samplers' 16x16 layers (two images per tile)
+                                             (200, 32, 32, 64, 384)])     # three channel tiles: 240 workgroups, ragged walk
+def test_persistent_conv3x3_walks_its_tiles_like_single_tile_workgroups(ops, B, H, W, Cin, Cout):
+    """k_conv3x3_v6's persistent form (round 6, opt-in: a workgroup walks several pixel tiles, the next tile's slab and first
+    weight tiles landing under the epilogue) against the same kernel with one tile per workgroup (EDM_V6_PERSIST, read per
+    call): bit-identical outputs for the epilogues it is built for -- plain (+ residual, + the strided / silu output
+    descriptor), forward modulation, the split-bf16 fp32 form -- and, on sampled images, against the fp64 convolution."""
+    import os
+    from tinyedm_amd import _lib
+    g = torch.Generator().manual_seed(B + Cin + Cout)
+    x = nhwc(q(torch.randn(B, Cin, H, W, generator=g)))
+    wf = q(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9))
+    wp = pack_fwd(wf)
+    res = nhwc(q(torch.randn(B, Cout, H, W, generator=g)))
+    lin = torch.randn(B, Cout + 24, generator=g).to(DEV)[:, 8:8 + Cout]
+    gain = torch.tensor(0.6, device=DEV)
+    wide = torch.zeros(B, H, W, Cout + 64, device=DEV, dtype=torch.bfloat16)
+    wide2 = torch.zeros_like(wide)
+    xp = ops.f32_to_pairs(x.float())
+    pk = ops.split_pack(wf.reshape(Cout, -1).contiguous().to(DEV), 9) if Cin <= 256 else None
+
+    def run():
+        out = {}
+        out["plain"] = ops.conv_igemm(x, wp, 9, alpha=0.9)
+        out["res"] = ops.conv_igemm(x, wp, 9, residual=res, alpha=0.7, beta=0.6)
+        wide.zero_(); wide2.zero_()
+        ops.conv_igemm(x, wp, 9, out=wide[..., :Cout], silu_out=wide2[..., :Cout])
+        out["desc"], out["desc_silu"] = wide.clone(), wide2.clone()
+        out["u"], out["a2"] = ops.conv3x3_mod(x, wp, lin, gain, 0.13, 77, 1, 2)
+        if pk is not None:
+            out["split"] = ops.split_conv(xp, pk, 9, alpha=0.8)
+        return out
+
+    prev = os.environ.get("EDM_V6_PERSIST")
+    try:
+        os.environ["EDM_V6_PERSIST"] = "0"
+        ref = run()
+        os.environ["EDM_V6_PERSIST"] = "1"
+        n0 = _lib.call("edm_v6_persistent_launches")
+        got = run()
+        assert _lib.call("edm_v6_persistent_launches") - n0 >= 5       # the form under test is the one that ran
+    finally:
+        if prev is None:
+            os.environ.pop("EDM_V6_PERSIST", None)
+        else:
+            os.environ["EDM_V6_PERSIST"] = prev
+    for k, v in ref.items():
+        assert torch.equal(got[k], v), k
+    for b in (0, B // 2, B - 1):       # and against the definition
+        want = 0.9 * F.conv2d(x[b:b + 1].permute(0, 3, 1, 2).double(), wf.double().to(DEV), padding=1)
+        assert rel(got["plain"][b:b + 1].permute(0, 3, 1, 2).double(), want) <= 6e-3

@@ -133,11 +133,12 @@ DIAG_SIGNATURES = {
     "edm_conv_igemm_v2_stamp": [P, P, P, I, I, I, I, I, P, P],
     "edm_conv_igemm_v2_ablate": [P, P, P, I, I, I, I, I, I, P],
     "edm_wgrad3_probe": [P, P],
+    "edm_v6_persistent_launches": [],
 }
-_RET = {"edm_last_error": ctypes.c_char_p, "edm_wgrad3_workspace": ctypes.c_long, "edm_wgrad3_table_bytes": ctypes.c_long,
+_RET = {"edm_last_error": ctypes.c_char_p, "edm_v6_persistent_launches": ctypes.c_long, "edm_wgrad3_workspace": ctypes.c_long, "edm_wgrad3_table_bytes": ctypes.c_long,
         "edm_skip_gate_wgrad_multi_table_bytes": ctypes.c_long,
         "edm_conv_wgrad_1x1_group_table_bytes": ctypes.c_long, "edm_wgrad_finish_multi_table_bytes": ctypes.c_long}
-_NO_STATUS = {"edm_conv3x3_fold_supported", "edm_skip_gate_wgrad_multi_table_bytes", "edm_version", "edm_graph_replay_safe", "edm_last_error", "edm_conv_wgrad_nsplit", "edm_conv_wgrad_1x1_nsplit", "edm_conv_wgrad_1x1_nsplit_grouped", "edm_wgrad3_workspace", "edm_wgrad3_table_bytes",
+_NO_STATUS = {"edm_v6_persistent_launches", "edm_conv3x3_fold_supported", "edm_skip_gate_wgrad_multi_table_bytes", "edm_version", "edm_graph_replay_safe", "edm_last_error", "edm_conv_wgrad_nsplit", "edm_conv_wgrad_1x1_nsplit", "edm_conv_wgrad_1x1_nsplit_grouped", "edm_wgrad3_workspace", "edm_wgrad3_table_bytes",
               "edm_conv_wgrad_1x1_group_table_bytes", "edm_wgrad_finish_multi_table_bytes", "edm_attention_qkv_supported"}
 
 _lib = None

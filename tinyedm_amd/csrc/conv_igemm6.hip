@@ -59,34 +59,29 @@ __device__ __forceinline__ void lgkm_wait() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-#ifdef EDM_V6_TIMELINE   // diagnostic build only (tools/v6_timeline.py): per-workgroup timestamps of the kernel's phases
+#ifdef EDM_V6_TIMELINE   // diagnostic build only (tools/v6_timeline.py): per-(workgroup, tile) timestamps of the kernel's phases
 __device__ unsigned long long* g_v6_timeline = nullptr;
+#define V6_ROW ((long)blockIdx.x + (long)tl_iter * gridDim.x)
 #define V6_STAMP(slot)                                                                                          \
-  if (g_v6_timeline && threadIdx.x == 0) g_v6_timeline[(long)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime()
+  if (g_v6_timeline && threadIdx.x == 0) g_v6_timeline[V6_ROW * 8 + (slot)] = __builtin_amdgcn_s_memrealtime()
 // the SHADER clock (s_memtime) at the same point: (d memtime) / (d memrealtime) x 100 MHz is the clock the chip holds there
 #define V6_CLK(slot)                                                                                            \
-  if (g_v6_timeline && threadIdx.x == 0) g_v6_timeline[(long)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime()
+  if (g_v6_timeline && threadIdx.x == 0) g_v6_timeline[V6_ROW * 8 + (slot)] = __builtin_amdgcn_s_memtime()
 #else
 #define V6_STAMP(slot)
 #define V6_CLK(slot)
 #endif
 
-template <int NX, int EPI = 0, int NI = 4, bool WPTR64 = true, int WB = 0, bool LATE_DMA = false, bool FOLD = false>
+template <int NX, int EPI = 0, int NI = 4, bool WPTR64 = true, int WB = 0, bool LATE_DMA = false, bool FOLD = false,
+          bool PERSIST = false>
 __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ X, const bf16* __restrict__ Wp,
                                                          bf16* __restrict__ Y, const bf16* __restrict__ R,
                                                          const char* __restrict__ zeros, float alpha, float beta,
                                                          int Npix, int H, int W, int Cin, int Cout, int tiles_m,
                                                          int tiles_n, ModEpilogue mod) {
   apply_dyn(mod);
-  V6_STAMP(0);
 #ifdef EDM_V6_TIMELINE
-  if (g_v6_timeline && threadIdx.x == 0) {
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    g_v6_timeline[(long)blockIdx.x * 8 + 5] = ((unsigned long long)xcc << 32) | hw;
-  }
+  int tl_iter = 0;
 #endif
   constexpr int NJ = 2;               // 32-pixel blocks per wave (epilogue units)
   constexpr int NA = 2 * NI, NAH = NI;  // 16-channel weight fragments per step / per half
@@ -104,15 +99,41 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
   // behind the slab and ring buffers) and leave as one global atomic per sample and channel of the tile
   float* const gmred = reinterpret_cast<float*>(smem + 2 * XBYTES + WRING * WTILE);
 
+  static_assert(!PERSIST || (!FOLD && !LATE_DMA && NX == 5), "persistent form: 5-slot slab, no folded phase");
   const int id = blockIdx.x;
   const int xcd = id & 7, k = id >> 3;
-  const int tn = k % tiles_n, tm = (k / tiles_n) * 8 + xcd;
+  const int tn = k % tiles_n;
+  int tm = (k / tiles_n) * 8 + xcd;
   if (tm >= tiles_m) return;
-  const int m0 = tm * BMW, n0 = tn * BNW;
+  // PERSIST (round 6): a workgroup walks the pixel tiles tm, tm + tm_step, ... of ONE channel tile (host: gridDim.x / 8 is a
+  // multiple of tiles_n, so the XCD and tn of a workgroup's tiles do not change).  The weight ring simply keeps turning
+  // across the tile boundary (tile (chunk 0, tap t) of the next pixel tile IS the ring's next tile) and the next tile's
+  // first slab is issued at tap 0 of this tile's last chunk, so both land under the epilogue: every tile but a
+  // workgroup's first starts with its prologue already done (tools/v6_timeline.py: 3.1 us of a 57-us tile).
+  const int tm_step = PERSIST ? ((int)(gridDim.x >> 3) / tiles_n) * 8 : 0;
+  int m0 = tm * BMW;
+  const int n0 = tn * BNW;
   const int HALO = W + 1;
   const int xrows = BMW + 2 * HALO;
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  int tid_v = threadIdx.x;
+  bool first_tile = true;
+  for (;;) {   // the pixel tiles of this workgroup (exactly one unless PERSIST)
+  // PERSIST: every per-lane address below is re-derived per tile from an opaque copy of the thread index, so that none of
+  // them (~45 registers) stays live across the epilogue (kept live, the 128-channel forms spill 28-123 registers)
+  if constexpr (PERSIST) asm volatile("" : "+v"(tid_v));
+  V6_STAMP(0);
+#ifdef EDM_V6_TIMELINE
+  if (g_v6_timeline && threadIdx.x == 0) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_v6_timeline[V6_ROW * 8 + 5] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
+  const bool next_tile = PERSIST ? (tm + tm_step < tiles_m) : false;
+  const int tid = tid_v, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = pixel octant of this wave
   const int l15 = lane & 15, lq = lane >> 4;
   const int drow = lane >> 2, dp = lane & 3;  // DMA lane -> (row in 16-row slot, physical 16-B piece)
@@ -135,26 +156,29 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
   const char* const wsrc = wbase + woff;      // NI == 2 (registers to spare): plain per-lane pointer, as k_conv3x3_v4
   const long tap_stride = (long)Cout * Cin * 2;
   const char* xsrc[NX];
+  auto set_xsrc = [&](int m0v, const char* (&xs)[NX]) {
 #pragma unroll
-  for (int i = 0; i < NX; ++i) {
-    const int row = (wave + 8 * i) * 16 + drow;
-    const int c = dp ^ ((row >> 2) & 3);
-    bool real = row < xrows;
-    if constexpr (WB >= 2) {
-      // images start and end on tile boundaries (H*W % 512 == 0): the rows above the first / below the last image row
-      // are fed as zeros, which is all the vertical border handling this form needs
-      const int hw = H * W;
-      if (m0 % hw == 0 && row < HALO) real = false;
-      if ((m0 + BMW) % hw == 0 && row >= HALO + BMW) real = false;
+    for (int i = 0; i < NX; ++i) {
+      const int row = (wave + 8 * i) * 16 + drow;
+      const int c = dp ^ ((row >> 2) & 3);
+      bool real = row < xrows;
+      if constexpr (WB >= 2) {
+        // images start and end on tile boundaries (H*W % 512 == 0): the rows above the first / below the last image row
+        // are fed as zeros, which is all the vertical border handling this form needs
+        const int hw = H * W;
+        if (m0v % hw == 0 && row < HALO) real = false;
+        if ((m0v + BMW) % hw == 0 && row >= HALO + BMW) real = false;
+      }
+      if (real) {
+        long pix = (long)m0v - HALO + row;
+        pix = pix < 0 ? 0 : (pix >= Npix ? Npix - 1 : pix);  // out-of-range rows only feed masked taps
+        xs[i] = reinterpret_cast<const char*>(X + pix * (mod.ldX ? mod.ldX : Cin) + c * 8);
+      } else {
+        xs[i] = zeros + c * 16;
+      }
     }
-    if (real) {
-      long pix = (long)m0 - HALO + row;
-      pix = pix < 0 ? 0 : (pix >= Npix ? Npix - 1 : pix);  // out-of-range rows only feed masked taps
-      xsrc[i] = reinterpret_cast<const char*>(X + pix * (mod.ldX ? mod.ldX : Cin) + c * 8);
-    } else {
-      xsrc[i] = zeros + c * 16;
-    }
-  }
+  };
+  set_xsrc(m0, xsrc);
 
   // ---- pixel-fragment addresses: ONE per tap (block 0 of this wave; block j = + j * 16 rows = + 1024 bytes, the
   // swizzle term of the row is unchanged by 16 j), the zero row, and the border masks
@@ -193,40 +217,41 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
   // with t8 = tap (tap < 4) or tap - 1.  A fragment read turns its bit into an all-ones / all-zeros word (v_bfe_i32) and
   // picks the tap address or the zero row with it (v_bfi_b32): two vector instructions, no scalar work, no VCC.
   unsigned vbits = 0;
+  auto set_vbits = [&](int m0v) {
+    vbits = 0;
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const int m = m0 + wave * 64 + 16 * j + l15;
-    const int w = m % W, h = (m / W) % H;
+    for (int j = 0; j < NB; ++j) {
+      const int m = m0v + wave * 64 + 16 * j + l15;
+      const int w = m % W, h = (m / W) % H;
 #pragma unroll
-    for (int t8 = 0; t8 < 8; ++t8) {
-      const int t = t8 < 4 ? t8 : t8 + 1;
-      const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
-      if (hh >= 0 && hh < H && ww >= 0 && ww < W) vbits |= 1u << (4 * t8 + j);
+      for (int t8 = 0; t8 < 8; ++t8) {
+        const int t = t8 < 4 ? t8 : t8 + 1;
+        const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+        if (hh >= 0 && hh < H && ww >= 0 && ww < W) vbits |= 1u << (4 * t8 + j);
+      }
     }
-  }
+  };
+  if constexpr (WB == 0) set_vbits(m0);
   // weight-fragment rows 16 i + l15: the swizzle term depends on l15 only
   const unsigned wb_off = (unsigned)(uintptr_t)(lds_char*)Wb;
   const unsigned ap = wb_off + l15 * ROWB + ((lq ^ ((l15 >> 2) & 3)) << 4);
 
   f32x4 acc[NA][NB];
-#pragma unroll
-  for (int i = 0; i < NA; ++i)
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
   const int nchunks = Cin / KC;  // even (host-checked)
   // split-bf16 evaluation (mod.kwrap != 0): K chunk c reads the X channels of chunk (c < kwrap ? c : c - kwrap) -- X rows
   // are [hi | lo] pairs, the pack [w_hi | w_lo | w_hi] (common.h)
   const int kwrap = mod.kwrap ? mod.kwrap : (1 << 30);
 
-  // ---- prologue: slab 0, then weight tiles 0..D-1 (issue order fixes the counted waits)
+  // ---- prologue: slab 0, then weight tiles 0..D-1 (issue order fixes the counted waits).  PERSIST: a workgroup's later
+  // tiles find both issued by the tile before them
+  if (!PERSIST || first_tile) {
 #pragma unroll
-  for (int i = 0; i < NX; ++i) dma16(xsrc[i], Xb + (wave + 8 * i) * 1024);
+    for (int i = 0; i < NX; ++i) dma16(xsrc[i], Xb + (wave + 8 * i) * 1024);
 #pragma unroll
-  for (int d = 0; d < D; ++d)
-    if (w_lane) dma16(wbase + d * tap_stride + woff, Wb + d * WTILE + wave * (WROWS * ROWB));
+    for (int d = 0; d < D; ++d)
+      if (w_lane) dma16(wbase + d * tap_stride + woff, Wb + d * WTILE + wave * (WROWS * ROWB));
+  }
 
   u32x4 fa[2][NAH], fb[NB];
   // (macros, not nested lambdas: clang rejects implicit captures of the kernel's locals from a generic lambda nested in
@@ -271,14 +296,21 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
     __builtin_amdgcn_sched_barrier(0);                                \
   }
 
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
   for (int chunk2 = 0; chunk2 < nchunks; chunk2 += 2) {
     static_for<0, 2 * TAPS>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
       constexpr int tap = u % TAPS, cpar = u / TAPS;
       const int chunk = chunk2 + cpar;
       const bool more_chunks = chunk + 1 < nchunks;
+      const bool more = more_chunks || next_tile;   // PERSIST: the next tile's DMAs take the place of the next chunk's
       // ---- retire weight tiles t and t+1 (and slab chunk+1 before its first read, issued at tap 8): as v4
-      if (more_chunks) {
+      if (more) {
         if (tap >= 1 && tap <= D - 1) wait_vmcnt<D - 2 + NX>();
         else wait_vmcnt<D - 2>();
       } else {
@@ -302,12 +334,17 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
         constexpr int tq = tap + D;
         constexpr int cq = cpar + (tq >= TAPS ? 1 : 0);
         constexpr int tapq = tq >= TAPS ? tq - TAPS : tq;
+        int cidx = chunk2 + cq;
+        bool wok = cidx < nchunks;
+        if constexpr (PERSIST) {
+          if (!wok && next_tile) { cidx = 0; wok = true; }   // (chunk2 + cq == nchunks: chunk 0 of the next tile)
+        }
         if constexpr (NI == 2 && WPTR64) {
-          if (chunk2 + cq < nchunks && w_lane)
-            dma16(wsrc + (long)(chunk2 + cq) * (KC * 2) + tapq * tap_stride,
+          if (wok && w_lane)
+            dma16(wsrc + (long)cidx * (KC * 2) + tapq * tap_stride,
                   Wb + ((u + D) % WRING) * WTILE + wave * (WROWS * ROWB));
-        } else if (chunk2 + cq < nchunks && w_lane) {
-          const char* ub = wbase + ((long)(chunk2 + cq) * (KC * 2) + tapq * tap_stride);
+        } else if (wok && w_lane) {
+          const char* ub = wbase + ((long)cidx * (KC * 2) + tapq * tap_stride);
           asm volatile("" : "+s"(ub));   // keep (chunk, tap) in the scalar base: SGPR-base + VGPR-offset DMA, no per-tap
                                          // 64-bit vector pointers hoisted out of the loop
           dma16(ub + woff, Wb + ((u + D) % WRING) * WTILE + wave * (WROWS * ROWB));
@@ -317,6 +354,16 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
 #pragma unroll
           for (int i = 0; i < NX; ++i)
             dma16(xsrc[i] + (long)xc_next * (KC * 2), Xb + (cpar ^ 1) * XBYTES + (wave + 8 * i) * 1024);
+        }
+        if constexpr (PERSIST && tap == 0 && cpar == 1) {
+          // last chunk of this tile (nchunks is even, so it sits in slab buffer 1): the next tile's chunk 0 goes to buffer 0
+          // (read last in chunk nchunks - 2: the barrier above is behind it)
+          if (!more_chunks && next_tile) {
+            const char* xn[NX];
+            set_xsrc((tm + tm_step) * BMW, xn);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) dma16(xn[i], Xb + (wave + 8 * i) * 1024);
+          }
         }
       };
       if (!late) issue_dma();
@@ -362,11 +409,6 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
       }
     });
   }
-#undef READ_A
-#undef RD_A
-#undef READ_B
-#undef MFMA_BLOCK
-#undef MFMA1
 
   // ---- FOLD (round 6): the decoder block's 512 -> 256 skip projection as a second reduction on the same accumulators
   // (common.h, ModEpilogue::X2).  A chunk of it is ONE step (centre tap only): a fresh 512-row slab (32 KB, no halo) and a
@@ -462,11 +504,23 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
   __builtin_amdgcn_s_barrier();  // every wave is done with the slab / weight ring
   V6_STAMP(2);
   V6_CLK(7);
+  // wave-private staging of the epilogue: over the slab buffers -- or (PERSIST: buffer 0 and ring slots 0..D-1 are being
+  // filled for the next tile) over slab buffer 1 for the first waves and ring slot D + the LDS behind the ring for the rest
+  constexpr int STG = EPI == 4 ? 16 * (NI * 128 + 16) : 32 * (NI * 64 + 16);
+  constexpr int NFIT = XBYTES / STG < 8 ? XBYTES / STG : 8;
+  char* stage = smem + wave * STG;
+  float* gmr = gmred;
+  if constexpr (PERSIST) {
+    static_assert(2 * XBYTES + D * WTILE + (8 - NFIT) * STG + (EPI == 1 ? 8 * BNW * 4 : 0) <= 160 * 1024,
+                  "persistent form: epilogue staging must fit beside the next tile's prefetch");
+    stage = wave < NFIT ? Xb + XBYTES + wave * STG : Wb + D * WTILE + (wave - NFIT) * STG;
+    gmr = reinterpret_cast<float*>(Wb + D * WTILE + (8 - NFIT) * STG);
+  }
   if constexpr (EPI == 1) {
     const bool wave_rows = mod.HW % (32 * NJ) == 0;   // a wave's 64 pixels lie in one sample
-    store_tile_transposed16<NI, NJ, EPI>(acc, smem + wave * (32 * (NI * 64 + 16)), Y, R, alpha, beta,
+    store_tile_transposed16<NI, NJ, EPI>(acc, stage, Y, R, alpha, beta,
                                          (long)m0 + wave * (32 * NJ), Npix, n0, Cout, mod,
-                                         wave_rows ? gmred + wave * BNW : nullptr);
+                                         wave_rows ? gmr + wave * BNW : nullptr);
     if (wave_rows) {
       __syncthreads();
       if (tid < BNW && n0 + tid < Cout) {
@@ -483,7 +537,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
             sum = 0.f;
             cur = sm;
           }
-          sum += gmred[w * BNW + tid];
+          sum += gmr[w * BNW + tid];
         }
         atomicAdd(mod.gm + cur * gstride + n0 + tid, sum);
       }
@@ -498,28 +552,67 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_v6(const bf16* __restrict__ 
       store_tile_f32_16<NI, NJ>(acc, reinterpret_cast<float*>(Y), reinterpret_cast<const float*>(R), alpha, beta,
                                 (long)m0 + wave * (32 * NJ), Npix, n0, Cout, mod);
     else
-      store_tile_f32_16_staged<NI, NJ>(acc, smem + wave * (16 * (NI * 128 + 16)), reinterpret_cast<float*>(Y),
+      store_tile_f32_16_staged<NI, NJ>(acc, stage, reinterpret_cast<float*>(Y),
                                        reinterpret_cast<const float*>(R), alpha, beta, (long)m0 + wave * (32 * NJ), Npix, n0,
                                        Cout, mod);
   } else {
-    store_tile_transposed16<NI, NJ, EPI>(acc, smem + wave * (32 * (NI * 64 + 16)), Y, R, alpha, beta,
+    store_tile_transposed16<NI, NJ, EPI>(acc, stage, Y, R, alpha, beta,
                                          (long)m0 + wave * (32 * NJ), Npix, n0, Cout, mod);
   }
   V6_STAMP(3);
 #ifdef EDM_V6_TIMELINE
-  __builtin_amdgcn_s_waitcnt(0);   // stores retired
-  V6_STAMP(4);
+  if (next_tile) { V6_STAMP(4); }   // (no store drain between a workgroup's tiles)
+  else {
+    __builtin_amdgcn_s_waitcnt(0);  // stores retired
+    V6_STAMP(4);
+  }
+  ++tl_iter;
 #endif
+  if (!next_tile) break;
+  tm += tm_step;
+  m0 = tm * BMW;
+  first_tile = false;
+  }   // tiles of this workgroup
+#undef READ_A
+#undef RD_A
+#undef READ_B
+#undef MFMA_BLOCK
+#undef MFMA1
 }
 
-template <int NX, int EPI, int NI, int WB = 0, bool FOLD = false>
+long g_persistent_launches = 0;   // (include/tinyedm_hip_diag.h: edm_v6_persistent_launches)
+
+// Workgroups of a persistent launch: one per CU, rounded down to whole (XCD, channel tile) sets.
+int persist_grid(int tiles_n) {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      n = 256;
+    return n < 8 ? 8 : n;
+  }();
+  const int per_xcd = cus / 8;
+  return 8 * tiles_n * (per_xcd / tiles_n > 0 ? per_xcd / tiles_n : 1);
+}
+
+template <int NX, int EPI, int NI, int WB = 0, bool FOLD = false, bool PERSIST = false>
 void launch6(const void* X, const void* Wp, void* Y, const void* R, float alpha, float beta, int Npix, int H, int W,
              int Cin, int Cout, const ModEpilogue& mod, hipStream_t st) {
   const int tiles_m = (Npix + BM - 1) / BM, tiles_n = (Cout + 32 * NI - 1) / (32 * NI);
   size_t lds = (size_t)2 * NX * 8 * 16 * ROWB + WRING * (32 * NI * ROWB) + (EPI == 1 ? 8 * 32 * NI * 4 : 0);
   if (FOLD && lds < (size_t)4 * (BM * ROWB + 32 * NI * ROWB)) lds = (size_t)4 * (BM * ROWB + 32 * NI * ROWB);   // phase 2: four slots
-  const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
-  auto kern = k_conv3x3_v6<NX, EPI, NI, true, WB, false, FOLD>;
+  int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
+  if (PERSIST) {
+    // epilogue staging beside the next tile's prefetch (see the kernel): waves that do not fit over slab buffer 1 stage
+    // behind ring slot D
+    constexpr int XBYTES = NX * 8 * 16 * ROWB, WTILE = 32 * NI * ROWB;
+    constexpr int STG = EPI == 4 ? 16 * (NI * 128 + 16) : 32 * (NI * 64 + 16);
+    constexpr int NFIT = XBYTES / STG < 8 ? XBYTES / STG : 8;
+    const size_t need = (size_t)2 * XBYTES + D * WTILE + (8 - NFIT) * STG + (EPI == 1 ? 8 * 32 * NI * 4 : 0);
+    if (lds < need) lds = need;
+    grid = persist_grid(tiles_n);
+    __atomic_add_fetch(&g_persistent_launches, 1L, __ATOMIC_RELAXED);
+  }
+  auto kern = k_conv3x3_v6<NX, EPI, NI, true, WB, false, FOLD, PERSIST>;
   EDM_MAX_LDS(kern, 160 * 1024);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const bf16*)X, (const bf16*)Wp, (bf16*)Y, (const bf16*)R,
                      (const char*)edm_zero_page(), alpha, beta, Npix, H, W, Cin, Cout, tiles_m, tiles_n, mod);
@@ -580,6 +673,28 @@ int edm_conv_igemm_v6_ex(const void* X, const void* Wp, void* Y, const void* R, 
     EDM_CHECK_LAUNCH("conv_igemm_v6 (folded projection)");
     return EDM_OK;
   }
+  // persistent form (round 6), OPT-IN (EDM_V6_PERSIST=1, read per call: A/B in one process): 128-channel tiles of the
+  // tile-aligned 16x16 / 32x32 layers when a CU gets two or more of them (B = 128: the 32x32 layers; the samplers' B = 512:
+  // 16x16 too), plain / forward-modulation / split-bf16 epilogues.  Inside a launch it does what it was built for (every tile
+  // after a workgroup's first starts 2.3 us earlier, 499 -> 475 us for the 2048 tiles of a B = 512 layer,
+  // profiles/r06_v6_persistent.txt) -- and in a sustained stream of such launches (the samplers) it changes nothing
+  // (587.8 vs 590.5 img/s bf16, 213.9 vs 215.4 split): the device is power-limited there, and the idle microseconds the
+  // form removes are what let the clock recover.  The modulation-backward / mp_silu-backward epilogues are not built in
+  // this form: their epilogues need the registers the walk keeps live (22 / 42 spilled).
+  if (nx5 && wide && (wb == 1 || wb == 2) && mod.mode != 1 && mod.mode != 2) {
+    const int tiles_n4 = (Cout + 127) / 128;
+    const char* e = getenv("EDM_V6_PERSIST");
+    if (e && e[0] == '1' && (long)((Npix + BM - 1) / BM + 7) / 8 * 8 * tiles_n4 >= 2L * persist_grid(tiles_n4)) {
+#define L6P(EPIV)                                                                                                  \
+  (wb == 1 ? launch6<5, EPIV, 4, 1, false, true>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st)         \
+           : launch6<5, EPIV, 4, 2, false, true>(X, Wp, Y, R, alpha, beta, Npix, H, W, Cin, Cout, mod, st))
+      if (mod.mode == 4) L6P(4);
+      else L6P(0);
+#undef L6P
+      EDM_CHECK_LAUNCH("conv_igemm_v6 (persistent)");
+      return EDM_OK;
+    }
+  }
   if (mod.mode == 1) L6(1);
   else if (mod.mode == 2) L6(2);
   else if (mod.mode == 4) L6(4);
@@ -590,6 +705,8 @@ int edm_conv_igemm_v6_ex(const void* X, const void* Wp, void* Y, const void* R, 
   EDM_CHECK_LAUNCH("conv_igemm_v6");
   return EDM_OK;
 }
+
+extern "C" long edm_v6_persistent_launches(void) { return __atomic_load_n(&g_persistent_launches, __ATOMIC_RELAXED); }
 
 #ifdef EDM_V6_TIMELINE
 extern "C" int edm_v6_set_timeline(unsigned long long* buf) {
