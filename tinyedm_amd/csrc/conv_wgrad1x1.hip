@@ -221,6 +221,12 @@ extern "C" int edm_conv_wgrad_1x1_nsplit_grouped(long npix, int Cin, int Cout) {
   const int single = edm_conv_wgrad_1x1_nsplit(npix, Cin, Cout);
   static const long stages = [] { const char* e = getenv("EDM_W1_STAGES"); return e ? atol(e) : 32L; }();   // tools only
   long S = (npix + stages * KP - 1) / (stages * KP);
+  // the splits of a layer are what spreads it over the XCDs (k_wgrad1x1_group: split = block % 8 within a chunk): with fewer
+  // than 8, the blocks of the missing splits exit at once and their XCDs idle through this layer's stretch of the grid (round 6,
+  // tools/microbench_wgrad1x1.py: sixteen 8x8 layers of the training batch, 4 -> 8 splits: 150 -> 106 us (256 -> 768),
+  // 105 -> 92 us (512 -> 256); 16-stage workgroups everywhere instead cost the 16x16 layers 15 %)
+  static const bool min8 = [] { const char* e = getenv("EDM_W1_MIN8"); return !(e && e[0] == '0'); }();   // tools only (A/B)
+  if (min8 && S < 8 && npix >= 8L * 12 * KP) S = 8;
   if (S > single) S = single;
   return S < 1 ? 1 : (int)S;
 }
