@@ -202,7 +202,7 @@ def train_bench(args, rank, world, device):
 
     def step(i):
         loss = model.training_step(batch, i)
-        loss.backward()
+        model.backward(loss)              # (Lightning's hook: what its automatic optimisation calls; trainer.LightningModule)
         base.grad_scale = reducer.finish()
         opt.step()
         opt.zero_grad()

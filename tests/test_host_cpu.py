@@ -325,3 +325,49 @@ def test_capture_token_releases_slots_and_plan_pins_once():
         ops.release_capture(None)
     finally:
         ops._tables = saved
+
+
+def test_backward_hook_feeds_a_cached_marked_unit_gradient():
+    """LightningModule.backward (Lightning's hook of the same name): the root gradient is ONE cached scalar carrying the
+    `_edm_unit` mark, the loss function's backward returns its saved gradient untouched when it sees the mark (metric._scaled)
+    and multiplies otherwise -- same parameter gradients as a plain loss.backward(), no ones_like / mul per step."""
+    import torch
+    from tinyedm_amd import metric, trainer
+
+    class Toy(trainer.LightningModule):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.arange(6.0).view(2, 3))
+
+        def loss(self, x):
+            return ((self.w * x) ** 2).sum()
+
+    seen = []
+
+    class Spy(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            seen.append(g)
+            return metric._scaled(torch.ones_like(g), g)
+
+    m = Toy()
+    x = torch.tensor([[1.0, -2.0, 0.5], [3.0, 0.25, -1.0]])
+    m.loss(x).backward()
+    ref = m.w.grad.clone()
+    m.w.grad = None
+    m.backward(Spy.apply(m.loss(x)))
+    assert torch.equal(m.w.grad, ref)
+    one = trainer.unit_gradient(torch.zeros(()))
+    assert getattr(one, "_edm_unit", False) and one.item() == 1.0 and trainer.unit_gradient(torch.zeros(())) is one
+    assert len(seen) == 1 and getattr(seen[0], "_edm_unit", False)        # the mark survives the trip through the engine
+    d = torch.full((2, 2), 3.0)
+    assert metric._scaled(d, one) is d                                     # marked: no multiplication
+    assert torch.equal(metric._scaled(d, torch.tensor(0.5)), d * 0.5)     # any other incoming gradient: the product
+    # non-scalar losses and explicit gradients take the ordinary path
+    m.w.grad = None
+    m.backward(m.w * 2.0, torch.ones(2, 3))
+    assert torch.equal(m.w.grad, torch.full((2, 3), 2.0))

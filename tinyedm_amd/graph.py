@@ -25,6 +25,16 @@ from . import _runtime_env, networks, ops
 from .ema import EMAOptimizer, FusedAdam
 
 
+def _backward(model, loss):
+    """the module's Lightning-style backward hook (trainer.LightningModule.backward: a cached, marked unit gradient instead of
+    autograd's per-step ones_like) when it has one"""
+    hook = getattr(model, "backward", None)
+    if callable(hook):
+        hook(loss)
+    else:
+        loss.backward()
+
+
 class StepParams:
     """Device `edm_step_params` record + a ring of pinned host copies (so the host never rewrites a slot whose
     asynchronous upload has not executed yet)."""
@@ -64,7 +74,7 @@ class CapturedTrainStep:
     optimizer kernel -- so they become nodes of the graph and an N-rank step costs the host one graph launch too (the
     eager step needs ~360 ctypes calls + the hook / collective launches per step from Python).  Every rank captures the
     same sequence of collectives, in the same order.  Semantics equal the eager sequence
-        loss = model.training_step(batch, i); loss.backward(); grad_scale = reducer.finish(); optimizer.step();
+        loss = model.training_step(batch, i); model.backward(loss); grad_scale = reducer.finish(); optimizer.step();
         optimizer.zero_grad()
     including the host-side counters (Philox step, Adam step, EMA step, weight epoch)."""
 
@@ -138,7 +148,7 @@ class CapturedTrainStep:
         try:
             with torch.cuda.stream(self.stream):
                 loss = self.model.training_step(batch, 0)
-                loss.backward()
+                _backward(self.model, loss)
                 if self.reducer is not None:
                     self.reducer.finish()   # joins the comm stream; 1/world rides in the device record (grad_scale)
                 self.base.step_dyn(self.params.dev, ema=self.ema.ema_arena if self.ema is not None else None)
@@ -235,7 +245,7 @@ class CapturedTrainStep:
         try:
             with torch.cuda.graph(graph, stream=self.stream, capture_error_mode=mode):
                 loss = self.model.training_step((sx, sy), 0)
-                loss.backward()                 # the reducer's hooks fork the comm stream off the capture stream ...
+                _backward(self.model, loss)     # the reducer's hooks fork the comm stream off the capture stream ...
                 if self.reducer is not None:
                     self.reducer.finish()       # ... and this joins it: the all-reduces are nodes of the graph
                 self.base.step_dyn(self.params.dev, ema=self.ema.ema_arena if self.ema is not None else None)

@@ -5,6 +5,11 @@ from torch import Tensor
 from . import ops
 
 
+def _scaled(dD: Tensor, g: Tensor) -> Tensor:
+    """dD * g -- without the launch when g is the marked unit gradient of LightningModule.backward (trainer.py)"""
+    return dD if getattr(g, "_edm_unit", False) else dD * g
+
+
 class _WeightedMSEFn(torch.autograd.Function):
     """loss = (1/B) sum_i mean_j w_i (p_ij - t_ij)^2 ; gradient w.r.t. preds produced in the same pass."""
 
@@ -17,7 +22,7 @@ class _WeightedMSEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dD,) = ctx.saved_tensors
-        return None, dD * g, None
+        return None, _scaled(dD, g), None
 
 
 class _SigmaMSEFn(torch.autograd.Function):
@@ -35,7 +40,7 @@ class _SigmaMSEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dD,) = ctx.saved_tensors
-        return None, None, dD * g, None, None, None, None
+        return None, None, _scaled(dD, g), None, None, None, None
 
 
 def weighted_mse_loss(weight: Tensor, preds: Tensor, target: Tensor) -> Tensor:

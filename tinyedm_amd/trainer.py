@@ -39,6 +39,31 @@ class LightningModule(torch.nn.Module):
     def configure_callbacks(self):
         return []
 
+    def backward(self, loss: torch.Tensor, *args, **kwargs) -> None:
+        """Lightning's `LightningModule.backward(loss)` hook (what its automatic optimisation calls after `training_step`;
+        default there: `loss.backward()`).  Here the root gradient is a cached scalar 1 that carries a mark: autograd's own
+        `ones_like(loss)` is a fill launch per step, and the loss function's backward (metric.py) multiplies its saved
+        gradient by the incoming one -- another launch -- unless it sees the mark.  Same gradients, two launches fewer."""
+        if loss.dim() == 0 and not args and not kwargs:
+            loss.backward(gradient=unit_gradient(loss))
+        else:
+            loss.backward(*args, **kwargs)
+
+
+_UNIT = {}
+
+
+def unit_gradient(loss: torch.Tensor) -> torch.Tensor:
+    """the cached 0-dim 1.0 of `loss`'s device / dtype, marked `_edm_unit` (see LightningModule.backward)"""
+    key = (loss.device, loss.dtype)
+    one = _UNIT.get(key)
+    if one is None:
+        if loss.is_cuda and torch.cuda.is_current_stream_capturing():
+            return torch.ones_like(loss)        # (never cache a tensor whose fill belongs to a graph being captured)
+        one = _UNIT[key] = torch.ones((), device=loss.device, dtype=loss.dtype)
+        one._edm_unit = True
+    return one
+
 
 class _ConstLR:
     def __init__(self, lr):
@@ -220,7 +245,10 @@ class Trainer:
                     if self.reducer is not None:
                         self.reducer.enabled = last_micro
                     loss = model.training_step(batch, bi)
-                    (loss / self.accumulate_grad_batches).backward()
+                    if self.accumulate_grad_batches == 1:
+                        model.backward(loss)
+                    else:
+                        (loss / self.accumulate_grad_batches).backward()
                     if last_micro:
                         base.grad_scale = self.reducer.finish() if self.reducer is not None else 1.0
                         opt.step()

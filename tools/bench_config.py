@@ -69,7 +69,7 @@ def main():
 
         def step(i):
             loss = model.training_step((x, y), i)
-            loss.backward()
+            model.backward(loss)
             base.grad_scale = red.finish()
             opt.step()
             opt.zero_grad()
