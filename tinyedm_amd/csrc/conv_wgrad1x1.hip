@@ -13,6 +13,7 @@
 //  * counted `s_waitcnt vmcnt(6)` + raw s_barrier keep the next stage in flight across the barrier.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -46,7 +47,7 @@ __device__ __forceinline__ bf16x8 frag_of(const u32x2_t& lo, const u32x2_t& hi) 
 
 __device__ __forceinline__ void wgrad1x1_body(const bf16* __restrict__ X, const bf16* __restrict__ dY,
                                               float* __restrict__ slabs, const bf16* __restrict__ zeros, long Npix, int Cin,
-                                              int Cout, int tiles_ci, long L, int tile, int s) {
+                                              int Cout, int tiles_ci, long L, int tile, int s, bool spread) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,10 +82,15 @@ __device__ __forceinline__ void wgrad1x1_body(const bf16* __restrict__ X, const 
       stride[i] = KP * Cin * 2;
     }
   }
-  auto issue = [&](int t) {  // stage t from the current pointers, then advance them
+  // DMAs i0 .. i1-1 of stage t from the current pointers, then advance them.  (Round 6: inside the loop the six DMAs of a
+  // stage are issued in three pairs BETWEEN the k-steps instead of in one burst behind the barrier -- a wave sits 60-180
+  // cycles in each LDS-DMA instruction, and both waves of a SIMD leave the barrier together, so the burst kept the matrix
+  // pipe idle for the first ~0.3 us of every stage.  Issue order per wave is unchanged: the counted vmcnt waits hold.)
+  auto issue_part = [&](int t, auto i0c, auto i1c) {
+    constexpr int i0 = decltype(i0c)::value, i1 = decltype(i1c)::value;
     char* dst = smem + (t % RING) * STAGE;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = i0; i < i1; ++i) {
       const int j = wave + 8 * i;
       const bool ok = chan_ok[i] && row_of[i] < k1;
       dma16(ok ? (const void*)src[i] : (const void*)zeros, dst + (j >> 2) * SUBB + (j & 3) * 1024);
@@ -92,6 +98,7 @@ __device__ __forceinline__ void wgrad1x1_body(const bf16* __restrict__ X, const 
       row_of[i] += KP;
     }
   };
+  auto issue = [&](int t) { issue_part(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 6>{}); };
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -116,7 +123,8 @@ __device__ __forceinline__ void wgrad1x1_body(const bf16* __restrict__ X, const 
     if (t + 1 < nst) wait_vmcnt<6>();  // stage t landed; stage t+1 (6 DMAs per wave) may stay in flight
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (t + 2 < nst) issue(t + 2);  // ring slot of stage t-1: every wave is past its reads (barrier above)
+    const bool more = t + 2 < nst;  // stage t+2 goes to the ring slot of stage t-1: every wave is past its reads (barrier above)
+    if (more && !spread) issue(t + 2);
     const unsigned sb = (t % RING) * STAGE;
     const unsigned au = a_rel + sb, bu = b_rel + sb;
     u32x2_t A[2][2][2], Bf[2][2][2];  // [set][block][half]
@@ -134,10 +142,15 @@ __device__ __forceinline__ void wgrad1x1_body(const bf16* __restrict__ X, const 
                                                      frag_of(Bf[set][0][0], Bf[set][0][1]), acc[1][0], 0, 0, 0); \
   acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(A[set][1][0], A[set][1][1]),                       \
                                                      frag_of(Bf[set][1][0], Bf[set][1][1]), acc[1][1], 0, 0, 0)
+    using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>;
+    using I4 = std::integral_constant<int, 4>; using I6 = std::integral_constant<int, 6>;
     RD(0, 0);
     RD(1, 1); LGKM_WAIT(8); MM(0); __builtin_amdgcn_sched_barrier(0);
+    if (more && spread) issue_part(t + 2, I0{}, I2{});
     RD(0, 2); LGKM_WAIT(8); MM(1); __builtin_amdgcn_sched_barrier(0);
+    if (more && spread) issue_part(t + 2, I2{}, I4{});
     RD(1, 3); LGKM_WAIT(8); MM(0); __builtin_amdgcn_sched_barrier(0);
+    if (more && spread) issue_part(t + 2, I4{}, I6{});
     LGKM_WAIT(0); MM(1); __builtin_amdgcn_sched_barrier(0);
 #undef RD
 #undef MM
@@ -162,7 +175,7 @@ __device__ __forceinline__ void wgrad1x1_body(const bf16* __restrict__ X, const 
 __global__ __launch_bounds__(512, 1) void k_wgrad1x1(const bf16* __restrict__ X, const bf16* __restrict__ dY,
                                                        float* __restrict__ slabs, const bf16* __restrict__ zeros,
                                                        long Npix, int Cin, int Cout, int tiles_ci, long L) {
-  wgrad1x1_body(X, dY, slabs, zeros, Npix, Cin, Cout, tiles_ci, L, blockIdx.x, blockIdx.y);
+  wgrad1x1_body(X, dY, slabs, zeros, Npix, Cin, Cout, tiles_ci, L, blockIdx.x, blockIdx.y, true);
 }
 
 // A GROUP of 1x1 layers in one launch (round 3).  The ~31 1x1 weight gradients of a step were 31 launches of 9-70 us, the
@@ -178,6 +191,7 @@ struct W1Group {
   int Cin[W1_MAX], Cout[W1_MAX], tiles_ci[W1_MAX], tiles[W1_MAX], nsplit[W1_MAX];
   int wg_end[W1_MAX];     // exclusive prefix of workgroups: layer i owns blocks [wg_end[i-1], wg_end[i])
   int n;
+  int spread;   // DMA issue spread over the k-steps (EDM_W1_SPREAD=0: one burst behind the barrier, the round-1..5 form)
   const bf16* zeros;
 };
 // Block -> (tile, split) inside a layer: the `tiles` workgroups of ONE split read the same pixel rows at the same time
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad1x1_group(const W1Group* __rest
   const int chunk = lid / per, j = lid - chunk * per;
   const int s = chunk * 8 + (j & 7), tile = j >> 3;
   if (s >= g.nsplit[i]) return;
-  wgrad1x1_body(g.X[i], g.dY[i], g.slabs[i], g.zeros, g.npix[i], g.Cin[i], g.Cout[i], g.tiles_ci[i], g.L[i], tile, s);
+  wgrad1x1_body(g.X[i], g.dY[i], g.slabs[i], g.zeros, g.npix[i], g.Cin[i], g.Cout[i], g.tiles_ci[i], g.L[i], tile, s, g.spread != 0);
 }
 
 }  // namespace
@@ -267,6 +281,10 @@ extern "C" int edm_conv_wgrad_1x1_group(const void* items_, int n, void* table_h
   EDM_ZERO_PAGE(zero_page_, "conv_wgrad_1x1_group");
   W1Group g;
   g.n = n;
+  {
+    const char* e = getenv("EDM_W1_SPREAD");   // read per call (A/B in one process; tools only)
+    g.spread = !(e && e[0] == '0');
+  }
   g.zeros = (const bf16*)zero_page_;
   long total = 0;
   for (int i = 0; i < n; ++i) {
