@@ -283,6 +283,21 @@ typedef struct {
 long edm_skip_gate_wgrad_multi_table_bytes(void);
 int edm_skip_gate_wgrad_multi(const edm_skip_gate_wgrad_item* items, int n, void* table_host, void* table_dev,
                               int defer_upload, edm_stream_t stream);
+/* round 6: edm_skip_gate_fwd for up to 32 skip tensors of ONE channel count in one launch (the U-Net's skips all exist when
+ * the encoder ends; one workgroup per (tensor, sample): a launch that fills the chip instead of nine half-empty ones on the
+ * decoder's critical chain).  Same values as the per-tensor entry point.  Launch-table contract as above. */
+typedef struct {
+  const void* skip;     /* bf16 [B*HW][C] */
+  const float* W1h;     /* [R][C+1] */
+  const float* W2h;     /* [C][R] */
+  float* mean;          /* [B][C]  written */
+  float* gate;          /* [B][C]  written */
+  float* z1save;        /* [B][R]  written */
+  int B, HW, C, R;
+} edm_skip_gate_fwd_item;
+long edm_skip_gate_fwd_multi_table_bytes(void);
+int edm_skip_gate_fwd_multi(const edm_skip_gate_fwd_item* items, int n, void* table_host, void* table_dev, int defer_upload,
+                            edm_stream_t stream);
 /* cat = [inp, skip*gate] (networks.py:311) and backward */
 int edm_concat_gate_fwd(const void* inp, const void* skip, const float* gate, void* cat, void* silu_out, int B, int HW,
                         int Ci, int Cs, edm_stream_t stream);

@@ -851,3 +851,26 @@ def test_persistent_conv3x3_walks_its_tiles_like_single_tile_workgroups(ops, B, 
     for b in (0, B // 2, B - 1):       # and against the definition
         want = 0.9 * F.conv2d(x[b:b + 1].permute(0, 3, 1, 2).double(), wf.double().to(DEV), padding=1)
         assert rel(got["plain"][b:b + 1].permute(0, 3, 1, 2).double(), want) <= 6e-3
+
+
+def test_skip_gate_fwd_multi_matches_the_per_tensor_launches(ops):
+    """edm_skip_gate_fwd_multi (round 6: the ScaleLong gates of every decoder block from ONE launch): mean, gate and z1 of each
+    tensor bit for bit those of edm_skip_gate_fwd (same body per (tensor, sample) workgroup), for tensors of different map
+    sizes, batch sizes and hidden widths sharing a channel count; a mixed channel count is refused."""
+    g = torch.Generator().manual_seed(77)
+    C = 256
+    items = []
+    for B, H, W, R in [(128, 32, 32, 16), (128, 16, 16, 16), (5, 8, 8, 24), (3, 5, 7, 8), (1, 1, 1, 16)]:
+        skip = nhwc(q(torch.randn(B, C, H, W, generator=g)))
+        w1h = (torch.randn(R, C + 1, generator=g) / math.sqrt(C + 1)).to(DEV)
+        w2h = (torch.randn(C, R, generator=g) / math.sqrt(R)).to(DEV)
+        items.append((skip, w1h, w2h))
+    got = ops.skip_gate_fwd_multi(items)
+    for (skip, w1h, w2h), (mean, gate, z1) in zip(items, got):
+        m0, g0, z0 = ops.skip_gate_fwd(skip, w1h, w2h)
+        assert torch.equal(mean, m0) and torch.equal(gate, g0) and torch.equal(z1, z0)
+        ref_mean = skip.float().mean(dim=(1, 2))
+        assert rel(mean, ref_mean) <= 1e-5
+    other = nhwc(q(torch.randn(2, 128, 4, 4, generator=g)))
+    with pytest.raises(ValueError):
+        ops.skip_gate_fwd_multi([items[0], (other, torch.zeros(8, 129, device=DEV), torch.zeros(128, 8, device=DEV))])

@@ -40,6 +40,8 @@ SIGNATURES = {
     "edm_skip_gate_bwd": [P, L, I, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     "edm_skip_gate_wgrad_multi": [P, I, P, P, I, P],
     "edm_skip_gate_wgrad_multi_table_bytes": [],
+    "edm_skip_gate_fwd_multi": [P, I, P, P, I, P],
+    "edm_skip_gate_fwd_multi_table_bytes": [],
     "edm_concat_gate_fwd": [P, P, P, P, P, I, I, I, I, P],
     "edm_concat_gate_bwd": [P, P, P, P, P, I, I, I, I, P],
     "edm_skip_half_fwd": [P, P, P, P, I, I, I, I, P],
@@ -136,9 +138,9 @@ DIAG_SIGNATURES = {
     "edm_v6_persistent_launches": [],
 }
 _RET = {"edm_last_error": ctypes.c_char_p, "edm_v6_persistent_launches": ctypes.c_long, "edm_wgrad3_workspace": ctypes.c_long, "edm_wgrad3_table_bytes": ctypes.c_long,
-        "edm_skip_gate_wgrad_multi_table_bytes": ctypes.c_long,
+        "edm_skip_gate_wgrad_multi_table_bytes": ctypes.c_long, "edm_skip_gate_fwd_multi_table_bytes": ctypes.c_long,
         "edm_conv_wgrad_1x1_group_table_bytes": ctypes.c_long, "edm_wgrad_finish_multi_table_bytes": ctypes.c_long}
-_NO_STATUS = {"edm_v6_persistent_launches", "edm_conv3x3_fold_supported", "edm_skip_gate_wgrad_multi_table_bytes", "edm_version", "edm_graph_replay_safe", "edm_last_error", "edm_conv_wgrad_nsplit", "edm_conv_wgrad_1x1_nsplit", "edm_conv_wgrad_1x1_nsplit_grouped", "edm_wgrad3_workspace", "edm_wgrad3_table_bytes",
+_NO_STATUS = {"edm_skip_gate_fwd_multi_table_bytes", "edm_v6_persistent_launches", "edm_conv3x3_fold_supported", "edm_skip_gate_wgrad_multi_table_bytes", "edm_version", "edm_graph_replay_safe", "edm_last_error", "edm_conv_wgrad_nsplit", "edm_conv_wgrad_1x1_nsplit", "edm_conv_wgrad_1x1_nsplit_grouped", "edm_wgrad3_workspace", "edm_wgrad3_table_bytes",
               "edm_conv_wgrad_1x1_group_table_bytes", "edm_wgrad_finish_multi_table_bytes", "edm_attention_qkv_supported"}
 
 _lib = None
@@ -157,6 +159,12 @@ class FinishItem(ctypes.Structure):
 class SkipGateWgradItem(ctypes.Structure):
     """edm_skip_gate_wgrad_item (include/tinyedm_hip.h): one ScaleLong gate of a grouped weight-gradient launch."""
     _fields_ = [("ws", P), ("mean", P), ("gW1h", P), ("gW2h", P), ("B", I), ("C", I), ("R", I), ("pad", I)]
+
+
+class SkipGateFwdItem(ctypes.Structure):
+    """edm_skip_gate_fwd_item (include/tinyedm_hip.h): one ScaleLong gate of a grouped forward launch."""
+    _fields_ = [("skip", P), ("W1h", P), ("W2h", P), ("mean", P), ("gate", P), ("z1save", P), ("B", I), ("HW", I), ("C", I),
+                ("R", I)]
 
 
 class WGrad1Item(ctypes.Structure):

@@ -802,16 +802,15 @@ __device__ __forceinline__ void sample_reduce(const bf16* __restrict__ x, long x
 }
 
 // forward: mean[b,:] = mean_hw skip[b];  gate = sigmoid(W2 mp_silu(W1 [mean;1]))   (networks.py:112-118)
-__global__ __launch_bounds__(1024) void k_skip_gate_fwd(const bf16* __restrict__ skip, const float* __restrict__ W1,
-                                                          const float* __restrict__ W2, float* __restrict__ mean,
-                                                          float* __restrict__ gate, float* __restrict__ z1save, int HW,
-                                                          int C, int R) {
+__device__ __forceinline__ void skip_gate_fwd_body(const bf16* __restrict__ skip, const float* __restrict__ W1,
+                                                   const float* __restrict__ W2, float* __restrict__ mean,
+                                                   float* __restrict__ gate, float* __restrict__ z1save, int HW,
+                                                   int C, int R, int b) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // red[rpp*C] | m[C+1] | h[R]
   const int rpp = blockDim.x / (C >> 3);
   float* red = sm;
   float* m = sm + rpp * C;
   float* h = m + C + 1;
-  const int b = blockIdx.x;
   sample_reduce<false>(skip + (long)b * HW * C, C, nullptr, 0, HW, C, red, m, 1.0f / (float)HW);
   for (int c = threadIdx.x; c < C; c += blockDim.x) mean[(long)b * C + c] = m[c];
   if (threadIdx.x == 0) m[C] = 1.0f;
@@ -828,6 +827,38 @@ __global__ __launch_bounds__(1024) void k_skip_gate_fwd(const bf16* __restrict__
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) gate[(long)b * C + c] = sigmoidf_(strided_dot(W2 + (long)c * R, 1, h, R));
+}
+__global__ __launch_bounds__(1024) void k_skip_gate_fwd(const bf16* __restrict__ skip, const float* __restrict__ W1,
+                                                          const float* __restrict__ W2, float* __restrict__ mean,
+                                                          float* __restrict__ gate, float* __restrict__ z1save, int HW,
+                                                          int C, int R) {
+  skip_gate_fwd_body(skip, W1, W2, mean, gate, z1save, HW, C, R, blockIdx.x);
+}
+// The gates of SEVERAL skip tensors in one launch (round 6).  A gate depends on its skip tensor and two small weights only, and
+// the U-Net's skips all exist when the encoder ends -- but each decoder block launched its own k_skip_gate_fwd: one workgroup
+// per sample, 128 workgroups on 256 CUs at the training batch, nine launches per step at 2.2-3.1 TB/s.  Here the (tensor, sample)
+// workgroups of every gate with the same channel count are laid end to end (blk0 = first workgroup of a gate): one launch
+// that fills the chip.  Same body, same values.
+constexpr int MAXSGF = 32;
+struct SgfItem {
+  const bf16* skip;
+  const float* W1;
+  const float* W2;
+  float* mean;
+  float* gate;
+  float* z1;
+  int B, HW, R, blk0;
+};
+struct SgfGroup {
+  SgfItem it[MAXSGF];
+  int n, C, pad[2];
+};
+__global__ __launch_bounds__(1024) void k_skip_gate_fwd_multi(const SgfGroup* __restrict__ g) {
+  int k = 0;
+  const int n = g->n;
+  while (k + 1 < n && (int)blockIdx.x >= g->it[k + 1].blk0) ++k;
+  const SgfItem it = g->it[k];
+  skip_gate_fwd_body(it.skip, it.W1, it.W2, it.mean, it.gate, it.z1, it.HW, g->C, it.R, (int)blockIdx.x - it.blk0);
 }
 // backward: ggate[b,c] = sum_hw gcat[b,hw,Ci+c] * skip[b,hw,c], then the MLP backward of k_scalelong_bwd per sample.
 // The weight gradients are sums over the batch of per-sample outer products; adding them with atomics from every
@@ -965,6 +996,49 @@ extern "C" int edm_skip_gate_fwd(const void* skip, const float* W1h, const float
   hipLaunchKernelGGL(k_skip_gate_fwd, dim3(B), dim3(threads), lds, st, (const bf16*)skip, W1h, W2h, mean, gate, z1save,
                      HW, C, R);
   EDM_CHECK_LAUNCH("skip_gate_fwd");
+  return EDM_OK;
+}
+struct edm_skip_gate_fwd_item_ {   // = edm_skip_gate_fwd_item (include/tinyedm_hip.h)
+  const void* skip;
+  const float* W1h;
+  const float* W2h;
+  float* mean;
+  float* gate;
+  float* z1save;
+  int B, HW, C, R;
+};
+extern "C" long edm_skip_gate_fwd_multi_table_bytes(void) { return (long)sizeof(SgfGroup); }
+// edm_skip_gate_fwd for up to 32 skip tensors of ONE channel count in one launch; `items` is host memory read during the
+// call, the table goes to device memory (launch tables, include/tinyedm_hip.h)
+extern "C" int edm_skip_gate_fwd_multi(const void* items_, int n, void* table_host, void* table_dev, int defer_upload,
+                                       hipStream_t st) {
+  const edm_skip_gate_fwd_item_* items = (const edm_skip_gate_fwd_item_*)items_;
+  EDM_REQUIRE(items && n > 0 && n <= MAXSGF, "skip_gate_fwd_multi: need 1..%d gates, got %d", MAXSGF, n);
+  SgfGroup g;
+  g.n = n;
+  g.C = items[0].C;
+  g.pad[0] = g.pad[1] = 0;
+  const int C = g.C;
+  EDM_REQUIRE(C > 0 && C % 8 == 0 && C <= 4096, "skip_gate_fwd_multi: bad channel count %d", C);
+  const int threads = skip_gate_threads(C);
+  EDM_REQUIRE(threads > 0, "skip_gate_fwd_multi: C too large");
+  long blk = 0;
+  int rmax = 0;
+  for (int k = 0; k < n; ++k) {
+    const edm_skip_gate_fwd_item_& a = items[k];
+    EDM_REQUIRE(a.skip && a.W1h && a.W2h && a.mean && a.gate && a.z1save, "skip_gate_fwd_multi: null pointer (gate %d)", k);
+    EDM_REQUIRE(a.C == C, "skip_gate_fwd_multi: the gates of one launch share a channel count (%d vs %d)", a.C, C);
+    EDM_REQUIRE(a.B > 0 && a.HW > 0 && a.R > 0 && a.R <= 1024, "skip_gate_fwd_multi: bad item %d", k);
+    g.it[k] = SgfItem{(const bf16*)a.skip, a.W1h, a.W2h, a.mean, a.gate, a.z1save, a.B, a.HW, a.R, (int)blk};
+    blk += a.B;
+    EDM_REQUIRE(blk < (1L << 30), "skip_gate_fwd_multi: grid too large");
+    if (a.R > rmax) rmax = a.R;
+  }
+  for (int k = n; k < MAXSGF; ++k) g.it[k] = SgfItem{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, (int)blk};
+  const size_t lds = ((size_t)(threads / (C / 8)) * C + C + 1 + rmax) * sizeof(float);
+  EDM_UPLOAD_TABLE(table_dev, table_host, &g, sizeof(SgfGroup), st, "skip_gate_fwd_multi", defer_upload);
+  hipLaunchKernelGGL(k_skip_gate_fwd_multi, dim3((unsigned)blk), dim3(threads), lds, st, (const SgfGroup*)table_dev);
+  EDM_CHECK_LAUNCH("skip_gate_fwd_multi");
   return EDM_OK;
 }
 // gcat rows of gcat_stride elements whose channels [c_off, c_off + C) are the gradient of skip * gate; gmean [B][C],

@@ -166,6 +166,7 @@ _bwd_end_queued = set()     # devices whose end-of-backward callback is queued f
 # ScaleLong gates: the batch sums that form the gate MLPs' weight gradients (the second launch of ops.skip_gate_bwd), for ALL
 # the gates of a backward pass in ONE launch behind it (round 6: nine launches less on the backward's chain); their finish
 # rides in the last multi-tensor finish.  Arena mode only; EDM_SG_DEFER=0: per gate, as round 5.
+SG_MULTI = os.environ.get("EDM_SG_MULTI", "1") != "0"     # every decoder gate of a forward pass in one launch (round 6)
 SG_DEFER = os.environ.get("EDM_SG_DEFER", "1") != "0"
 _sg_pending = {}            # device index -> [(ScaleLong module, ws, mean, R)]
 _w3_pending = {}            # device index -> [(mod, x, dy, scale)] 3x3 layers waiting for their grouped launch
@@ -905,7 +906,7 @@ class _ResBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, u, emb, w1x1, w1, w2, wemb, gain, blk, lin_view, glin_view, token, s_pre=None, alias=False,
-                gm_view=None, skip=None, w_sl1=None, w_sl2=None, pre=None, dest=None, pool=False):
+                gm_view=None, skip=None, w_sl1=None, w_sl2=None, pre=None, dest=None, pool=False, gate_pre=None):
         # skip (decoder blocks with a U-Net skip and no upsample, FUSE_CAT): the concatenation of networks.py:311 happens
         # HERE.  pre = (cat, sil) whose left halves the producer of u already wrote (u is that half of cat): only the gated
         # skip half is filled in; otherwise the standalone concat kernel builds both.  dest = the (cat, sil) buffers of the
@@ -927,8 +928,11 @@ class _ResBlockFn(torch.autograd.Function):
         ctx.has_skip = skip is not None
         if skip is not None:
             sl = blk.cat_factor
-            w1h, w2h = sl.layer1.packs()[2], sl.layer2.packs()[2]
-            mean, gate, z1 = ops.skip_gate_fwd(skip, w1h, w2h)      # mean over H*W + gate MLP: one launch
+            if gate_pre is not None:    # (SG_MULTI: the Denoiser computed every decoder gate in one launch behind the encoder)
+                mean, gate, z1, w1h, w2h = gate_pre
+            else:
+                w1h, w2h = sl.layer1.packs()[2], sl.layer2.packs()[2]
+                mean, gate, z1 = ops.skip_gate_fwd(skip, w1h, w2h)      # mean over H*W + gate MLP: one launch
             ctx.Ci = u.shape[-1]
             if pre is not None and pre[0].shape[-1] == u.shape[-1] + skip.shape[-1] and pre[0].data_ptr() == u.data_ptr():
                 cat, s_pre = pre
@@ -1099,7 +1103,7 @@ class _ResBlockFn(torch.autograd.Function):
         if g_alias is not None:         # decoder blocks are never asked for an alias; kept for completeness
             gu = ops.axpby(gu, 1.0, g_alias, 1.0)
         return (gu, gemb, gw11, gw1, gw2, gwemb, ggain, None, None, None, gtoken, None, None, None, gskip, gwsl1, gwsl2,
-                None, None, None)
+                None, None, None, None)
 
 
 _rng_sub_counter = [0]
@@ -1118,7 +1122,8 @@ class _BlockBase(nn.Module):
         _rng_sub_counter[0] += 1
         self.rng_sub = _rng_sub_counter[0]
 
-    def _res(self, u: Tensor, embedding: Tensor, lin=None, s_pre=None, alias=False, skip=None, dest=None, pool=False):
+    def _res(self, u: Tensor, embedding: Tensor, lin=None, s_pre=None, alias=False, skip=None, dest=None, pool=False,
+             gate=None):
         """alias=True: returns (out, alias of u) -- see _ResBlockFn.forward.  skip / dest: FUSE_CAT (decoder blocks);
         pool: u is the block input BEFORE its 2x2 average pool (FUSE_RESAMPLE, encoder blocks)"""
         w11 = self.conv_1x1.weight if isinstance(self.conv_1x1, Conv2d) else None
@@ -1127,7 +1132,8 @@ class _BlockBase(nn.Module):
         if skip is not None or dest is not None or pool:
             cf = self.cat_factor if skip is not None else None
             sk = (skip, cf.layer1.weight if cf is not None else None, cf.layer2.weight if cf is not None else None,
-                  getattr(u, "_edm_cat", None) if skip is not None else None, None if has_attn else dest, bool(pool))
+                  getattr(u, "_edm_cat", None) if skip is not None else None, None if has_attn else dest, bool(pool),
+                  gate if skip is not None else None)
         if lin is None:
             out = _ResBlockFn.apply(u, embedding, w11, self.conv_3x3_1.weight, self.conv_3x3_2.weight,
                                     self.embed.weight, self.gain, self, None, None, None, s_pre, alias, None, *sk)
@@ -1318,7 +1324,12 @@ class DecoderBlock(_BlockBase):
         self.conv_3x3_1 = Conv2d(total, out_channels, 3)
         self._common(out_channels, embedding_dim, attention, num_heads, dropout_rate)
 
-    def forward(self, input: Tensor, embedding: Tensor, skip: Tensor | None = None, _lin=None, _dest=None) -> Tensor:
+    def _gate_in_block(self) -> bool:
+        """the concatenation, the ScaleLong gate and their backward live inside this block's autograd node"""
+        return (FUSE_CAT and SKIP_GATE_FUSED and not isinstance(self.resample, UpSample)
+                and isinstance(self.conv_1x1, Conv2d) and self.cat_factor is not None)
+
+    def forward(self, input: Tensor, embedding: Tensor, skip: Tensor | None = None, _lin=None, _dest=None, _gate=None) -> Tensor:
         x, conv = _as_nhwc(input)
         s_pre = None
         if skip is not None and FUSE_CAT and SKIP_GATE_FUSED and not isinstance(self.resample, UpSample) \
@@ -1326,7 +1337,8 @@ class DecoderBlock(_BlockBase):
             # the concatenation, the ScaleLong gate and their backward live inside the block's autograd node
             assert self.cat_factor is not None
             sk, _ = _as_nhwc(skip)
-            out = self._res(x, None if _lin is not None else _emb32(embedding, x.shape[0]), _lin, skip=sk, dest=_dest)
+            out = self._res(x, None if _lin is not None else _emb32(embedding, x.shape[0]), _lin, skip=sk, dest=_dest,
+                            gate=_gate)
             return ops.nhwc_bf16_to_nchw(out).to(input.dtype) if conv else _tag(out)
         if skip is not None:
             assert self.cat_factor is not None
@@ -1635,6 +1647,10 @@ class Denoiser(nn.Module):
         return cached[1]
 
     @staticmethod
+    def _decoder_gates(dec, skips):
+        return _decoder_gates_impl(dec, skips)
+
+    @staticmethod
     def _silu_dest(block, nxt, x, up, down=False):
         """(out, sil) buffers for `block`'s output when its consumer `nxt` is a decoder block WITHOUT a skip, an upsample or
         a 1x1 conv in front of its first 3x3 conv: that conv reads mp_silu(input) (networks.py:313-316), which the producer's
@@ -1859,6 +1875,7 @@ class Denoiser(nn.Module):
             x, x_in = block(_tag(x), None, _lin=lins[block], _alias=True, _dest=dest)
             skips.append(x_in)
         skips.append(x)
+        gates = self._decoder_gates(dec, skips) if SG_MULTI else {}
         for i, (block, has_skip) in enumerate(dec):
             skip = skips.pop() if has_skip else None
             dest = None
@@ -1878,11 +1895,35 @@ class Denoiser(nn.Module):
             cat_pre = getattr(x, "_edm_cat", None)
             if cat_pre is not None:
                 xin._edm_cat = cat_pre
-            x = block(xin, None, _tag(skip) if has_skip else None, _lin=lins[block], _dest=dest)
+            x = block(xin, None, _tag(skip) if has_skip else None, _lin=lins[block], _dest=dest, _gate=gates.get(block))
         D = _ConvOutFn.apply(x, self.conv_out.weight, self.gain_out, noisy, sig, self)
         if self.training:
             rng.step += 1
         return D.to(noisy_image.dtype)
+
+
+def _decoder_gates_impl(dec, skips):
+    """{decoder block: (mean, gate, z1, w1h, w2h)} for every block whose ScaleLong gate lives in its autograd node: the gates
+    depend on the skip tensors and two small weights only, so all of them are computed HERE, behind the encoder, by one
+    launch per channel count (ops.skip_gate_fwd_multi) instead of one half-empty launch per decoder block."""
+    st = list(skips)
+    todo = {}
+    for block, has_skip in dec:
+        if not has_skip:
+            continue
+        skip = st.pop()
+        if not (isinstance(block, DecoderBlock) and block._gate_in_block() and skip.dim() == 4 and skip.dtype == bf16):
+            continue
+        sl = block.cat_factor
+        todo.setdefault(skip.shape[-1], []).append((block, skip, sl.layer1.packs()[2], sl.layer2.packs()[2]))
+    out = {}
+    for items in todo.values():
+        for k0 in range(0, len(items), 32):
+            part = items[k0:k0 + 32]
+            res = ops.skip_gate_fwd_multi([(skip, w1h, w2h) for _, skip, w1h, w2h in part])
+            for (block, _, w1h, w2h), (mean, gate, z1) in zip(part, res):
+                out[block] = (mean, gate, z1, w1h, w2h)
+    return out
 
 
 class DenoiserWrapper(nn.Module):

@@ -163,7 +163,8 @@ class _LaunchTables:
                                    "created under stream capture (pinned + device allocations): run one eager step first, "
                                    "or bracket the capture with ops.capture_begin() / capture_end()")
             nb = max(int(_lib.call("edm_wgrad3_table_bytes")), int(_lib.call("edm_conv_wgrad_1x1_group_table_bytes")),
-                     int(_lib.call("edm_wgrad_finish_multi_table_bytes")), int(_lib.call("edm_skip_gate_wgrad_multi_table_bytes")))
+                     int(_lib.call("edm_wgrad_finish_multi_table_bytes")), int(_lib.call("edm_skip_gate_wgrad_multi_table_bytes")),
+                     int(_lib.call("edm_skip_gate_fwd_multi_table_bytes")))
             nb = (nb + 255) // 256 * 256
             d = torch.device("cuda", key)
             st = self.dev[key] = {
@@ -532,6 +533,34 @@ def skip_gate_fwd(skip, w1h, w2h):
     z1 = torch.empty(B, R, device=skip.device, dtype=f32)
     _lib.call("edm_skip_gate_fwd", _p(skip), _p(w1h), _p(w2h), _p(mean), _p(gate), _p(z1), B, H * W, C, R, _stream())
     return mean, gate, z1
+
+
+def skip_gate_fwd_multi(items):
+    """skip_gate_fwd for several skip tensors of ONE channel count in one launch: items = sequence (<= 32) of
+    (skip, w1h, w2h) -> list of (mean, gate, z1), the values of the per-tensor call."""
+    n = len(items)
+    if not 0 < n <= 32:
+        raise ValueError("skip_gate_fwd_multi: 1..32 gates per launch")
+    arr = (_lib.SkipGateFwdItem * n)()
+    out = []
+    C0 = items[0][0].shape[-1]
+    for k, (skip, w1h, w2h) in enumerate(items):
+        B, H, W, C = _nhwc(skip, "skip")
+        if C != C0:
+            raise ValueError("skip_gate_fwd_multi: the gates of one launch share a channel count")
+        R = w1h.shape[0]
+        _chk(w1h, f32, "w1h", (R, C + 1))
+        _chk(w2h, f32, "w2h", (C, R))
+        mean = torch.empty(B, C, device=skip.device, dtype=f32)
+        gate = torch.empty(B, C, device=skip.device, dtype=f32)
+        z1 = torch.empty(B, R, device=skip.device, dtype=f32)
+        arr[k] = _lib.SkipGateFwdItem(skip.data_ptr(), w1h.data_ptr(), w2h.data_ptr(), mean.data_ptr(), gate.data_ptr(),
+                                      z1.data_ptr(), B, H * W, C, R)
+        out.append((mean, gate, z1))
+    th, td, defer, release = _tables.take(items[0][0].device)
+    _lib.call("edm_skip_gate_fwd_multi", ctypes.byref(arr), n, ctypes.c_void_p(th), ctypes.c_void_p(td), defer, _stream())
+    release()
+    return out
 
 
 def skip_gate_bwd(gcat, Ci, skip, mean, w1h, w2h, gate, z1, defer_wgrad=False):
