@@ -298,6 +298,35 @@ typedef struct {
 long edm_skip_gate_fwd_multi_table_bytes(void);
 int edm_skip_gate_fwd_multi(const edm_skip_gate_fwd_item* items, int n, void* table_host, void* table_dev, int defer_upload,
                             edm_stream_t stream);
+/* ... and the backward of those gates, deferred: nothing on the backward's critical chain needs a gate's gmean (it only feeds
+ * the gradient of the U-Net skip, which the encoder's backward consumes), so the decoder blocks queue and the last one
+ * launches (a) edm_skip_gate_bwd_multi = the first launch of edm_skip_gate_bwd (gmean, ws written; weight gradients by
+ * edm_skip_gate_wgrad_multi as before) for all gates of one channel count, (b) edm_skip_half_bwd_multi = edm_skip_half_bwd for
+ * all their tensors.  Tables of edm_skip_gate_bwd_multi_table_bytes() bytes. */
+typedef struct {
+  const void* gcat;     /* bf16 rows of gcat_stride elements; channels [c_off, c_off + C) = d loss / d (skip * gate) */
+  long gcat_stride;
+  const void* skip;     /* bf16 [B*HW][C] */
+  const float* W1h;
+  const float* W2h;
+  const float* gate;
+  const float* z1save;
+  float* gmean;         /* [B][C]       written */
+  float* ws;            /* [B][C + 2R]  written */
+  int c_off, B, HW, C, R, pad;
+} edm_skip_gate_bwd_item;
+typedef struct {
+  const void* gcs;      /* bf16 [B*HW][Cs] */
+  const float* gate;
+  const float* gmean;
+  void* gskip;          /* bf16 [B*HW][Cs]  written: gcs * gate + gmean / HW */
+  int B, HW, Cs, pad;
+} edm_skip_half_bwd_item;
+long edm_skip_gate_bwd_multi_table_bytes(void);
+int edm_skip_gate_bwd_multi(const edm_skip_gate_bwd_item* items, int n, void* table_host, void* table_dev, int defer_upload,
+                            edm_stream_t stream);
+int edm_skip_half_bwd_multi(const edm_skip_half_bwd_item* items, int n, void* table_host, void* table_dev, int defer_upload,
+                            edm_stream_t stream);
 /* cat = [inp, skip*gate] (networks.py:311) and backward */
 int edm_concat_gate_fwd(const void* inp, const void* skip, const float* gate, void* cat, void* silu_out, int B, int HW,
                         int Ci, int Cs, edm_stream_t stream);

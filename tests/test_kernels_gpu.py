@@ -874,3 +874,27 @@ def test_skip_gate_fwd_multi_matches_the_per_tensor_launches(ops):
     other = nhwc(q(torch.randn(2, 128, 4, 4, generator=g)))
     with pytest.raises(ValueError):
         ops.skip_gate_fwd_multi([items[0], (other, torch.zeros(8, 129, device=DEV), torch.zeros(128, 8, device=DEV))])
+
+
+def test_skip_gate_backward_multi_matches_the_per_tensor_launches(ops):
+    """edm_skip_gate_bwd_multi + edm_skip_half_bwd_multi (round 6: the deferred backward of every decoder gate, two launches):
+    gmean, the per-sample scratch ws and the skip gradient of each gate bit for bit those of edm_skip_gate_bwd (deferred
+    weight-gradient form) + edm_skip_half_bwd, for different map / batch sizes and hidden widths."""
+    g = torch.Generator().manual_seed(78)
+    C = 256
+    gates, ref = [], []
+    for B, H, W, R in [(128, 32, 32, 16), (64, 16, 16, 16), (5, 8, 8, 24), (3, 5, 7, 8)]:
+        skip = nhwc(q(torch.randn(B, C, H, W, generator=g)))
+        gcs = nhwc(q(torch.randn(B, C, H, W, generator=g)))
+        w1h = (torch.randn(R, C + 1, generator=g) / math.sqrt(C + 1)).to(DEV)
+        w2h = (torch.randn(C, R, generator=g) / math.sqrt(R)).to(DEV)
+        mean, gate, z1 = ops.skip_gate_fwd(skip, w1h, w2h)
+        gmean, ws = ops.skip_gate_bwd(gcs, 0, skip, mean, w1h, w2h, gate, z1, defer_wgrad=True)
+        ref.append((gmean, ws, ops.skip_half_bwd(gcs, gate, gmean)))
+        gates.append((gcs, 0, skip, w1h, w2h, gate, z1))
+    got = ops.skip_gate_bwd_multi(gates)
+    holders = [torch.full_like(gt[0], float("nan")) for gt in gates]
+    ops.skip_half_bwd_multi([(gt[0], gt[5], gm, h) for gt, (gm, _), h in zip(gates, got, holders)])
+    for (gmean, ws), h, (gmean0, ws0, gskip0) in zip(got, holders, ref):
+        assert torch.equal(gmean, gmean0) and torch.equal(ws, ws0)
+        assert torch.equal(h, gskip0)

@@ -42,6 +42,9 @@ SIGNATURES = {
     "edm_skip_gate_wgrad_multi_table_bytes": [],
     "edm_skip_gate_fwd_multi": [P, I, P, P, I, P],
     "edm_skip_gate_fwd_multi_table_bytes": [],
+    "edm_skip_gate_bwd_multi": [P, I, P, P, I, P],
+    "edm_skip_half_bwd_multi": [P, I, P, P, I, P],
+    "edm_skip_gate_bwd_multi_table_bytes": [],
     "edm_concat_gate_fwd": [P, P, P, P, P, I, I, I, I, P],
     "edm_concat_gate_bwd": [P, P, P, P, P, I, I, I, I, P],
     "edm_skip_half_fwd": [P, P, P, P, I, I, I, I, P],
@@ -138,9 +141,9 @@ DIAG_SIGNATURES = {
     "edm_v6_persistent_launches": [],
 }
 _RET = {"edm_last_error": ctypes.c_char_p, "edm_v6_persistent_launches": ctypes.c_long, "edm_wgrad3_workspace": ctypes.c_long, "edm_wgrad3_table_bytes": ctypes.c_long,
-        "edm_skip_gate_wgrad_multi_table_bytes": ctypes.c_long, "edm_skip_gate_fwd_multi_table_bytes": ctypes.c_long,
+        "edm_skip_gate_wgrad_multi_table_bytes": ctypes.c_long, "edm_skip_gate_fwd_multi_table_bytes": ctypes.c_long, "edm_skip_gate_bwd_multi_table_bytes": ctypes.c_long,
         "edm_conv_wgrad_1x1_group_table_bytes": ctypes.c_long, "edm_wgrad_finish_multi_table_bytes": ctypes.c_long}
-_NO_STATUS = {"edm_skip_gate_fwd_multi_table_bytes", "edm_v6_persistent_launches", "edm_conv3x3_fold_supported", "edm_skip_gate_wgrad_multi_table_bytes", "edm_version", "edm_graph_replay_safe", "edm_last_error", "edm_conv_wgrad_nsplit", "edm_conv_wgrad_1x1_nsplit", "edm_conv_wgrad_1x1_nsplit_grouped", "edm_wgrad3_workspace", "edm_wgrad3_table_bytes",
+_NO_STATUS = {"edm_skip_gate_bwd_multi_table_bytes", "edm_skip_gate_fwd_multi_table_bytes", "edm_v6_persistent_launches", "edm_conv3x3_fold_supported", "edm_skip_gate_wgrad_multi_table_bytes", "edm_version", "edm_graph_replay_safe", "edm_last_error", "edm_conv_wgrad_nsplit", "edm_conv_wgrad_1x1_nsplit", "edm_conv_wgrad_1x1_nsplit_grouped", "edm_wgrad3_workspace", "edm_wgrad3_table_bytes",
               "edm_conv_wgrad_1x1_group_table_bytes", "edm_wgrad_finish_multi_table_bytes", "edm_attention_qkv_supported"}
 
 _lib = None
@@ -165,6 +168,17 @@ class SkipGateFwdItem(ctypes.Structure):
     """edm_skip_gate_fwd_item (include/tinyedm_hip.h): one ScaleLong gate of a grouped forward launch."""
     _fields_ = [("skip", P), ("W1h", P), ("W2h", P), ("mean", P), ("gate", P), ("z1save", P), ("B", I), ("HW", I), ("C", I),
                 ("R", I)]
+
+
+class SkipGateBwdItem(ctypes.Structure):
+    """edm_skip_gate_bwd_item (include/tinyedm_hip.h)"""
+    _fields_ = [("gcat", P), ("gcat_stride", L), ("skip", P), ("W1h", P), ("W2h", P), ("gate", P), ("z1save", P), ("gmean", P),
+                ("ws", P), ("c_off", I), ("B", I), ("HW", I), ("C", I), ("R", I), ("pad", I)]
+
+
+class SkipHalfBwdItem(ctypes.Structure):
+    """edm_skip_half_bwd_item (include/tinyedm_hip.h)"""
+    _fields_ = [("gcs", P), ("gate", P), ("gmean", P), ("gskip", P), ("B", I), ("HW", I), ("Cs", I), ("pad", I)]
 
 
 class WGrad1Item(ctypes.Structure):

@@ -865,17 +865,16 @@ __global__ __launch_bounds__(1024) void k_skip_gate_fwd_multi(const SgfGroup* __
 // workgroup (the first form of this kernel) meant B-way contention on each of the 2 C R addresses -- 20 us per launch
 // whatever the image size.  Each workgroup now leaves its vectors (d z2, d z1, h) in ws[b][C + 2R] and
 // k_skip_gate_wgrad sums the outer products over b in a fixed order.
-__global__ __launch_bounds__(1024) void k_skip_gate_bwd(const bf16* __restrict__ gcat, long gs, const bf16* __restrict__ skip,
-                                                          const float* __restrict__ W1, const float* __restrict__ W2,
-                                                          const float* __restrict__ gate, const float* __restrict__ z1save,
-                                                          float* __restrict__ gmean, float* __restrict__ ws, int HW, int C,
-                                                          int R) {
+__device__ __forceinline__ void skip_gate_bwd_body(const bf16* __restrict__ gcat, long gs, const bf16* __restrict__ skip,
+                                                   const float* __restrict__ W1, const float* __restrict__ W2,
+                                                   const float* __restrict__ gate, const float* __restrict__ z1save,
+                                                   float* __restrict__ gmean, float* __restrict__ ws, int HW, int C,
+                                                   int R, int b) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // red[rpp*C] | gz2[C] | gz1[R]
   const int rpp = blockDim.x / (C >> 3);
   float* red = sm;
   float* gz2 = sm + rpp * C;
   float* gz1 = gz2 + C;
-  const int b = blockIdx.x;
   float* wsb = ws + (long)b * (C + 2 * R);
   sample_reduce<true>(gcat + (long)b * HW * gs, gs, skip + (long)b * HW * C, C, HW, C, red, gz2, 1.0f);   // gz2 <- ggate
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -897,6 +896,41 @@ __global__ __launch_bounds__(1024) void k_skip_gate_bwd(const bf16* __restrict__
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) gmean[(long)b * C + c] = strided_dot(W1 + c, C + 1, gz1, R);
+}
+__global__ __launch_bounds__(1024) void k_skip_gate_bwd(const bf16* __restrict__ gcat, long gs, const bf16* __restrict__ skip,
+                                                          const float* __restrict__ W1, const float* __restrict__ W2,
+                                                          const float* __restrict__ gate, const float* __restrict__ z1save,
+                                                          float* __restrict__ gmean, float* __restrict__ ws, int HW, int C,
+                                                          int R) {
+  skip_gate_bwd_body(gcat, gs, skip, W1, W2, gate, z1save, gmean, ws, HW, C, R, blockIdx.x);
+}
+// The per-sample backward passes of SEVERAL gates in one launch (round 6; the forward's k_skip_gate_fwd_multi has the why: one
+// workgroup per sample is 128 workgroups on 256 CUs).  Nothing on the backward's critical chain needs a gate's gmean -- it only
+// feeds the gradient of the U-Net skip, which the ENCODER's backward consumes -- so the decoder blocks queue their gate
+// backward and the last of them launches all (networks.py _flush_sgb).  Same body, same values.
+struct SgbItem {
+  const bf16* gcat;
+  long gs;
+  const bf16* skip;
+  const float* W1;
+  const float* W2;
+  const float* gate;
+  const float* z1;
+  float* gmean;
+  float* ws;
+  int B, HW, R, blk0;
+};
+struct SgbGroup {
+  SgbItem it[MAXSGF];
+  int n, C, pad[2];
+};
+__global__ __launch_bounds__(1024) void k_skip_gate_bwd_multi(const SgbGroup* __restrict__ g) {
+  int k = 0;
+  const int n = g->n;
+  while (k + 1 < n && (int)blockIdx.x >= g->it[k + 1].blk0) ++k;
+  const SgbItem it = g->it[k];
+  skip_gate_bwd_body(it.gcat, it.gs, it.skip, it.W1, it.W2, it.gate, it.z1, it.gmean, it.ws, it.HW, g->C, it.R,
+                     (int)blockIdx.x - it.blk0);
 }
 // gW2[c][r] = sum_b dz2[b][c] h[b][r];  gW1[r][c'] = sum_b dz1[b][r] [mean[b]; 1][c']   (b ascending: reproducible).
 // A workgroup owns four columns of the C (resp. C+1) dimension and all R rows: it stages A[b][4] and Bm[b][R] in LDS with
@@ -1065,6 +1099,55 @@ extern "C" int edm_skip_gate_bwd(const void* gcat, long gcat_stride, int c_off, 
   return EDM_OK;
 }
 
+struct edm_skip_gate_bwd_item_ {   // = edm_skip_gate_bwd_item (include/tinyedm_hip.h)
+  const void* gcat;
+  long gcat_stride;
+  const void* skip;
+  const float* W1h;
+  const float* W2h;
+  const float* gate;
+  const float* z1save;
+  float* gmean;
+  float* ws;
+  int c_off, B, HW, C, R, pad;
+};
+// the first launch of edm_skip_gate_bwd (gW1h == gW2h == NULL form: gmean and ws written) for up to 32 gates of ONE channel
+// count at once
+extern "C" int edm_skip_gate_bwd_multi(const void* items_, int n, void* table_host, void* table_dev, int defer_upload,
+                                       hipStream_t st) {
+  const edm_skip_gate_bwd_item_* items = (const edm_skip_gate_bwd_item_*)items_;
+  EDM_REQUIRE(items && n > 0 && n <= MAXSGF, "skip_gate_bwd_multi: need 1..%d gates, got %d", MAXSGF, n);
+  SgbGroup g;
+  g.n = n;
+  g.C = items[0].C;
+  g.pad[0] = g.pad[1] = 0;
+  const int C = g.C;
+  EDM_REQUIRE(C > 0 && C % 8 == 0 && C <= 4096, "skip_gate_bwd_multi: bad channel count %d", C);
+  const int threads = skip_gate_threads(C);
+  EDM_REQUIRE(threads > 0, "skip_gate_bwd_multi: C too large");
+  long blk = 0;
+  int rmax = 0;
+  for (int k = 0; k < n; ++k) {
+    const edm_skip_gate_bwd_item_& a = items[k];
+    EDM_REQUIRE(a.gcat && a.skip && a.W1h && a.W2h && a.gate && a.z1save && a.gmean && a.ws,
+                "skip_gate_bwd_multi: null pointer (gate %d)", k);
+    EDM_REQUIRE(a.C == C, "skip_gate_bwd_multi: the gates of one launch share a channel count (%d vs %d)", a.C, C);
+    EDM_REQUIRE(a.B > 0 && a.HW > 0 && a.R > 0 && a.R <= 1024 && a.c_off >= 0 && a.c_off % 8 == 0 &&
+                    a.gcat_stride >= a.c_off + C && a.gcat_stride % 8 == 0, "skip_gate_bwd_multi: bad item %d", k);
+    g.it[k] = SgbItem{(const bf16*)a.gcat + a.c_off, a.gcat_stride, (const bf16*)a.skip, a.W1h, a.W2h, a.gate, a.z1save,
+                      a.gmean, a.ws, a.B, a.HW, a.R, (int)blk};
+    blk += a.B;
+    EDM_REQUIRE(blk < (1L << 30), "skip_gate_bwd_multi: grid too large");
+    if (a.R > rmax) rmax = a.R;
+  }
+  for (int k = n; k < MAXSGF; ++k)
+    g.it[k] = SgbItem{nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, (int)blk};
+  const size_t lds = ((size_t)(threads / (C / 8)) * C + C + rmax) * sizeof(float);
+  EDM_UPLOAD_TABLE(table_dev, table_host, &g, sizeof(SgbGroup), st, "skip_gate_bwd_multi", defer_upload);
+  hipLaunchKernelGGL(k_skip_gate_bwd_multi, dim3((unsigned)blk), dim3(threads), lds, st, (const SgbGroup*)table_dev);
+  EDM_CHECK_LAUNCH("skip_gate_bwd_multi");
+  return EDM_OK;
+}
 struct edm_skip_gate_wgrad_item_ {   // = edm_skip_gate_wgrad_item (include/tinyedm_hip.h)
   const float* ws;
   const float* mean;
@@ -1175,11 +1258,11 @@ __global__ void k_skip_half_fwd(const bf16* __restrict__ skip, const float* __re
   }
 }
 // gskip = gcs*gate + gmean/HW  (gcs: the skip half of d loss / d cat, [B*HW][Cs], written by the split-output 1x1 dgrad)
-__global__ void k_skip_half_bwd(const bf16* __restrict__ gcs, const float* __restrict__ gate,
-                                const float* __restrict__ gmean, bf16* __restrict__ gskip, int HW, int Cs, long n8,
-                                float inv_hw) {
+__device__ __forceinline__ void skip_half_bwd_body(const bf16* __restrict__ gcs, const float* __restrict__ gate,
+                                                   const float* __restrict__ gmean, bf16* __restrict__ gskip, int HW, int Cs,
+                                                   long n8, float inv_hw, long first, long stride) {
   const int CLs = Cs >> 3;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+  for (long i = first; i < n8; i += stride) {
     const int cs = (int)(i % CLs) * 8;
     const int b = (int)((i / CLs) / HW);
     float v[8];
@@ -1190,6 +1273,34 @@ __global__ void k_skip_half_bwd(const bf16* __restrict__ gcs, const float* __res
     for (int j = 0; j < 8; ++j) v[j] = v[j] * gp[j] + mp[j] * inv_hw;
     store8(gskip + i * 8, v);
   }
+}
+__global__ void k_skip_half_bwd(const bf16* __restrict__ gcs, const float* __restrict__ gate,
+                                const float* __restrict__ gmean, bf16* __restrict__ gskip, int HW, int Cs, long n8,
+                                float inv_hw) {
+  skip_half_bwd_body(gcs, gate, gmean, gskip, HW, Cs, n8, inv_hw, (long)blockIdx.x * blockDim.x + threadIdx.x,
+                     (long)gridDim.x * blockDim.x);
+}
+// ... and the gradients of the gated skips of those gates, one launch: item k owns the workgroups [blk0, blk0 + nblk)
+struct ShbItem {
+  const bf16* gcs;
+  const float* gate;
+  const float* gmean;
+  bf16* gskip;
+  long n8;
+  float inv_hw;
+  int HW, Cs, blk0, nblk, pad;
+};
+struct ShbGroup {
+  ShbItem it[MAXSGF];
+  int n, pad[3];
+};
+__global__ void k_skip_half_bwd_multi(const ShbGroup* __restrict__ g) {
+  int k = 0;
+  const int n = g->n;
+  while (k + 1 < n && (int)blockIdx.x >= g->it[k + 1].blk0) ++k;
+  const ShbItem it = g->it[k];
+  skip_half_bwd_body(it.gcs, it.gate, it.gmean, it.gskip, it.HW, it.Cs, it.n8, it.inv_hw,
+                     (long)((int)blockIdx.x - it.blk0) * blockDim.x + threadIdx.x, (long)it.nblk * blockDim.x);
 }
 extern "C" int edm_skip_half_fwd(const void* skip, const float* gate, void* cat, void* silu_out, int B, int HW, int Ci,
                                  int Cs, hipStream_t st) {
@@ -1211,6 +1322,42 @@ extern "C" int edm_skip_half_bwd(const void* gcs, const float* gate, const float
   EDM_CHECK_LAUNCH("skip_half_bwd");
   return EDM_OK;
 }
+extern "C" long edm_skip_gate_bwd_multi_table_bytes(void) {
+  return (long)(sizeof(SgbGroup) > sizeof(ShbGroup) ? sizeof(SgbGroup) : sizeof(ShbGroup));
+}
+struct edm_skip_half_bwd_item_ {   // = edm_skip_half_bwd_item (include/tinyedm_hip.h)
+  const void* gcs;
+  const float* gate;
+  const float* gmean;
+  void* gskip;
+  int B, HW, Cs, pad;
+};
+// edm_skip_half_bwd for up to 32 tensors at once (table of edm_skip_gate_bwd_multi_table_bytes() bytes)
+extern "C" int edm_skip_half_bwd_multi(const void* items_, int n, void* table_host, void* table_dev, int defer_upload,
+                                       hipStream_t st) {
+  const edm_skip_half_bwd_item_* items = (const edm_skip_half_bwd_item_*)items_;
+  EDM_REQUIRE(items && n > 0 && n <= MAXSGF, "skip_half_bwd_multi: need 1..%d tensors, got %d", MAXSGF, n);
+  ShbGroup g;
+  g.n = n;
+  g.pad[0] = g.pad[1] = g.pad[2] = 0;
+  long blk = 0;
+  for (int k = 0; k < n; ++k) {
+    const edm_skip_half_bwd_item_& a = items[k];
+    EDM_REQUIRE(a.gcs && a.gate && a.gmean && a.gskip, "skip_half_bwd_multi: null pointer (tensor %d)", k);
+    EDM_REQUIRE(a.B > 0 && a.HW > 0 && a.Cs % 8 == 0 && a.Cs > 0, "skip_half_bwd_multi: bad item %d", k);
+    const long n8 = (long)a.B * a.HW * a.Cs / 8;
+    const int nblk = grid_for(n8, 256);
+    g.it[k] = ShbItem{(const bf16*)a.gcs, a.gate, a.gmean, (bf16*)a.gskip, n8, 1.0f / (float)a.HW, a.HW, a.Cs, (int)blk, nblk, 0};
+    blk += nblk;
+    EDM_REQUIRE(blk < (1L << 30), "skip_half_bwd_multi: grid too large");
+  }
+  for (int k = n; k < MAXSGF; ++k) g.it[k] = ShbItem{nullptr, nullptr, nullptr, nullptr, 0, 0.f, 1, 8, (int)blk, 0, 0};
+  EDM_UPLOAD_TABLE(table_dev, table_host, &g, sizeof(ShbGroup), st, "skip_half_bwd_multi", defer_upload);
+  hipLaunchKernelGGL(k_skip_half_bwd_multi, dim3((unsigned)blk), dim3(256), 0, st, (const ShbGroup*)table_dev);
+  EDM_CHECK_LAUNCH("skip_half_bwd_multi");
+  return EDM_OK;
+}
+
 extern "C" int edm_concat_gate_fwd(const void* inp, const void* skip, const float* gate, void* cat, void* silu_out,
                                    int B, int HW, int Ci, int Cs, hipStream_t st) {
   EDM_REQUIRE(B > 0 && HW > 0 && Ci % 8 == 0 && Cs % 8 == 0 && Ci > 0 && Cs > 0, "concat_gate_fwd: bad args");

@@ -167,6 +167,7 @@ _bwd_end_queued = set()     # devices whose end-of-backward callback is queued f
 # the gates of a backward pass in ONE launch behind it (round 6: nine launches less on the backward's chain); their finish
 # rides in the last multi-tensor finish.  Arena mode only; EDM_SG_DEFER=0: per gate, as round 5.
 SG_MULTI = os.environ.get("EDM_SG_MULTI", "1") != "0"     # every decoder gate of a forward pass in one launch (round 6)
+SG_BWD_MULTI = os.environ.get("EDM_SG_BWD_MULTI", "1") != "0"   # ... and their backward, deferred to the last of them
 SG_DEFER = os.environ.get("EDM_SG_DEFER", "1") != "0"
 _sg_pending = {}            # device index -> [(ScaleLong module, ws, mean, R)]
 _w3_pending = {}            # device index -> [(mod, x, dy, scale)] 3x3 layers waiting for their grouped launch
@@ -928,8 +929,9 @@ class _ResBlockFn(torch.autograd.Function):
         ctx.has_skip = skip is not None
         if skip is not None:
             sl = blk.cat_factor
+            ctx.sgb = None
             if gate_pre is not None:    # (SG_MULTI: the Denoiser computed every decoder gate in one launch behind the encoder)
-                mean, gate, z1, w1h, w2h = gate_pre
+                mean, gate, z1, w1h, w2h, ctx.sgb = gate_pre
             else:
                 w1h, w2h = sl.layer1.packs()[2], sl.layer2.packs()[2]
                 mean, gate, z1 = ops.skip_gate_fwd(skip, w1h, w2h)      # mean over H*W + gate MLP: one launch
@@ -1086,20 +1088,34 @@ class _ResBlockFn(torch.autograd.Function):
             sl = blk.cat_factor
             wsl = (sl.layer1.weight, sl.layer2.weight)
             defer = SG_DEFER and all(w.grad is not None and getattr(w, "_edm_direct", False) for w in wsl)
+            sgb = getattr(ctx, "sgb", None)
+            queued = False
             if gcs is None:             # (no split form for this shape: the skip half is read out of gcat in place)
                 gmean, *gws = ops.skip_gate_bwd(gu, Ci, skip, mean, w1h, w2h, gate, z1, defer_wgrad=defer)
                 gu, gskip = ops.concat_gate_bwd(gu, gate, gmean, Ci)
+            elif defer and sgb is not None and SG_BWD_MULTI:
+                # nothing on the backward's chain needs this gate's backward: only the gradient of the U-Net skip does, and
+                # the ENCODER consumes that.  gskip goes out as a placeholder; the last decoder gate of the pass to get here
+                # runs the gate backward of all of them in one launch and fills every placeholder in a second (_SgbPass)
+                gskip = torch.empty_like(gcs)
+                sgb.pending.append((gcs, skip, w1h, w2h, gate, z1, gskip, sl, mean))
+                queued = True
             else:
                 gmean, *gws = ops.skip_gate_bwd(gcs, 0, skip, mean, w1h, w2h, gate, z1, defer_wgrad=defer)
                 gskip = ops.skip_half_bwd(gcs, gate, gmean)
             if defer:       # the batch sums of every gate's weight gradients: one launch at the end of the pass (_flush_sg)
-                _sg_pending.setdefault(wsl[0].device.index, []).append((sl, gws[0], mean, w1h.shape[0]))
+                if not queued:
+                    _sg_pending.setdefault(wsl[0].device.index, []).append((sl, gws[0], mean, w1h.shape[0]))
                 wsl[0]._edm_deferred = wsl[1]._edm_deferred = True
                 _queue_backward_end(wsl[0].device)
             else:
                 gw1h, gw2h = gws
                 gwsl1 = sl.layer1.finish_grad(gw1h.view(1, 1, *gw1h.shape))
                 gwsl2 = sl.layer2.finish_grad(gw2h.view(1, 1, *gw2h.shape))
+            if sgb is not None:
+                sgb.arrived += 1
+                if sgb.arrived == sgb.expected:
+                    sgb.flush()
         if g_alias is not None:         # decoder blocks are never asked for an alias; kept for completeness
             gu = ops.axpby(gu, 1.0, g_alias, 1.0)
         return (gu, gemb, gw11, gw1, gw2, gwemb, ggain, None, None, None, gtoken, None, None, None, gskip, gwsl1, gwsl2,
@@ -1902,6 +1918,34 @@ class Denoiser(nn.Module):
         return D.to(noisy_image.dtype)
 
 
+class _SgbPass:
+    """The decoder gates of ONE forward pass whose backward is deferred (SG_BWD_MULTI): each block's backward queues
+    (gcs, skip, weights, gate, z1, its gskip placeholder) and counts itself in; the last one flushes -- one
+    skip_gate_bwd_multi per channel count, one skip_half_bwd_multi over every placeholder -- before any consumer of a
+    placeholder (the encoder's backward; autograd's sum for the last encoder output) can run."""
+
+    def __init__(self, expected: int):
+        self.expected, self.arrived, self.pending = expected, 0, []
+
+    def flush(self):
+        items, self.pending = self.pending, []
+        if not items:
+            return
+        by_c = {}
+        for it in items:
+            by_c.setdefault(it[1].shape[-1], []).append(it)
+        halves = []
+        for group in by_c.values():
+            for k0 in range(0, len(group), 32):
+                part = group[k0:k0 + 32]
+                res = ops.skip_gate_bwd_multi([(gcs, 0, skip, w1h, w2h, gate, z1) for gcs, skip, w1h, w2h, gate, z1, _, _, _ in part])
+                for (gcs, skip, w1h, w2h, gate, z1, gskip, sl, mean), (gmean, ws) in zip(part, res):
+                    halves.append((gcs, gate, gmean, gskip))
+                    _sg_pending.setdefault(sl.layer1.weight.device.index, []).append((sl, ws, mean, w1h.shape[0]))
+        for k0 in range(0, len(halves), 32):
+            ops.skip_half_bwd_multi(halves[k0:k0 + 32])
+
+
 def _decoder_gates_impl(dec, skips):
     """{decoder block: (mean, gate, z1, w1h, w2h)} for every block whose ScaleLong gate lives in its autograd node: the gates
     depend on the skip tensors and two small weights only, so all of them are computed HERE, behind the encoder, by one
@@ -1917,12 +1961,13 @@ def _decoder_gates_impl(dec, skips):
         sl = block.cat_factor
         todo.setdefault(skip.shape[-1], []).append((block, skip, sl.layer1.packs()[2], sl.layer2.packs()[2]))
     out = {}
+    tok = _SgbPass(sum(len(v) for v in todo.values())) if torch.is_grad_enabled() else None
     for items in todo.values():
         for k0 in range(0, len(items), 32):
             part = items[k0:k0 + 32]
             res = ops.skip_gate_fwd_multi([(skip, w1h, w2h) for _, skip, w1h, w2h in part])
             for (block, _, w1h, w2h), (mean, gate, z1) in zip(part, res):
-                out[block] = (mean, gate, z1, w1h, w2h)
+                out[block] = (mean, gate, z1, w1h, w2h, tok)
     return out
 
 

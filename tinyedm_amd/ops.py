@@ -164,7 +164,7 @@ class _LaunchTables:
                                    "or bracket the capture with ops.capture_begin() / capture_end()")
             nb = max(int(_lib.call("edm_wgrad3_table_bytes")), int(_lib.call("edm_conv_wgrad_1x1_group_table_bytes")),
                      int(_lib.call("edm_wgrad_finish_multi_table_bytes")), int(_lib.call("edm_skip_gate_wgrad_multi_table_bytes")),
-                     int(_lib.call("edm_skip_gate_fwd_multi_table_bytes")))
+                     int(_lib.call("edm_skip_gate_fwd_multi_table_bytes")), int(_lib.call("edm_skip_gate_bwd_multi_table_bytes")))
             nb = (nb + 255) // 256 * 256
             d = torch.device("cuda", key)
             st = self.dev[key] = {
@@ -561,6 +561,54 @@ def skip_gate_fwd_multi(items):
     _lib.call("edm_skip_gate_fwd_multi", ctypes.byref(arr), n, ctypes.c_void_p(th), ctypes.c_void_p(td), defer, _stream())
     release()
     return out
+
+
+def skip_gate_bwd_multi(items):
+    """the per-sample pass of skip_gate_bwd(defer_wgrad=True) for several gates of ONE channel count in one launch:
+    items = sequence (<= 32) of (gcat, Ci, skip, w1h, w2h, gate, z1) -> list of (gmean (B, C), ws (B, C + 2R))."""
+    n = len(items)
+    if not 0 < n <= 32:
+        raise ValueError("skip_gate_bwd_multi: 1..32 gates per launch")
+    arr = (_lib.SkipGateBwdItem * n)()
+    out = []
+    C0 = items[0][2].shape[-1]
+    for k, (gcat, Ci, skip, w1h, w2h, gate, z1) in enumerate(items):
+        B, H, W, Ct = _nhwc(gcat, "gcat")
+        Bs, Hs, Ws, C = _nhwc(skip, "skip")
+        if (Bs, Hs, Ws) != (B, H, W) or Ct != Ci + C or C != C0:
+            raise ValueError("skip_gate_bwd_multi: gcat/skip shape mismatch, or mixed channel counts in one launch")
+        R = w1h.shape[0]
+        _chk(w1h, f32, "w1h", (R, C + 1))
+        _chk(w2h, f32, "w2h", (C, R))
+        _chk(gate, f32, "gate", (B, C))
+        _chk(z1, f32, "z1", (B, R))
+        gmean = torch.empty(B, C, device=skip.device, dtype=f32)
+        ws = torch.empty(B, C + 2 * R, device=skip.device, dtype=f32)
+        arr[k] = _lib.SkipGateBwdItem(gcat.data_ptr(), Ct, skip.data_ptr(), w1h.data_ptr(), w2h.data_ptr(), gate.data_ptr(),
+                                      z1.data_ptr(), gmean.data_ptr(), ws.data_ptr(), Ci, B, H * W, C, R, 0)
+        out.append((gmean, ws))
+    th, td, defer, release = _tables.take(items[0][2].device)
+    _lib.call("edm_skip_gate_bwd_multi", ctypes.byref(arr), n, ctypes.c_void_p(th), ctypes.c_void_p(td), defer, _stream())
+    release()
+    return out
+
+
+def skip_half_bwd_multi(items):
+    """skip_half_bwd for several tensors in one launch: items = sequence (<= 32) of (gcs, gate, gmean, gskip) with gskip an
+    uninitialised tensor like gcs that is WRITTEN (the caller handed it out earlier as a placeholder)."""
+    n = len(items)
+    if not 0 < n <= 32:
+        raise ValueError("skip_half_bwd_multi: 1..32 tensors per launch")
+    arr = (_lib.SkipHalfBwdItem * n)()
+    for k, (gcs, gate, gmean, gskip) in enumerate(items):
+        B, H, W, Cs = _nhwc(gcs, "gcs")
+        _chk(gate, f32, "gate", (B, Cs))
+        _chk(gmean, f32, "gmean", (B, Cs))
+        _chk(gskip, bf16, "gskip", (B, H, W, Cs))
+        arr[k] = _lib.SkipHalfBwdItem(gcs.data_ptr(), gate.data_ptr(), gmean.data_ptr(), gskip.data_ptr(), B, H * W, Cs, 0)
+    th, td, defer, release = _tables.take(items[0][0].device)
+    _lib.call("edm_skip_half_bwd_multi", ctypes.byref(arr), n, ctypes.c_void_p(th), ctypes.c_void_p(td), defer, _stream())
+    release()
 
 
 def skip_gate_bwd(gcat, Ci, skip, mean, w1h, w2h, gate, z1, defer_wgrad=False):
