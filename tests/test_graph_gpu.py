@@ -284,9 +284,10 @@ def test_captured_launch_table_pool_grows_outside_capture():
     from tinyedm_amd import ops
     t = ops._tables
     st = t._state(torch.cuda.current_device())
-    before_chunks, before_i = len(st["pool_devb"]), st["pool_i"]
+    before_chunks, before_i, before_free = len(st["pool_devb"]), st["pool_i"], list(st["free"])
     try:
-        st["pool_i"] = len(st["pool_devb"]) * t.POOL - 3          # three slots left
+        st["pool_i"] = len(st["pool_devb"]) * t.POOL - 3          # three slots left ...
+        st["free"][:] = []                                        # ... and none handed back by graphs that are gone
         ops.capture_begin()
         assert len(st["pool_devb"]) == before_chunks + 1
         assert len(st["pool_devb"]) * t.POOL - st["pool_i"] >= 64
@@ -294,6 +295,7 @@ def test_captured_launch_table_pool_grows_outside_capture():
     finally:
         ops.capture_end()
         st["pool_i"] = max(before_i, 0)
+        st["free"][:] = before_free
 
 
 def test_launch_table_slots_are_released_and_bare_captures_have_their_own_index():

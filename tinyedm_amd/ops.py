@@ -224,7 +224,7 @@ class _LaunchTables:
     def begin(self):
         self.deferring, self.pending, self.taken, self.pins = True, [], [], []
         if torch.cuda.is_available():
-            self._reserve(self._state(torch.cuda.current_device()), 64)     # (a captured training step takes 9)
+            self._reserve(self._state(torch.cuda.current_device()), 64)     # (a captured training step takes 12)
 
     def end(self):
         """upload the tables of the capture that just ended (their launches have only been recorded so far)"""
