@@ -1929,6 +1929,7 @@ class _SgbPass:
 
     def flush(self):
         items, self.pending = self.pending, []
+        self.arrived = 0            # (a second backward over a retained graph counts its gates in again)
         if not items:
             return
         by_c = {}
