@@ -293,7 +293,9 @@ typedef struct {
   float* mean;          /* [B][C]  written */
   float* gate;          /* [B][C]  written */
   float* z1save;        /* [B][R]  written */
-  int B, HW, C, R;
+  void* cat;            /* optional: bf16 rows of Ci + C elements; columns [Ci, Ci + C) receive skip * gate (edm_skip_half_fwd's */
+  void* silu_out;       /* work, done by the workgroup that just reduced the sample) and, if given, mp_silu of it here */
+  int B, HW, C, R, Ci, pad;
 } edm_skip_gate_fwd_item;
 long edm_skip_gate_fwd_multi_table_bytes(void);
 int edm_skip_gate_fwd_multi(const edm_skip_gate_fwd_item* items, int n, void* table_host, void* table_dev, int defer_upload,

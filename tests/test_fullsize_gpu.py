@@ -380,14 +380,15 @@ def test_resample_fusions_leave_the_cifar10_step_unchanged():
     x = (0.5 * torch.randn(8, 3, 32, 32, generator=g)).to(DEV)
     sigma = torch.randn(8, generator=g).exp().to(DEV)
     res = {}
-    old = (N.FUSE_RESAMPLE, N.FUSE_CAT, N.SG_MULTI, N.SG_BWD_MULTI)
+    old = (N.FUSE_RESAMPLE, N.FUSE_CAT, N.SG_MULTI, N.SG_BWD_MULTI, N.SG_HALVES)
     # (third flag, SG_MULTI: every decoder gate of a pass from one launch behind the encoder; fourth, SG_BWD_MULTI: their
     # backward deferred to the last of them, placeholders for the skip gradients -- same kernel bodies, same values)
-    modes = [(False, True, False, False), (True, True, True, True), (True, False, True, True), (True, True, False, False),
-             (True, True, True, False)]
+    # (fifth, SG_HALVES: that launch also writes the gated-skip halves of the decoder's cat / mp_silu(cat) buffers)
+    modes = [(False, True, False, False, False), (True, True, True, True, True), (True, False, True, True, True),
+             (True, True, False, False, False), (True, True, True, False, True), (True, True, True, True, False)]
     try:
         for mode in modes:
-            N.FUSE_RESAMPLE, N.FUSE_CAT, N.SG_MULTI, N.SG_BWD_MULTI = mode
+            N.FUSE_RESAMPLE, N.FUSE_CAT, N.SG_MULTI, N.SG_BWD_MULTI, N.SG_HALVES = mode
             N._rng_sub_counter[0] = 0           # the same dropout sub-streams for both models
             model, den = _cifar_model(T, seed=4)
             opt = FusedAdam(model.parameters(), lr=1e-3)
@@ -402,7 +403,7 @@ def test_resample_fusions_leave_the_cifar10_step_unchanged():
             torch.cuda.synchronize()
             res[mode] = (D, float(loss), opt.arena.grad.clone())
     finally:
-        N.FUSE_RESAMPLE, N.FUSE_CAT, N.SG_MULTI, N.SG_BWD_MULTI = old
+        N.FUSE_RESAMPLE, N.FUSE_CAT, N.SG_MULTI, N.SG_BWD_MULTI, N.SG_HALVES = old
     ref = res[modes[0]]
     for mode in modes[1:]:
         assert torch.equal(res[mode][0], ref[0]), mode

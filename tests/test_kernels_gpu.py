@@ -871,6 +871,26 @@ def test_skip_gate_fwd_multi_matches_the_per_tensor_launches(ops):
         assert torch.equal(mean, m0) and torch.equal(gate, g0) and torch.equal(z1, z0)
         ref_mean = skip.float().mean(dim=(1, 2))
         assert rel(mean, ref_mean) <= 1e-5
+    # ... and with the (cat, sil) buffers of the consuming decoder blocks: the right halves == skip_half_fwd, the left halves
+    # (the producer's columns) untouched; an item without buffers rides in the same launch
+    Ci = 64
+    bufs = []
+    for k, (skip, _, _) in enumerate(items):
+        B, H, W, _ = skip.shape
+        cat = torch.full((B, H, W, Ci + C), 3.0, device=DEV, dtype=torch.bfloat16)
+        bufs.append(None if k == 2 else (cat, None if k == 1 else torch.full_like(cat, 5.0)))
+    got2 = ops.skip_gate_fwd_multi([it + (b if b is not None else ()) for it, b in zip(items, bufs)])
+    for (skip, _, _), (mean, gate, z1), (m0, g0, z0), b in zip(items, got2, got, bufs):
+        assert torch.equal(mean, m0) and torch.equal(gate, g0) and torch.equal(z1, z0)
+        if b is None:
+            continue
+        B, H, W, _ = skip.shape
+        cat0 = torch.full((B, H, W, Ci + C), 3.0, device=DEV, dtype=torch.bfloat16)
+        sil0 = torch.full_like(cat0, 5.0) if b[1] is not None else None
+        ops.skip_half_fwd(skip, gate, cat0, sil0)
+        assert torch.equal(b[0], cat0)
+        if sil0 is not None:
+            assert torch.equal(b[1], sil0)
     other = nhwc(q(torch.randn(2, 128, 4, 4, generator=g)))
     with pytest.raises(ValueError):
         ops.skip_gate_fwd_multi([items[0], (other, torch.zeros(8, 129, device=DEV), torch.zeros(128, 8, device=DEV))])

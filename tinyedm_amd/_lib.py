@@ -166,8 +166,8 @@ class SkipGateWgradItem(ctypes.Structure):
 
 class SkipGateFwdItem(ctypes.Structure):
     """edm_skip_gate_fwd_item (include/tinyedm_hip.h): one ScaleLong gate of a grouped forward launch."""
-    _fields_ = [("skip", P), ("W1h", P), ("W2h", P), ("mean", P), ("gate", P), ("z1save", P), ("B", I), ("HW", I), ("C", I),
-                ("R", I)]
+    _fields_ = [("skip", P), ("W1h", P), ("W2h", P), ("mean", P), ("gate", P), ("z1save", P), ("cat", P), ("silu_out", P),
+                ("B", I), ("HW", I), ("C", I), ("R", I), ("Ci", I), ("pad", I)]
 
 
 class SkipGateBwdItem(ctypes.Structure):

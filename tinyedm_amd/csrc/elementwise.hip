@@ -802,6 +802,7 @@ __device__ __forceinline__ void sample_reduce(const bf16* __restrict__ x, long x
 }
 
 // forward: mean[b,:] = mean_hw skip[b];  gate = sigmoid(W2 mp_silu(W1 [mean;1]))   (networks.py:112-118)
+template <bool KEEP = false>
 __device__ __forceinline__ void skip_gate_fwd_body(const bf16* __restrict__ skip, const float* __restrict__ W1,
                                                    const float* __restrict__ W2, float* __restrict__ mean,
                                                    float* __restrict__ gate, float* __restrict__ z1save, int HW,
@@ -826,7 +827,11 @@ __device__ __forceinline__ void skip_gate_fwd_body(const bf16* __restrict__ skip
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) gate[(long)b * C + c] = sigmoidf_(strided_dot(W2 + (long)c * R, 1, h, R));
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float gv = sigmoidf_(strided_dot(W2 + (long)c * R, 1, h, R));
+    gate[(long)b * C + c] = gv;
+    if (KEEP) red[c] = gv;      // (the reduction scratch is free again: the caller's second pass reads the gate from LDS)
+  }
 }
 __global__ __launch_bounds__(1024) void k_skip_gate_fwd(const bf16* __restrict__ skip, const float* __restrict__ W1,
                                                           const float* __restrict__ W2, float* __restrict__ mean,
@@ -847,6 +852,9 @@ struct SgfItem {
   float* mean;
   float* gate;
   float* z1;
+  bf16* cat;     // optional: the (cat, mp_silu(cat)) buffers of the decoder block that concatenates this skip, rows of Ci + C
+  bf16* sil;     // elements -- the workgroup then also writes the sample's gated skip into their right halves (k_skip_half_fwd's
+  int Ci, pad;   // work) while the sample is still in the cache it was just reduced from
   int B, HW, R, blk0;
 };
 struct SgfGroup {
@@ -858,7 +866,31 @@ __global__ __launch_bounds__(1024) void k_skip_gate_fwd_multi(const SgfGroup* __
   const int n = g->n;
   while (k + 1 < n && (int)blockIdx.x >= g->it[k + 1].blk0) ++k;
   const SgfItem it = g->it[k];
-  skip_gate_fwd_body(it.skip, it.W1, it.W2, it.mean, it.gate, it.z1, it.HW, g->C, it.R, (int)blockIdx.x - it.blk0);
+  const int C = g->C, b = (int)blockIdx.x - it.blk0;
+  skip_gate_fwd_body<true>(it.skip, it.W1, it.W2, it.mean, it.gate, it.z1, it.HW, C, it.R, b);
+  if (it.cat == nullptr) return;      // (workgroup-uniform)
+  __syncthreads();
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // sm[0 .. C): this sample's gate (skip_gate_fwd_body<true>)
+  const int CLs = C >> 3;
+  const long ld = it.Ci + C;
+  const bf16* __restrict__ sk = it.skip + (long)b * it.HW * C;
+  bf16* __restrict__ cat = it.cat + (long)b * it.HW * ld + it.Ci;
+  bf16* __restrict__ sil = it.sil ? it.sil + (long)b * it.HW * ld + it.Ci : nullptr;
+  const int n8 = it.HW * CLs;
+  for (int i = threadIdx.x; i < n8; i += blockDim.x) {     // (as k_skip_half_fwd: same arithmetic, same roundings)
+    const int cs = (i % CLs) * 8;
+    const int pix = i / CLs;
+    float v[8];
+    load8(sk + (long)pix * C + cs, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)(bf16)(v[j] * sm[cs + j]);
+    store8(cat + (long)pix * ld + cs, v);
+    if (sil) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = mp_silu_b(v[j]);
+      store8(sil + (long)pix * ld + cs, v);
+    }
+  }
 }
 // backward: ggate[b,c] = sum_hw gcat[b,hw,Ci+c] * skip[b,hw,c], then the MLP backward of k_scalelong_bwd per sample.
 // The weight gradients are sums over the batch of per-sample outer products; adding them with atomics from every
@@ -1039,7 +1071,9 @@ struct edm_skip_gate_fwd_item_ {   // = edm_skip_gate_fwd_item (include/tinyedm_
   float* mean;
   float* gate;
   float* z1save;
-  int B, HW, C, R;
+  void* cat;
+  void* silu_out;
+  int B, HW, C, R, Ci, pad;
 };
 extern "C" long edm_skip_gate_fwd_multi_table_bytes(void) { return (long)sizeof(SgfGroup); }
 // edm_skip_gate_fwd for up to 32 skip tensors of ONE channel count in one launch; `items` is host memory read during the
@@ -1063,12 +1097,16 @@ extern "C" int edm_skip_gate_fwd_multi(const void* items_, int n, void* table_ho
     EDM_REQUIRE(a.skip && a.W1h && a.W2h && a.mean && a.gate && a.z1save, "skip_gate_fwd_multi: null pointer (gate %d)", k);
     EDM_REQUIRE(a.C == C, "skip_gate_fwd_multi: the gates of one launch share a channel count (%d vs %d)", a.C, C);
     EDM_REQUIRE(a.B > 0 && a.HW > 0 && a.R > 0 && a.R <= 1024, "skip_gate_fwd_multi: bad item %d", k);
-    g.it[k] = SgfItem{(const bf16*)a.skip, a.W1h, a.W2h, a.mean, a.gate, a.z1save, a.B, a.HW, a.R, (int)blk};
+    EDM_REQUIRE(a.cat ? (a.Ci > 0 && a.Ci % 8 == 0) : (a.silu_out == nullptr),
+                "skip_gate_fwd_multi: cat needs Ci %% 8 == 0 (gate %d); silu_out needs cat", k);
+    g.it[k] = SgfItem{(const bf16*)a.skip, a.W1h, a.W2h, a.mean, a.gate, a.z1save, (bf16*)a.cat, (bf16*)a.silu_out, a.Ci, 0,
+                      a.B, a.HW, a.R, (int)blk};
     blk += a.B;
     EDM_REQUIRE(blk < (1L << 30), "skip_gate_fwd_multi: grid too large");
     if (a.R > rmax) rmax = a.R;
   }
-  for (int k = n; k < MAXSGF; ++k) g.it[k] = SgfItem{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, (int)blk};
+  for (int k = n; k < MAXSGF; ++k)
+    g.it[k] = SgfItem{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, (int)blk};
   const size_t lds = ((size_t)(threads / (C / 8)) * C + C + 1 + rmax) * sizeof(float);
   EDM_UPLOAD_TABLE(table_dev, table_host, &g, sizeof(SgfGroup), st, "skip_gate_fwd_multi", defer_upload);
   hipLaunchKernelGGL(k_skip_gate_fwd_multi, dim3((unsigned)blk), dim3(threads), lds, st, (const SgfGroup*)table_dev);

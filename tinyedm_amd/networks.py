@@ -167,6 +167,7 @@ _bwd_end_queued = set()     # devices whose end-of-backward callback is queued f
 # the gates of a backward pass in ONE launch behind it (round 6: nine launches less on the backward's chain); their finish
 # rides in the last multi-tensor finish.  Arena mode only; EDM_SG_DEFER=0: per gate, as round 5.
 SG_MULTI = os.environ.get("EDM_SG_MULTI", "1") != "0"     # every decoder gate of a forward pass in one launch (round 6)
+SG_HALVES = os.environ.get("EDM_SG_HALVES", "1") != "0"       # ... which also writes the gated-skip halves of cat / mp_silu(cat)
 SG_BWD_MULTI = os.environ.get("EDM_SG_BWD_MULTI", "1") != "0"   # ... and their backward, deferred to the last of them
 SG_DEFER = os.environ.get("EDM_SG_DEFER", "1") != "0"
 _sg_pending = {}            # device index -> [(ScaleLong module, ws, mean, R)]
@@ -931,14 +932,15 @@ class _ResBlockFn(torch.autograd.Function):
             sl = blk.cat_factor
             ctx.sgb = None
             if gate_pre is not None:    # (SG_MULTI: the Denoiser computed every decoder gate in one launch behind the encoder)
-                mean, gate, z1, w1h, w2h, ctx.sgb = gate_pre
+                mean, gate, z1, w1h, w2h, ctx.sgb, halves = gate_pre
             else:
                 w1h, w2h = sl.layer1.packs()[2], sl.layer2.packs()[2]
                 mean, gate, z1 = ops.skip_gate_fwd(skip, w1h, w2h)      # mean over H*W + gate MLP: one launch
             ctx.Ci = u.shape[-1]
             if pre is not None and pre[0].shape[-1] == u.shape[-1] + skip.shape[-1] and pre[0].data_ptr() == u.data_ptr():
                 cat, s_pre = pre
-                ops.skip_half_fwd(skip, gate, cat, s_pre)
+                if not (gate_pre is not None and halves == cat.data_ptr()):    # (else: the gate launch wrote them already)
+                    ops.skip_half_fwd(skip, gate, cat, s_pre)
             else:
                 cat, s_pre = ops.concat_gate_fwd(u.contiguous(), skip, gate, True)
             u = cat
@@ -1663,8 +1665,8 @@ class Denoiser(nn.Module):
         return cached[1]
 
     @staticmethod
-    def _decoder_gates(dec, skips):
-        return _decoder_gates_impl(dec, skips)
+    def _decoder_gates(dec, skips, dests=None):
+        return _decoder_gates_impl(dec, skips, dests)
 
     @staticmethod
     def _silu_dest(block, nxt, x, up, down=False):
@@ -1891,20 +1893,15 @@ class Denoiser(nn.Module):
             x, x_in = block(_tag(x), None, _lin=lins[block], _alias=True, _dest=dest)
             skips.append(x_in)
         skips.append(x)
-        gates = self._decoder_gates(dec, skips) if SG_MULTI else {}
+        # the next block concatenates a block's output with a skip: that block's last kernel writes its output and mp_silu
+        # of it into the left halves of those operands (no concat copy); the buffers exist before the decoder runs
+        dests = _decoder_dests_impl(dec, skips, x) if FUSE_CAT and SKIP_GATE_FUSED else {}
+        gates = self._decoder_gates(dec, skips, dests) if SG_MULTI else {}
         for i, (block, has_skip) in enumerate(dec):
             skip = skips.pop() if has_skip else None
-            dest = None
-            if FUSE_CAT and SKIP_GATE_FUSED and i + 1 < len(dec) and dec[i + 1][1]:
-                nxt = dec[i + 1][0]
-                if not isinstance(nxt.resample, UpSample) and isinstance(nxt.conv_1x1, Conv2d):
-                    # the next block concatenates this block's output with skips[-1]: this block's last kernel writes its
-                    # output and mp_silu of it into the left halves of those operands (no concat copy)
-                    up = 2 if isinstance(block.resample, UpSample) else 1
-                    Bx, Hx, Wx, _ = x.shape
-                    Ct = block.conv_3x3_2.weight.shape[0] + skips[-1].shape[-1]
-                    dest = (torch.empty(Bx, Hx * up, Wx * up, Ct, device=x.device, dtype=bf16),
-                            torch.empty(Bx, Hx * up, Wx * up, Ct, device=x.device, dtype=bf16))
+            dest = dests.get(i)
+            if dest is not None:
+                pass
             elif i + 1 < len(dec):
                 dest = self._silu_dest(block, dec[i + 1][0], x, 2 if isinstance(block.resample, UpSample) else 1)
             xin = _tag(x)
@@ -1947,28 +1944,54 @@ class _SgbPass:
             ops.skip_half_bwd_multi(halves[k0:k0 + 32])
 
 
-def _decoder_gates_impl(dec, skips):
-    """{decoder block: (mean, gate, z1, w1h, w2h)} for every block whose ScaleLong gate lives in its autograd node: the gates
-    depend on the skip tensors and two small weights only, so all of them are computed HERE, behind the encoder, by one
-    launch per channel count (ops.skip_gate_fwd_multi) instead of one half-empty launch per decoder block."""
+def _decoder_dests_impl(dec, skips, x):
+    """{decoder index i: (cat, sil) buffers of block i + 1} where block i + 1 concatenates a U-Net skip in its autograd node
+    (FUSE_CAT): block i's last kernel writes its output and mp_silu of it into their LEFT halves (no concat copy).  Allocated
+    before the decoder runs (round 6) so that the gate launch behind the encoder can fill the RIGHT halves too."""
+    out = {}
+    st = list(skips)
+    h, w = x.shape[1], x.shape[2]
+    for i, (block, has_skip) in enumerate(dec):
+        if has_skip:
+            st.pop()
+        if isinstance(block.resample, UpSample):
+            h, w = 2 * h, 2 * w
+        if i + 1 < len(dec) and dec[i + 1][1]:
+            nxt = dec[i + 1][0]
+            if not isinstance(nxt.resample, UpSample) and isinstance(nxt.conv_1x1, Conv2d):
+                Ct = block.conv_3x3_2.weight.shape[0] + st[-1].shape[-1]
+                out[i] = (torch.empty(x.shape[0], h, w, Ct, device=x.device, dtype=bf16),
+                          torch.empty(x.shape[0], h, w, Ct, device=x.device, dtype=bf16))
+    return out
+
+
+def _decoder_gates_impl(dec, skips, dests=None):
+    """{decoder block: (mean, gate, z1, w1h, w2h, backward token, halves written)} for every block whose ScaleLong gate lives
+    in its autograd node: the gates depend on the skip tensors and two small weights only, so all of them are computed HERE,
+    behind the encoder, by one launch per channel count (ops.skip_gate_fwd_multi) instead of one half-empty launch per
+    decoder block -- and the workgroup that reduced a sample also writes its gated skip (and mp_silu of it) into the right
+    halves of the block's (cat, sil) buffers (`dests[i - 1]`), the work of the block's k_skip_half_fwd launch."""
     st = list(skips)
     todo = {}
-    for block, has_skip in dec:
+    for i, (block, has_skip) in enumerate(dec):
         if not has_skip:
             continue
         skip = st.pop()
         if not (isinstance(block, DecoderBlock) and block._gate_in_block() and skip.dim() == 4 and skip.dtype == bf16):
             continue
         sl = block.cat_factor
-        todo.setdefault(skip.shape[-1], []).append((block, skip, sl.layer1.packs()[2], sl.layer2.packs()[2]))
+        pre = dests.get(i - 1) if dests and SG_HALVES else None
+        if pre is not None and not (pre[0].shape[:3] == skip.shape[:3] and pre[0].shape[-1] > skip.shape[-1]):
+            pre = None
+        todo.setdefault(skip.shape[-1], []).append((block, skip, sl.layer1.packs()[2], sl.layer2.packs()[2], pre))
     out = {}
     tok = _SgbPass(sum(len(v) for v in todo.values())) if torch.is_grad_enabled() else None
     for items in todo.values():
         for k0 in range(0, len(items), 32):
             part = items[k0:k0 + 32]
-            res = ops.skip_gate_fwd_multi([(skip, w1h, w2h) for _, skip, w1h, w2h in part])
-            for (block, _, w1h, w2h), (mean, gate, z1) in zip(part, res):
-                out[block] = (mean, gate, z1, w1h, w2h, tok)
+            res = ops.skip_gate_fwd_multi([(skip, w1h, w2h) + (pre if pre is not None else ()) for _, skip, w1h, w2h, pre in part])
+            for (block, _, w1h, w2h, pre), (mean, gate, z1) in zip(part, res):
+                out[block] = (mean, gate, z1, w1h, w2h, tok, None if pre is None else pre[0].data_ptr())
     return out
 
 

@@ -537,15 +537,29 @@ def skip_gate_fwd(skip, w1h, w2h):
 
 def skip_gate_fwd_multi(items):
     """skip_gate_fwd for several skip tensors of ONE channel count in one launch: items = sequence (<= 32) of
-    (skip, w1h, w2h) -> list of (mean, gate, z1), the values of the per-tensor call."""
+    (skip, w1h, w2h) or (skip, w1h, w2h, cat, sil) -> list of (mean, gate, z1), the values of the per-tensor call.
+    cat / sil: (B, H, W, Ci + C) contiguous bf16 buffers whose right C columns receive skip * gate and mp_silu of it
+    (== skip_half_fwd(skip, gate, cat, sil), by the workgroup that just reduced the sample)."""
     n = len(items)
     if not 0 < n <= 32:
         raise ValueError("skip_gate_fwd_multi: 1..32 gates per launch")
     arr = (_lib.SkipGateFwdItem * n)()
     out = []
     C0 = items[0][0].shape[-1]
-    for k, (skip, w1h, w2h) in enumerate(items):
+    for k, item in enumerate(items):
+        skip, w1h, w2h = item[:3]
+        cat, sil = item[3:5] if len(item) > 3 else (None, None)
         B, H, W, C = _nhwc(skip, "skip")
+        Ci = 0
+        if cat is not None:
+            Ci = cat.shape[-1] - C
+            _chk(cat, bf16, "cat", (B, H, W, Ci + C))
+            if sil is not None:
+                _chk(sil, bf16, "sil", (B, H, W, Ci + C))
+            if Ci <= 0 or Ci % 8:
+                raise ValueError("skip_gate_fwd_multi: cat must have Ci + C channels with Ci a positive multiple of 8")
+        elif sil is not None:
+            raise ValueError("skip_gate_fwd_multi: sil needs cat")
         if C != C0:
             raise ValueError("skip_gate_fwd_multi: the gates of one launch share a channel count")
         R = w1h.shape[0]
@@ -555,7 +569,7 @@ def skip_gate_fwd_multi(items):
         gate = torch.empty(B, C, device=skip.device, dtype=f32)
         z1 = torch.empty(B, R, device=skip.device, dtype=f32)
         arr[k] = _lib.SkipGateFwdItem(skip.data_ptr(), w1h.data_ptr(), w2h.data_ptr(), mean.data_ptr(), gate.data_ptr(),
-                                      z1.data_ptr(), B, H * W, C, R)
+                                      z1.data_ptr(), _p(cat), _p(sil), B, H * W, C, R, Ci, 0)
         out.append((mean, gate, z1))
     th, td, defer, release = _tables.take(items[0][0].device)
     _lib.call("edm_skip_gate_fwd_multi", ctypes.byref(arr), n, ctypes.c_void_p(th), ctypes.c_void_p(td), defer, _stream())
