@@ -315,6 +315,7 @@ typedef struct {
   const float* z1save;
   float* gmean;         /* [B][C]       written */
   float* ws;            /* [B][C + 2R]  written */
+  void* gskip;          /* optional: bf16 [B*HW][C] written = gcat[:, c_off:c_off+C] * gate + gmean / HW (edm_skip_half_bwd's work) */
   int c_off, B, HW, C, R, pad;
 } edm_skip_gate_bwd_item;
 typedef struct {

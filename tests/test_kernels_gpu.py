@@ -918,3 +918,9 @@ def test_skip_gate_backward_multi_matches_the_per_tensor_launches(ops):
     for (gmean, ws), h, (gmean0, ws0, gskip0) in zip(got, holders, ref):
         assert torch.equal(gmean, gmean0) and torch.equal(ws, ws0)
         assert torch.equal(h, gskip0)
+    # ... and the one-launch form: the gate's workgroup writes the skip gradient of its sample itself
+    holders2 = [torch.full_like(gt[0], float("nan")) for gt in gates]
+    got2 = ops.skip_gate_bwd_multi([gt + (h,) for gt, h in zip(gates, holders2)])
+    for (gmean, ws), h, (gmean0, ws0, gskip0) in zip(got2, holders2, ref):
+        assert torch.equal(gmean, gmean0) and torch.equal(ws, ws0)
+        assert torch.equal(h, gskip0)

@@ -173,7 +173,7 @@ class SkipGateFwdItem(ctypes.Structure):
 class SkipGateBwdItem(ctypes.Structure):
     """edm_skip_gate_bwd_item (include/tinyedm_hip.h)"""
     _fields_ = [("gcat", P), ("gcat_stride", L), ("skip", P), ("W1h", P), ("W2h", P), ("gate", P), ("z1save", P), ("gmean", P),
-                ("ws", P), ("c_off", I), ("B", I), ("HW", I), ("C", I), ("R", I), ("pad", I)]
+                ("ws", P), ("gskip", P), ("c_off", I), ("B", I), ("HW", I), ("C", I), ("R", I), ("pad", I)]
 
 
 class SkipHalfBwdItem(ctypes.Structure):

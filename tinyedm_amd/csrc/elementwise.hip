@@ -950,6 +950,8 @@ struct SgbItem {
   const float* z1;
   float* gmean;
   float* ws;
+  bf16* gskip;   // optional: the gradient of the U-Net skip, gcat * gate + gmean / HW (edm_skip_half_bwd's work), written by
+                 // the workgroup that just reduced the sample (its gcat rows are still in the caches)
   int B, HW, R, blk0;
 };
 struct SgbGroup {
@@ -961,8 +963,28 @@ __global__ __launch_bounds__(1024) void k_skip_gate_bwd_multi(const SgbGroup* __
   const int n = g->n;
   while (k + 1 < n && (int)blockIdx.x >= g->it[k + 1].blk0) ++k;
   const SgbItem it = g->it[k];
-  skip_gate_bwd_body(it.gcat, it.gs, it.skip, it.W1, it.W2, it.gate, it.z1, it.gmean, it.ws, it.HW, g->C, it.R,
-                     (int)blockIdx.x - it.blk0);
+  const int C = g->C, b = (int)blockIdx.x - it.blk0;
+  skip_gate_bwd_body(it.gcat, it.gs, it.skip, it.W1, it.W2, it.gate, it.z1, it.gmean, it.ws, it.HW, C, it.R, b);
+  if (it.gskip == nullptr) return;    // (workgroup-uniform)
+  __syncthreads();                    // this sample's gmean row (global, written above by this workgroup) is complete
+  const int CLs = C >> 3;
+  const float inv_hw = 1.0f / (float)it.HW;
+  const bf16* __restrict__ gc = it.gcat + (long)b * it.HW * it.gs;
+  bf16* __restrict__ out = it.gskip + (long)b * it.HW * C;
+  const float* gp0 = it.gate + (long)b * C;
+  const float* mp0 = it.gmean + (long)b * C;
+  const int n8 = it.HW * CLs;
+  for (int i = threadIdx.x; i < n8; i += blockDim.x) {     // (as skip_half_bwd_body: same expression, same rounding)
+    const int cs = (i % CLs) * 8;
+    const int pix = i / CLs;
+    float v[8];
+    load8(gc + (long)pix * it.gs + cs, v);
+    const float* gp = gp0 + cs;
+    const float* mp = mp0 + cs;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = v[j] * gp[j] + mp[j] * inv_hw;
+    store8(out + (long)pix * C + cs, v);
+  }
 }
 // gW2[c][r] = sum_b dz2[b][c] h[b][r];  gW1[r][c'] = sum_b dz1[b][r] [mean[b]; 1][c']   (b ascending: reproducible).
 // A workgroup owns four columns of the C (resp. C+1) dimension and all R rows: it stages A[b][4] and Bm[b][R] in LDS with
@@ -1147,6 +1169,7 @@ struct edm_skip_gate_bwd_item_ {   // = edm_skip_gate_bwd_item (include/tinyedm_
   const float* z1save;
   float* gmean;
   float* ws;
+  void* gskip;
   int c_off, B, HW, C, R, pad;
 };
 // the first launch of edm_skip_gate_bwd (gW1h == gW2h == NULL form: gmean and ws written) for up to 32 gates of ONE channel
@@ -1173,13 +1196,13 @@ extern "C" int edm_skip_gate_bwd_multi(const void* items_, int n, void* table_ho
     EDM_REQUIRE(a.B > 0 && a.HW > 0 && a.R > 0 && a.R <= 1024 && a.c_off >= 0 && a.c_off % 8 == 0 &&
                     a.gcat_stride >= a.c_off + C && a.gcat_stride % 8 == 0, "skip_gate_bwd_multi: bad item %d", k);
     g.it[k] = SgbItem{(const bf16*)a.gcat + a.c_off, a.gcat_stride, (const bf16*)a.skip, a.W1h, a.W2h, a.gate, a.z1save,
-                      a.gmean, a.ws, a.B, a.HW, a.R, (int)blk};
+                      a.gmean, a.ws, (bf16*)a.gskip, a.B, a.HW, a.R, (int)blk};
     blk += a.B;
     EDM_REQUIRE(blk < (1L << 30), "skip_gate_bwd_multi: grid too large");
     if (a.R > rmax) rmax = a.R;
   }
   for (int k = n; k < MAXSGF; ++k)
-    g.it[k] = SgbItem{nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, (int)blk};
+    g.it[k] = SgbItem{nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, (int)blk};
   const size_t lds = ((size_t)(threads / (C / 8)) * C + C + rmax) * sizeof(float);
   EDM_UPLOAD_TABLE(table_dev, table_host, &g, sizeof(SgbGroup), st, "skip_gate_bwd_multi", defer_upload);
   hipLaunchKernelGGL(k_skip_gate_bwd_multi, dim3((unsigned)blk), dim3(threads), lds, st, (const SgbGroup*)table_dev);

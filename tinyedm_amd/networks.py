@@ -1936,9 +1936,11 @@ class _SgbPass:
         for group in by_c.values():
             for k0 in range(0, len(group), 32):
                 part = group[k0:k0 + 32]
-                res = ops.skip_gate_bwd_multi([(gcs, 0, skip, w1h, w2h, gate, z1) for gcs, skip, w1h, w2h, gate, z1, _, _, _ in part])
+                res = ops.skip_gate_bwd_multi([(gcs, 0, skip, w1h, w2h, gate, z1) + ((gskip,) if SG_HALVES else ())
+                                               for gcs, skip, w1h, w2h, gate, z1, gskip, _, _ in part])
                 for (gcs, skip, w1h, w2h, gate, z1, gskip, sl, mean), (gmean, ws) in zip(part, res):
-                    halves.append((gcs, gate, gmean, gskip))
+                    if not SG_HALVES:
+                        halves.append((gcs, gate, gmean, gskip))
                     _sg_pending.setdefault(sl.layer1.weight.device.index, []).append((sl, ws, mean, w1h.shape[0]))
         for k0 in range(0, len(halves), 32):
             ops.skip_half_bwd_multi(halves[k0:k0 + 32])

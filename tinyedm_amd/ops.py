@@ -579,14 +579,18 @@ def skip_gate_fwd_multi(items):
 
 def skip_gate_bwd_multi(items):
     """the per-sample pass of skip_gate_bwd(defer_wgrad=True) for several gates of ONE channel count in one launch:
-    items = sequence (<= 32) of (gcat, Ci, skip, w1h, w2h, gate, z1) -> list of (gmean (B, C), ws (B, C + 2R))."""
+    items = sequence (<= 32) of (gcat, Ci, skip, w1h, w2h, gate, z1[, gskip]) -> list of (gmean (B, C), ws (B, C + 2R)).
+    gskip: an uninitialised (B, H, W, C) bf16 tensor that receives gcat[..., Ci:] * gate + gmean / HW (== skip_half_bwd), written
+    by the workgroup that just reduced the sample."""
     n = len(items)
     if not 0 < n <= 32:
         raise ValueError("skip_gate_bwd_multi: 1..32 gates per launch")
     arr = (_lib.SkipGateBwdItem * n)()
     out = []
     C0 = items[0][2].shape[-1]
-    for k, (gcat, Ci, skip, w1h, w2h, gate, z1) in enumerate(items):
+    for k, item in enumerate(items):
+        gcat, Ci, skip, w1h, w2h, gate, z1 = item[:7]
+        gskip = item[7] if len(item) > 7 else None
         B, H, W, Ct = _nhwc(gcat, "gcat")
         Bs, Hs, Ws, C = _nhwc(skip, "skip")
         if (Bs, Hs, Ws) != (B, H, W) or Ct != Ci + C or C != C0:
@@ -598,8 +602,10 @@ def skip_gate_bwd_multi(items):
         _chk(z1, f32, "z1", (B, R))
         gmean = torch.empty(B, C, device=skip.device, dtype=f32)
         ws = torch.empty(B, C + 2 * R, device=skip.device, dtype=f32)
+        if gskip is not None:
+            _chk(gskip, bf16, "gskip", (B, H, W, C))
         arr[k] = _lib.SkipGateBwdItem(gcat.data_ptr(), Ct, skip.data_ptr(), w1h.data_ptr(), w2h.data_ptr(), gate.data_ptr(),
-                                      z1.data_ptr(), gmean.data_ptr(), ws.data_ptr(), Ci, B, H * W, C, R, 0)
+                                      z1.data_ptr(), gmean.data_ptr(), ws.data_ptr(), _p(gskip), Ci, B, H * W, C, R, 0)
         out.append((gmean, ws))
     th, td, defer, release = _tables.take(items[0][2].device)
     _lib.call("edm_skip_gate_bwd_multi", ctypes.byref(arr), n, ctypes.c_void_p(th), ctypes.c_void_p(td), defer, _stream())
