@@ -76,8 +76,18 @@ GROUP_WIDE = [
 ]
 
 
+# channel counts of the default (ImageNet) Denoiser: 3 x 6, 5 x 9, 5 x 12 and 3 x 3 tiles -- the team shapes 1 x 8 and 2 x 4 the
+# round-6 plan picks where they leave fewer members idle than the power-of-two rule (conv_wgrad3.hip make_plan)
+GROUP_TEAMS = [
+    dict(B=2, H=8, W=8, Cin=384, Cout=384),
+    dict(B=1, H=8, W=8, Cin=576, Cout=576, scale=0.7),
+    dict(B=2, H=4, W=4, Cin=768, Cout=576, perm=True),
+    dict(B=1, H=8, W=8, Cin=192, Cout=384, accumulate=True),
+]
+
+
 @pytest.mark.parametrize("name,group", [("small", GROUP_SMALL), ("wide", GROUP_WIDE), ("single", GROUP_SMALL[1:2]),
-                                        ("sixteen", (GROUP_SMALL * 2)[:16])])
+                                        ("sixteen", (GROUP_SMALL * 2)[:16]), ("teams", GROUP_TEAMS)])
 def test_wgrad3_group_matches_oracle(ops, name, group):
     g = torch.Generator().manual_seed(len(group) * 31 + 5)
     items, refs = zip(*[_layer(g, **kw) for kw in group])

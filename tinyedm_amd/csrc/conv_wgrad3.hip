@@ -608,6 +608,20 @@ int make_plan(const edm_wgrad3_item* it, int n, Plan& P) {
     L.tiles_ci = (a.Cin + TCI - 1) / TCI;
     L.tiles_co = (a.Cout + TCO - 1) / TCO;
     L.gco = L.tiles_co >= 8 ? 8 : L.tiles_co >= 4 ? 4 : L.tiles_co >= 2 ? 2 : 1;   // members along co: each X slice is shared by gco
+    {
+      // ... unless another shape of the team of eight leaves fewer members without a tile (round 6): 3 x 6 tiles (384
+      // channels) fill 18 of 32 slots as 2 x 4 teams and 18 of 24 as 1 x 8; 5 x 9 (576 channels) 45 of 80 as 4 x 2 and 45 of 72
+      // as 2 x 4.  The rule above stays the tie-break (256 channels: 2 x 4 tiles, full either way -- plans unchanged).
+      auto slots = [&](int gco) {
+        const int gci = 8 / gco;
+        return ((L.tiles_co + gco - 1) / gco) * ((L.tiles_ci + gci - 1) / gci);
+      };
+      static const bool search = [] { const char* e = getenv("EDM_W3_TEAMS"); return !(e && e[0] == '0'); }();   // tools only (A/B)
+      int best = L.gco;
+      for (int gco = 1; search && gco <= 8; gco *= 2)
+        if (slots(gco) < slots(best)) best = gco;
+      L.gco = best;
+    }
     L.gci = 8 / L.gco;                                                             // ... and each dY slice by gci members
     L.nblk_ci = (L.tiles_ci + L.gci - 1) / L.gci;
     L.ngroups = ((L.tiles_co + L.gco - 1) / L.gco) * L.nblk_ci;
