@@ -19,6 +19,10 @@ int edm_conv_igemm_v2_ablate(const void* X, const void* Wp, void* Y, int B, int 
  * k_wgrad3 launch ONLY -- not around the launch-table upload before it and k_wgrad3_finish behind it.  One-shot. */
 int edm_wgrad3_probe(void* ev_start, void* ev_end);
 
+/* diagnostics : K shares per tile that edm_wgrad3_group's plan gives each of the n layers of `items` (host memory, as for
+ * edm_wgrad3_group; 1 = the layer's K range is not split) -- lets the parity test assert that the split form really ran. */
+int edm_wgrad3_plan_ksplit(const edm_wgrad3_item* items, int n, int* ksplit_out);
+
 /* measurement : launches of k_conv3x3_v6's persistent form (EDM_V6_PERSIST=1) by this process so far -- lets the parity test
  * assert that the form it compares really ran. */
 long edm_v6_persistent_launches(void);

@@ -86,7 +86,31 @@ GROUP_TEAMS = [
 ]
 
 
-@pytest.mark.parametrize("name,group", [("small", GROUP_SMALL), ("wide", GROUP_WIDE), ("single", GROUP_SMALL[1:2]),
+# layers whose tiles do not fill a team of eight: the plan splits their K range into shares (virtual tiles, conv_wgrad3.hip):
+# 1 x 2 tiles (MNIST's 128 channels), 2 x 3 (192), 1 x 1, 3 x 6 with a perm, a share whose last stages lie past the end of K
+# (stage counts that are no multiple of the share count), beside a 256-channel layer that must not split
+GROUP_KSPLIT = [
+    dict(B=9, H=28, W=28, Cin=128, Cout=128, scale=0.7),
+    dict(B=16, H=32, W=32, Cin=192, Cout=192, accumulate=True),
+    dict(B=40, H=14, W=14, Cin=64, Cout=64),
+    dict(B=4, H=16, W=16, Cin=256, Cout=256),
+    dict(B=48, H=16, W=16, Cin=384, Cout=384, perm=True),
+    dict(B=11, H=28, W=28, Cin=32, Cout=128, I=1),
+]
+GROUP_KSPLIT_WIDE = [
+    dict(B=3, H=64, W=64, Cin=192, Cout=192),
+    dict(B=2, H=64, W=64, Cin=64, Cout=128, perm=True, accumulate=True),
+]
+
+
+def test_wgrad3_ksplit_groups_really_split(ops):
+    for group in (GROUP_KSPLIT, GROUP_KSPLIT_WIDE):
+        ks = ops.wgrad3_plan_ksplit([(kw["B"], kw["H"], kw["W"], kw["Cin"], kw["Cout"]) for kw in group])
+        assert sum(k > 1 for k in ks) >= len(group) - 1, ks
+    assert ops.wgrad3_plan_ksplit([(4, 16, 16, 256, 256)]) == [1]
+
+
+@pytest.mark.parametrize("name,group", [("ksplit", GROUP_KSPLIT), ("ksplit-wide", GROUP_KSPLIT_WIDE), ("small", GROUP_SMALL), ("wide", GROUP_WIDE), ("single", GROUP_SMALL[1:2]),
                                         ("sixteen", (GROUP_SMALL * 2)[:16]), ("teams", GROUP_TEAMS)])
 def test_wgrad3_group_matches_oracle(ops, name, group):
     g = torch.Generator().manual_seed(len(group) * 31 + 5)

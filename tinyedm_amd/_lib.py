@@ -138,6 +138,7 @@ DIAG_SIGNATURES = {
     "edm_conv_igemm_v2_stamp": [P, P, P, I, I, I, I, I, P, P],
     "edm_conv_igemm_v2_ablate": [P, P, P, I, I, I, I, I, I, P],
     "edm_wgrad3_probe": [P, P],
+    "edm_wgrad3_plan_ksplit": [P, I, P],
     "edm_v6_persistent_launches": [],
 }
 _RET = {"edm_last_error": ctypes.c_char_p, "edm_v6_persistent_launches": ctypes.c_long, "edm_wgrad3_workspace": ctypes.c_long, "edm_wgrad3_table_bytes": ctypes.c_long,

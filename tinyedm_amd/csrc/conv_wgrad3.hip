@@ -18,7 +18,13 @@
 //    partial tile only when the team crosses a group boundary or its range ends; a partial's position is static:
 //    slot(member, team, group) = member * (teams + groups) + team + group;
 //  * `k_wgrad3_finish` (one launch per group, one workgroup per weight row) sums a row's partials, applies the
-//    weight-normalisation projection and accumulates into the gradient arena.
+//    weight-normalisation projection and accumulates into the gradient arena;
+//  * layers whose tiles do not fill a team (round 6: 128 channels = 1 x 2 tiles, 192 = 2 x 3, 384 = 3 x 6 ...) split their
+//    K RANGE as well: with `ksplit` = S the layer has T * S VIRTUAL tiles (v = ks * T + tile; group = v / 8, member = v % 8),
+//    a group is ceil(nst / S) stages long and member m walks the stages of its K share ks -- every member of the team has
+//    a tile where 6 of 8 (MNIST's 28x28 layers) or 2 of 8 (192-channel 64x64 layers) sat idle.  Members of one group no
+//    longer all read the same pixel rows (different shares), which these layers' few tiles could not share much anyway;
+//    each share is one more 288-KiB partial tile for the finish pass, which make_plan prices (W3_FLUSH_STAGES).
 #include "common.h"
 #include <stdlib.h>
 
@@ -51,6 +57,7 @@ struct W3Layer {
   int PW, PH, lead_rows, kmult;
   int tiles_ci, tiles_co, nst;
   int gci, gco, nblk_ci, ngroups, group0;   // tile groups of 8 = gco x gci (see the header)
+  int ksplit;                               // > 1: K shares per tile (virtual tiles; nst = stages of ONE share)
   long stage0, kbeg0, kend;
 };
 struct W3Group {
@@ -138,15 +145,25 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3(const W3Group* __restrict__ g
     const int st0 = (int)(rel - (long)grp * g.L[li].nst);
     int nst = g.L[li].nst - st0;
     if ((long)nst > pend - pos) nst = (int)(pend - pos);
-    const int bco = grp / g.L[li].nblk_ci, bci = grp - bco * g.L[li].nblk_ci;
-    const int tco = bco * g.L[li].gco + member / g.L[li].gci, tci = bci * g.L[li].gci + member % g.L[li].gci;
+    int tco, tci, ksh = 0;
+    if (g.L[li].ksplit > 1) {   // virtual tile v = K share * tiles + tile (see the header); all of this is workgroup-uniform
+      const int T = g.L[li].tiles_co * g.L[li].tiles_ci, v = grp * 8 + member;
+      ksh = v / T;
+      const int tl = v - ksh * T;
+      tco = ksh < g.L[li].ksplit ? tl / g.L[li].tiles_ci : g.L[li].tiles_co;
+      tci = tl % g.L[li].tiles_ci;
+    } else {
+      const int bco = grp / g.L[li].nblk_ci, bci = grp - bco * g.L[li].nblk_ci;
+      tco = bco * g.L[li].gco + member / g.L[li].gci;
+      tci = bci * g.L[li].gci + member % g.L[li].gci;
+    }
     if (tco >= g.L[li].tiles_co || tci >= g.L[li].tiles_ci) {   // this member has no tile in the group (workgroup-uniform)
       pos += nst;
       if (pos >= g.L[li].stage0 + (long)g.L[li].ngroups * g.L[li].nst) ++li;
       continue;
     }
     const int co0 = tco * TCO, ci0 = tci * TCI;
-    const long ks0 = g.L[li].kbeg0 + (long)st0 * KP;
+    const long ks0 = g.L[li].kbeg0 + ((long)ksh * g.L[li].nst + st0) * KP;   // (a share's last stages may lie past kend: zeros)
     const long ks1 = (ks0 + (long)nst * KP < g.L[li].kend) ? ks0 + (long)nst * KP : g.L[li].kend;
     float* __restrict__ out = g.work + ((long)member * g.slots_per_member + team + g.L[li].group0 + grp) * TILE_FLOATS;
 
@@ -439,6 +456,7 @@ struct F3Layer {
   const int* perm;
   int O, I, Cin, tiles_ci, nst, row0;
   int gci, gco, nblk_ci, group0;
+  int ksplit, tiles_co;
   float scale;
   int accumulate;
   long stage0;
@@ -491,17 +509,28 @@ __global__ __launch_bounds__(256) void k_wgrad3_finish(const F3Group* __restrict
   for (int idx = threadIdx.x; idx < items; idx += blockDim.x) {
     const int c4 = idx & 15, tt = idx >> 4;
     const int tp = tt % 9, tci = tt / 9;
-    // the tile's group and owner, then the teams whose stage ranges touch the group: one partial each
-    const int gco = g.L[li].gco, gci = g.L[li].gci;
-    const int grp = (tco / gco) * g.L[li].nblk_ci + tci / gci, member = (tco % gco) * gci + tci % gci;
-    const long s0 = g.L[li].stage0 + (long)grp * nst;
-    const int w_lo = (int)(s0 / g.q), w_hi = (int)((s0 + nst - 1) / g.q);
-    const float* p = g.work + ((long)member * g.slots_per_member + w_lo + g.L[li].group0 + grp) * TILE_FLOATS +
-                     ((long)tp * TCO + rl) * TCI + c4 * 4;
-    f32x4 a = *reinterpret_cast<const f32x4*>(p);
-    for (int w = w_lo + 1; w <= w_hi; ++w) {
-      p += TILE_FLOATS;
-      a += *reinterpret_cast<const f32x4*>(p);
+    // the tile's group and owner, then the teams whose stage ranges touch the group: one partial each -- and that for
+    // every K share of the tile when the layer's K range is split (fixed order: share, then team)
+    const int gco = g.L[li].gco, gci = g.L[li].gci, ksplit = g.L[li].ksplit;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int ksh = 0; ksh < ksplit; ++ksh) {
+      int grp, member;
+      if (ksplit > 1) {
+        const int v = ksh * (g.L[li].tiles_co * tiles_ci) + tco * tiles_ci + tci;
+        grp = v >> 3;
+        member = v & 7;
+      } else {
+        grp = (tco / gco) * g.L[li].nblk_ci + tci / gci;
+        member = (tco % gco) * gci + tci % gci;
+      }
+      const long s0 = g.L[li].stage0 + (long)grp * nst;
+      const int w_lo = (int)(s0 / g.q), w_hi = (int)((s0 + nst - 1) / g.q);
+      const float* p = g.work + ((long)member * g.slots_per_member + w_lo + g.L[li].group0 + grp) * TILE_FLOATS +
+                       ((long)tp * TCO + rl) * TCI + c4 * 4;
+      for (int w = w_lo; w <= w_hi; ++w) {
+        a += *reinterpret_cast<const f32x4*>(p);
+        p += TILE_FLOATS;
+      }
     }
     const int i0 = tci * TCI + c4 * 4;
 #pragma unroll
@@ -627,11 +656,33 @@ int make_plan(const edm_wgrad3_item* it, int n, Plan& P) {
     L.ngroups = ((L.tiles_co + L.gco - 1) / L.gco) * L.nblk_ci;
     L.group0 = group;
     L.nst = (int)((L.kend - L.kbeg0 + KP - 1) / KP);
+    L.ksplit = 1;
+    {
+      // K shares (see the header): the team walks ceil(T * S / 8) groups of ceil(nst / S) stages instead of `ngroups` groups of
+      // nst; every group costs each member the flush of a 288-KiB partial tile (and the finish pass its read), priced at
+      // W3_FLUSH_STAGES stages (a stage is ~2 us of a CU, 256 partial tiles at once ~25 us of HBM writes + their read back).
+      // 256-channel layers (2 x 4 or 2 x 8 tiles: no idle member) never split -- the CIFAR-10 plans are unchanged.
+      constexpr int W3_FLUSH_STAGES = 16;
+      static const int smax = [] { const char* e = getenv("EDM_W3_KSPLIT"); return e ? atoi(e) : 8; }();   // 0 / 1: off (tools, A/B)
+      const int T = L.tiles_co * L.tiles_ci;
+      long best = (long)L.ngroups * (L.nst + W3_FLUSH_STAGES);
+      for (int sp = 2; sp <= smax && sp <= 8; ++sp) {
+        const int nst_s = (L.nst + sp - 1) / sp;
+        if (nst_s < W3_FLUSH_STAGES) break;   // a share shorter than its own flush: more partial tiles for nothing
+        const long cost = (long)((T * sp + 7) / 8) * (nst_s + W3_FLUSH_STAGES);
+        if (cost < best) { best = cost; L.ksplit = sp; }
+      }
+      if (L.ksplit > 1) {
+        L.ngroups = (T * L.ksplit + 7) / 8;
+        L.nst = (L.nst + L.ksplit - 1) / L.ksplit;
+      }
+    }
     L.stage0 = stage;
     F3Layer& F = P.fg.L[k];
     F.w = a.w; F.grad = a.grad; F.perm = a.perm;
     F.O = a.Cout; F.I = a.I; F.Cin = a.Cin; F.tiles_ci = L.tiles_ci; F.nst = L.nst; F.row0 = row;
     F.gci = L.gci; F.gco = L.gco; F.nblk_ci = L.nblk_ci; F.group0 = group;
+    F.ksplit = L.ksplit; F.tiles_co = L.tiles_co;
     F.scale = a.scale; F.accumulate = a.accumulate; F.stage0 = stage;
     stage += (long)L.ngroups * L.nst;
     group += L.ngroups;
@@ -663,6 +714,16 @@ extern "C" long edm_wgrad3_workspace(const edm_wgrad3_item* items, int n) {
   Plan P;
   if (make_plan(items, n, P) != EDM_OK) return -1;
   return P.work_floats * 4;
+}
+
+// Diagnostics (include/tinyedm_hip_diag.h): the K shares per tile the plan of this group gives each layer (1 = not split).
+extern "C" int edm_wgrad3_plan_ksplit(const edm_wgrad3_item* items, int n, int* ksplit_out) {
+  Plan P;
+  const int rc = make_plan(items, n, P);
+  if (rc != EDM_OK) return rc;
+  EDM_REQUIRE(ksplit_out, "wgrad3_plan_ksplit: null output");
+  for (int k = 0; k < n; ++k) ksplit_out[k] = P.wg.L[k].ksplit;
+  return EDM_OK;
 }
 
 // Weight gradients of up to 16 3x3 layers: one stream-K launch + one finish launch.  `items` is HOST memory (read

@@ -1123,6 +1123,18 @@ def wgrad3_supported(x, dy, I):
     return Cin % 32 == 0 and Cout % 32 == 0 and W <= 126 and I * 9 * 4 <= 64 * 1024 and B * (H + 1) * (W + 1) < (1 << 30)
 
 
+def wgrad3_plan_ksplit(shapes):
+    """K shares per tile that edm_wgrad3_group's plan gives each layer of a group (diagnostics, host logic only: no
+    launch, no device memory).  shapes: sequence of (B, H, W, Cin, Cout)."""
+    n = len(shapes)
+    arr = (_lib.WGrad3Item * n)()
+    for k, (B, H, W, Cin, Cout) in enumerate(shapes):
+        arr[k] = _lib.WGrad3Item(1, 1, 1, 1, None, B, H, W, Cin, Cout, Cin, 1.0, 0)     # (pointers only checked for NULL)
+    out = (ctypes.c_int * n)()
+    _lib.call("edm_wgrad3_plan_ksplit", ctypes.byref(arr), n, out)
+    return list(out)
+
+
 def wgrad3_group(items):
     """Weight gradients of up to 16 3x3 conv layers in ONE stream-K launch + ONE finish launch.
     items: sequence of (x, dy, w, grad, perm, scale, accumulate) with x (B,H,W,Cin) / dy (B,H,W,Cout) NHWC bf16,
