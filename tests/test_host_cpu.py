@@ -375,10 +375,12 @@ def test_backward_hook_feeds_a_cached_marked_unit_gradient():
 
 def test_wgrad3_plan_splits_k_only_where_team_members_would_idle():
     """conv_wgrad3.hip make_plan (host logic): layers whose 128 x 64 tiles do not fill a team of eight workgroups split
-    their K range into shares; the 256 / 512-channel layers of the CIFAR-10 net (2 x 4, 2 x 8 tiles) never do."""
+    their K range into shares; the 256 / 512-channel layers of the CIFAR-10 net (2 x 4, 2 x 8 tiles) never do, its conv_in does."""
     from tinyedm_amd import ops
     cifar = [(128, 32, 32, 256, 256), (128, 32, 32, 512, 256), (128, 16, 16, 256, 256), (128, 8, 8, 512, 256)]
     assert ops.wgrad3_plan_ksplit(cifar) == [1, 1, 1, 1]
+    # ... but its conv_in does (4 input channels padded to 32 -> 256: 2 x 1 tiles; 2 of 8 members busy without the shares)
+    assert ops.wgrad3_plan_ksplit([(128, 32, 32, 32, 256)] + cifar[:1]) == [4, 1]
     # MNIST 28x28 / 14x14 128-channel layers: 1 x 2 tiles -> 4 shares fill the team
     assert ops.wgrad3_plan_ksplit([(128, 28, 28, 128, 128), (128, 14, 14, 128, 128)]) == [4, 4]
     # ImageNet-64 192-channel layers (2 x 3 tiles, 6 of 8 members): 4 shares = 3 full groups of a quarter of the stages

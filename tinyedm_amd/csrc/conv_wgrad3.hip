@@ -661,7 +661,7 @@ int make_plan(const edm_wgrad3_item* it, int n, Plan& P) {
       // K shares (see the header): the team walks ceil(T * S / 8) groups of ceil(nst / S) stages instead of `ngroups` groups of
       // nst; every group costs each member the flush of a 288-KiB partial tile (and the finish pass its read), priced at
       // W3_FLUSH_STAGES stages (a stage is ~2 us of a CU, 256 partial tiles at once ~25 us of HBM writes + their read back).
-      // 256-channel layers (2 x 4 or 2 x 8 tiles: no idle member) never split -- the CIFAR-10 plans are unchanged.
+      // 256-channel layers (2 x 4 or 2 x 8 tiles: no idle member) never split; of the CIFAR-10 net only conv_in does (2 x 1 tiles).
       constexpr int W3_FLUSH_STAGES = 16;
       static const int smax = [] { const char* e = getenv("EDM_W3_KSPLIT"); return e ? atoi(e) : 8; }();   // 0 / 1: off (tools, A/B)
       const int T = L.tiles_co * L.tiles_ci;
