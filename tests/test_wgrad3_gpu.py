@@ -181,3 +181,32 @@ def test_wgrad1x1_grouped_launch_matches_per_layer_kernels():
         got = sl.double().sum(0)[0]
         e = ((got - ref).norm() / ref.norm()).item()
         assert e <= 1e-5, (tuple(x.shape), tuple(dy.shape), e)
+
+
+def test_wgrad_finish_multi_matches_the_per_tensor_finish():
+    """edm_wgrad_finish_multi (one launch for up to 40 small weight gradients; round 6: master row and old gradient loaded
+    while the slab loads are in flight) against edm_wgrad_finish per tensor: 1x1 convs / Linears (the prefetched form),
+    rows longer than the prefetch window, 3x3 taps, permuted rows, accumulate on and off, ragged Ipad"""
+    from tinyedm_amd import ops
+    g = torch.Generator().manual_seed(11)
+    shapes = [  # (S, taps, O, I, Ipad, perm, accumulate, scale)
+        (8, 1, 256, 256, 256, False, False, 1.0), (16, 1, 768, 256, 256, True, True, 0.7), (4, 1, 256, 768, 768, False, True, 1.0),
+        (2, 1, 64, 1280, 1280, False, False, 0.5), (3, 9, 32, 4, 32, False, True, 1.0), (1, 1, 10, 3, 8, False, False, 1.0),
+        (5, 9, 64, 64, 64, True, False, 1.3), (8, 1, 256, 512, 512, False, True, 1.0),
+    ]
+    items, refs = [], []
+    for (S, taps, O, I, Ipad, perm, acc, scale) in shapes:
+        slabs = torch.randn(S, taps, O, Ipad, generator=g).to(DEV)
+        w = torch.randn(O, I, taps, generator=g).to(DEV)
+        p = torch.randperm(O, generator=g).to(torch.int32).to(DEV) if perm else None
+        g0 = torch.randn(O, I, taps, generator=g).to(DEV)
+        ref = ops.wgrad_finish(slabs, w, taps, I, perm=p, scale=scale, out=g0.clone() if acc else None)
+        grad = g0.clone()
+        items.append((slabs, w, grad, p, taps, I, scale, acc))
+        refs.append(ref)
+    ops.wgrad_finish_multi(items)
+    torch.cuda.synchronize()
+    for k, (it, ref) in enumerate(zip(items, refs)):
+        # (the two kernels may split the S slabs into a different number of partial sums: equal up to fp32 summation order)
+        e = rel(it[2], ref)
+        assert torch.isfinite(it[2]).all() and e <= 1e-6, f"tensor {k} {shapes[k]}: rel {e:.3e}"

@@ -422,7 +422,7 @@ struct FinItem {
 };
 struct FinGroup {
   FinItem it[MAXF];
-  int n;
+  int n, prefetch;
 };
 __global__ __launch_bounds__(512) void k_wgrad_finish_multi(const FinGroup* __restrict__ gp) {
   const FinGroup& g = *gp;   // (device memory: common.h EDM_UPLOAD_TABLE)
@@ -440,6 +440,24 @@ __global__ __launch_bounds__(512) void k_wgrad_finish_multi(const FinGroup* __re
   float* gm = smm + (long)G * n;     // [n] master order
   const float* row = g.it[k].w + (long)mo * n;
   const long slab_stride = (long)taps * O * Ipad;
+  // The kernel is a chain of memory round trips per workgroup (table -> slabs -> master row -> old gradient -> store) over
+  // ~10 rounds of workgroups per launch: the master row and (accumulate) the old gradient are loaded NOW, while the slab
+  // loads are in flight -- as k_wgrad3_finish does (rows of up to 2 x 512 elements: every 1x1 conv / Linear of the nets here)
+  constexpr int WPF = 2;
+  const bool pf = g.prefetch && n <= WPF * 512;
+  float* out = g.it[k].grad + (long)mo * n;
+  const int accumulate = g.it[k].accumulate;
+  float wpre[WPF] = {0.f, 0.f}, opre[WPF] = {0.f, 0.f};
+  if (pf) {
+#pragma unroll
+    for (int q = 0; q < WPF; ++q) {
+      const int e = threadIdx.x + q * 512;
+      if (e < n) {
+        wpre[q] = row[e];
+        if (accumulate) opre[q] = out[e];
+      }
+    }
+  }
   if ((I & 3) == 0 && (Ipad & 3) == 0) {
     const int I4 = I >> 2, E4 = taps * I4;
     for (int idx = threadIdx.x; idx < E4 * G; idx += blockDim.x) {
@@ -470,15 +488,30 @@ __global__ __launch_bounds__(512) void k_wgrad_finish_multi(const FinGroup* __re
   }
   __syncthreads();
   float dot = 0.f, ss = 0.f;
-  for (int e = threadIdx.x; e < n; e += blockDim.x) {
-    float a = 0.f;
-    for (int sg = 0; sg < G; ++sg) a += part[(long)sg * n + e];
-    a *= scale;
-    const int t = e / I, i = e - t * I;
-    const float wv = row[i * taps + t];
-    gm[i * taps + t] = a;
-    dot += a * wv;
-    ss += wv * wv;
+  if (pf && taps == 1) {   // packed order == master order: element e of the row is the prefetched one
+#pragma unroll
+    for (int q = 0; q < WPF; ++q) {
+      const int e = threadIdx.x + q * 512;
+      if (e < n) {
+        float a = 0.f;
+        for (int sg = 0; sg < G; ++sg) a += part[(long)sg * n + e];
+        a *= scale;
+        gm[e] = a;
+        dot += a * wpre[q];
+        ss += wpre[q] * wpre[q];
+      }
+    }
+  } else {
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+      float a = 0.f;
+      for (int sg = 0; sg < G; ++sg) a += part[(long)sg * n + e];
+      a *= scale;
+      const int t = e / I, i = e - t * I;
+      const float wv = row[i * taps + t];
+      gm[i * taps + t] = a;
+      dot += a * wv;
+      ss += wv * wv;
+    }
   }
   dot = block_sum(dot, red);
   ss = block_sum(ss, red);
@@ -488,11 +521,20 @@ __global__ __launch_bounds__(512) void k_wgrad_finish_multi(const FinGroup* __re
   const float c0 = 1.0f / (d * sqn);
   const float c1 = rn > 0.f ? dot / (d * rn * sqn) : 0.f;
   __syncthreads();
-  float* out = g.it[k].grad + (long)mo * n;
-  const int accumulate = g.it[k].accumulate;
-  for (int e = threadIdx.x; e < n; e += blockDim.x) {
-    const float v = c0 * (gm[e] - row[e] * c1);
-    out[e] = accumulate ? out[e] + v : v;
+  if (pf) {
+#pragma unroll
+    for (int q = 0; q < WPF; ++q) {
+      const int e = threadIdx.x + q * 512;
+      if (e < n) {
+        const float v = c0 * (gm[e] - wpre[q] * c1);
+        out[e] = accumulate ? opre[q] + v : v;
+      }
+    }
+  } else {
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+      const float v = c0 * (gm[e] - row[e] * c1);
+      out[e] = accumulate ? out[e] + v : v;
+    }
   }
 }
 
@@ -517,6 +559,8 @@ extern "C" int edm_wgrad_finish_multi(const edm_finish_item* items, int n, void*
   EDM_REQUIRE(items && n > 0 && n <= MAXF, "wgrad_finish_multi: need 1..%d tensors, got %d", MAXF, n);
   FinGroup g;
   g.n = n;
+  static const int prefetch = [] { const char* e = getenv("EDM_FIN_PREFETCH"); return e ? atoi(e) : 1; }();   // tools only (A/B)
+  g.prefetch = prefetch;
   int row = 0;
   size_t lds = 0;
   for (int k = 0; k < n; ++k) {
