@@ -144,7 +144,7 @@ int edm_conv_wgrad_1x1_group(const edm_wgrad1_item* items, int n, void* table_ho
  * networks.py:32-36's normalisation): the reduction dimension of all layers is laid end to end and cut into equal
  * ranges, one per workgroup (128x64x9 tile, one wave per SIMD); partial tiles go to `workspace`; a second launch sums
  * each weight row's partials, projects through w_hat = w/(eps + |w|/sqrt(n))/sqrt(n) and writes (accumulate=0) or
- * accumulates (1) grad.  `items` is a HOST array read during the call; <= 16 layers, all with W <= 62 or all with
+ * accumulates (1) grad.  `items` is a HOST array read during the call; <= edm_wgrad3_max_layers() (48) layers, all with W <= 62 or all with
  * 62 < W <= 126; Cin, Cout % 32 == 0.  workspace >= edm_wgrad3_workspace(items, n) bytes (-1 on bad arguments). */
 typedef struct {
   const void* X;    /* bf16 [B*H*W][Cin]  layer input */
@@ -158,6 +158,7 @@ typedef struct {
 } edm_wgrad3_item;
 long edm_wgrad3_workspace(const edm_wgrad3_item* items, int n);
 long edm_wgrad3_table_bytes(void);
+int edm_wgrad3_max_layers(void);
 int edm_wgrad3_group(const edm_wgrad3_item* items, int n, void* workspace, long workspace_bytes, void* table_host,
                      void* table_dev, int defer_upload, edm_stream_t stream);
 

@@ -389,3 +389,7 @@ def test_wgrad3_plan_splits_k_only_where_team_members_would_idle():
     assert ops.wgrad3_plan_ksplit([(1, 8, 8, 64, 64), (2, 8, 8, 128, 128)]) == [1, 1]
     ks = ops.wgrad3_plan_ksplit([(64, 32, 32, 384, 384), (64, 16, 16, 576, 576), (64, 64, 64, 64, 64)][:2])
     assert all(1 <= k <= 8 for k in ks)
+    # the group size the Python side queues up to is the kernel table's (48 layers: every 3x3 layer of the CIFAR-10 net)
+    from tinyedm_amd import _lib
+    assert ops.W3_MAX_LAYERS == _lib.call("edm_wgrad3_max_layers") == 48
+    assert ops.wgrad3_plan_ksplit([(128, 8, 8, 256, 256)] * 48) == [1] * 48

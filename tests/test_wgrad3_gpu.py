@@ -111,7 +111,8 @@ def test_wgrad3_ksplit_groups_really_split(ops):
 
 
 @pytest.mark.parametrize("name,group", [("ksplit", GROUP_KSPLIT), ("ksplit-wide", GROUP_KSPLIT_WIDE), ("small", GROUP_SMALL), ("wide", GROUP_WIDE), ("single", GROUP_SMALL[1:2]),
-                                        ("sixteen", (GROUP_SMALL * 2)[:16]), ("teams", GROUP_TEAMS)])
+                                        ("sixteen", (GROUP_SMALL * 2)[:16]), ("forty-three", (GROUP_SMALL * 6)[:43]),
+                                        ("teams", GROUP_TEAMS)])
 def test_wgrad3_group_matches_oracle(ops, name, group):
     g = torch.Generator().manual_seed(len(group) * 31 + 5)
     items, refs = zip(*[_layer(g, **kw) for kw in group])

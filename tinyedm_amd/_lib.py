@@ -78,6 +78,7 @@ SIGNATURES = {
     "edm_wgrad3_workspace": [P, I],
     "edm_wgrad3_group": [P, I, P, L, P, P, I, P],
     "edm_wgrad3_table_bytes": [],
+    "edm_wgrad3_max_layers": [],
     # attention.hip
     "edm_attention_fwd": [P, P, I, I, I, I, P],
     "edm_attention_bwd": [P, P, P, P, I, I, I, I, P],
@@ -144,7 +145,7 @@ DIAG_SIGNATURES = {
 _RET = {"edm_last_error": ctypes.c_char_p, "edm_v6_persistent_launches": ctypes.c_long, "edm_wgrad3_workspace": ctypes.c_long, "edm_wgrad3_table_bytes": ctypes.c_long,
         "edm_skip_gate_wgrad_multi_table_bytes": ctypes.c_long, "edm_skip_gate_fwd_multi_table_bytes": ctypes.c_long, "edm_skip_gate_bwd_multi_table_bytes": ctypes.c_long,
         "edm_conv_wgrad_1x1_group_table_bytes": ctypes.c_long, "edm_wgrad_finish_multi_table_bytes": ctypes.c_long}
-_NO_STATUS = {"edm_skip_gate_bwd_multi_table_bytes", "edm_skip_gate_fwd_multi_table_bytes", "edm_v6_persistent_launches", "edm_conv3x3_fold_supported", "edm_skip_gate_wgrad_multi_table_bytes", "edm_version", "edm_graph_replay_safe", "edm_last_error", "edm_conv_wgrad_nsplit", "edm_conv_wgrad_1x1_nsplit", "edm_conv_wgrad_1x1_nsplit_grouped", "edm_wgrad3_workspace", "edm_wgrad3_table_bytes",
+_NO_STATUS = {"edm_skip_gate_bwd_multi_table_bytes", "edm_skip_gate_fwd_multi_table_bytes", "edm_v6_persistent_launches", "edm_conv3x3_fold_supported", "edm_skip_gate_wgrad_multi_table_bytes", "edm_version", "edm_graph_replay_safe", "edm_last_error", "edm_conv_wgrad_nsplit", "edm_conv_wgrad_1x1_nsplit", "edm_conv_wgrad_1x1_nsplit_grouped", "edm_wgrad3_workspace", "edm_wgrad3_table_bytes", "edm_wgrad3_max_layers",
               "edm_conv_wgrad_1x1_group_table_bytes", "edm_wgrad_finish_multi_table_bytes", "edm_attention_qkv_supported"}
 
 _lib = None

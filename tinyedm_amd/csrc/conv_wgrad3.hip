@@ -39,7 +39,7 @@ constexpr int KP = 64;                 // padded pixel rows per stage
 constexpr int SUBB = KP * 64;          // bytes of one [64 rows][32 ch] sub-image
 constexpr int TCO = 128, TCI = 64;     // workgroup tile
 constexpr int TILE_FLOATS = 9 * TCO * TCI;
-constexpr int MAXL = 16;               // layers per group (kernel-argument table)
+constexpr int MAXL = 48;               // layers per group (the launch table lives in device memory: common.h EDM_UPLOAD_TABLE)
 constexpr int DYRING = 3;
 
 template <int LEADS>
@@ -132,7 +132,14 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3(const W3Group* __restrict__ g
   long pos = (long)team * g.q;
   const long pend = (pos + g.q < g.total) ? pos + g.q : g.total;
   int li = 0;
-  while (li + 1 < g.nlayers && pos >= g.L[li + 1].stage0) ++li;
+  {   // the layer of the team's first stage: bisection over the layers' first stages (up to 48 layers: 6 dependent scalar loads)
+    int hi = g.nlayers - 1;
+    while (li < hi) {
+      const int mid = (li + hi + 1) >> 1;
+      if (pos >= g.L[mid].stage0) li = mid;
+      else hi = mid - 1;
+    }
+  }
 
   while (pos < pend) {
     // ---- one segment: `nst` consecutive stages of tile `tl` of layer `li`, starting at stage st0 of the tile
@@ -484,7 +491,14 @@ __global__ __launch_bounds__(256) void k_wgrad3_finish(const F3Group* __restrict
   extern __shared__ __attribute__((aligned(16))) float gsm[];  // [n] gradient row in master order (i*9 + t)
   __shared__ float red[8];
   int li = 0;
-  while (li + 1 < g.nlayers && (int)blockIdx.x >= g.L[li + 1].row0) ++li;
+  {   // bisection over the layers' first rows (a walk is up to 47 dependent scalar loads at the head of a short workgroup)
+    int hi = g.nlayers - 1;
+    while (li < hi) {
+      const int mid = (li + hi + 1) >> 1;
+      if ((int)blockIdx.x >= g.L[mid].row0) li = mid;
+      else hi = mid - 1;
+    }
+  }
   const int r = blockIdx.x - g.L[li].row0;
   const int I = g.L[li].I, tiles_ci = g.L[li].tiles_ci, nst = g.L[li].nst;
   const int n = I * 9;
@@ -726,9 +740,10 @@ extern "C" int edm_wgrad3_plan_ksplit(const edm_wgrad3_item* items, int n, int* 
   return EDM_OK;
 }
 
-// Weight gradients of up to 16 3x3 layers: one stream-K launch + one finish launch.  `items` is HOST memory (read
+// Weight gradients of up to 48 3x3 layers (edm_wgrad3_max_layers): one stream-K launch + one finish launch.  `items` is HOST memory (read
 // during the call only); workspace is device memory of at least edm_wgrad3_workspace(items, n) bytes.
 extern "C" long edm_wgrad3_table_bytes(void) { return (long)(sizeof(W3Group) + sizeof(F3Group)); }
+extern "C" int edm_wgrad3_max_layers(void) { return MAXL; }
 
 // Measurement hook (bench.py's roofline leg; include/tinyedm_hip_diag.h): the NEXT edm_wgrad3_group call of this thread
 // records `ev_start` right before and `ev_end` right behind its k_wgrad3 launch -- the grouped entry point also uploads its

@@ -147,7 +147,7 @@ WGRAD_STREAM = os.environ.get("EDM_WGRAD_STREAM", "1") != "0"
 # largest layer (pixels) that joins a group.  A layer with more pixels fills the chip alone and its per-layer launch
 # overlaps the backward pass at a finer grain (ImageNet-64 config, 64x64 layers at batch 176: 144 vs 147 ms).  Only with
 # the side stream: on one chain (captured step) everything is grouped (154.6 vs 161 ms).
-W3_GROUP = max(0, min(16, int(os.environ.get("EDM_W3_GROUP", "16"))))
+W3_GROUP = max(0, min(ops.W3_MAX_LAYERS, int(os.environ.get("EDM_W3_GROUP", "16"))))
 # Data-parallel runs: the LAST grouped launch of a backward pass finishes at the very end of it, so the all-reduce of its
 # layers' gradients has nothing left to hide under except the optimizer.  W3_TAIL > 0 cuts the groups so that the final one
 # holds at most that many layers (CIFAR-10: 43 layers as 16 + 16 + 7 + 4 instead of 16 + 16 + 11: 9.4 MB = 6.6 % of the

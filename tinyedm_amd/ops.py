@@ -1116,6 +1116,9 @@ def conv_wgrad_1x1_group(pairs):
     return out
 
 
+W3_MAX_LAYERS = 48      # csrc/conv_wgrad3.hip MAXL (edm_wgrad3_max_layers; checked by tests/test_host_cpu.py)
+
+
 def wgrad3_supported(x, dy, I):
     """shapes the grouped 3x3 weight-gradient path (csrc/conv_wgrad3.hip) covers"""
     B, H, W, Cin = x.shape
@@ -1136,13 +1139,13 @@ def wgrad3_plan_ksplit(shapes):
 
 
 def wgrad3_group(items):
-    """Weight gradients of up to 16 3x3 conv layers in ONE stream-K launch + ONE finish launch.
+    """Weight gradients of up to W3_MAX_LAYERS (48) 3x3 conv layers in ONE stream-K launch + ONE finish launch.
     items: sequence of (x, dy, w, grad, perm, scale, accumulate) with x (B,H,W,Cin) / dy (B,H,W,Cout) NHWC bf16,
     w the fp32 master weight (Cout, I, 3, 3) with I <= Cin, grad an fp32 tensor like w that receives (accumulate=0)
     or accumulates (1) the projected gradient, perm the optional packed-row permutation (int32)."""
     n = len(items)
-    if not 0 < n <= 16:
-        raise ValueError("wgrad3_group: 1..16 layers per group")
+    if not 0 < n <= W3_MAX_LAYERS:
+        raise ValueError(f"wgrad3_group: 1..{W3_MAX_LAYERS} layers per group")
     arr = (_lib.WGrad3Item * n)()
     flops = nbytes = 0.0
     halo = None
