@@ -243,6 +243,12 @@ int edm_mod_silu_drop_fwd(const void* r, const float* lin, long lin_stride, cons
 int edm_mod_silu_drop_bwd(const void* r, const float* lin, long lin_stride, const float* gain, const void* ga, void* gr,
                           float* gm, float* glin, long glin_stride, float* ggain, int B, int HW, int C, float pdrop,
                           unsigned long long seed, unsigned sub, unsigned step, const void* dyn, edm_stream_t stream);
+/* its first half alone: gr, and the raw modulation gradient accumulated into gm (zero-filled fp32, rows of gm_stride floats:
+ * a column slice of the buffer all blocks share) -- finished for every block by ONE edm_mod_finish_multi (the form
+ * edm_conv3x3_modbwd takes with a shared buffer, for maps whose H*W is no multiple of 32, which that entry refuses) */
+int edm_mod_silu_drop_bwd_raw(const void* r, const float* lin, long lin_stride, const float* gain, const void* ga, void* gr,
+                              float* gm, long gm_stride, int B, int HW, int C, float pdrop, unsigned long long seed,
+                              unsigned sub, unsigned step, const void* dyn, edm_stream_t stream);
 int edm_dropout_mask(unsigned char* mask, long n, float pdrop, unsigned long long seed, unsigned sub, unsigned step,
                      edm_stream_t stream);
 /* 2x2 average pool / nearest-exact x2 (networks.py:80, 72); H,W = OUTPUT dims; scale folds the backward factors */

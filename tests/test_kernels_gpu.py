@@ -474,6 +474,23 @@ def test_mod_silu_dropout(ops, pdrop):
     close_bf16(nchw(gr), rr.grad)
     assert rel(glin.cpu(), ll.grad) < 2e-3
     assert abs(ggain.item() - gg.grad.item()) <= 2e-3 * abs(gg.grad.item()) + 1e-3
+    # the first half alone (edm_mod_silu_drop_bwd_raw): the raw modulation gradient into a column slice of a wider buffer --
+    # what a block does when the network shares one buffer and ONE edm_mod_finish_multi finishes all blocks; an odd map size
+    # (H*W = 49, no multiple of 32: the case the fused dgrad epilogue refuses)
+    gm_all = torch.zeros(B, C + 96, device=DEV)
+    gr2, none1, none2 = ops.mod_silu_drop_bwd(rd, lin.to(DEV), gain.to(DEV), nhwc(ga), pdrop, seed, sub, step,
+                                              gm_out=gm_all[:, 32:32 + C])
+    assert none1 is None and none2 is None and torch.equal(gr2, gr)
+    assert (gm_all[:, :32] == 0).all() and (gm_all[:, 32 + C:] == 0).all()
+    gm = gm_all[:, 32:32 + C].cpu()
+    assert rel(gm * gain, ll.grad) < 2e-3                                   # glin = gm * gain (k_mod_finish)
+    assert abs((gm * lin).sum().item() - gg.grad.item()) <= 2e-3 * abs(gg.grad.item()) + 1e-3
+    r7 = nhwc(q(torch.randn(B, C, 7, 7, generator=g)))
+    ga7 = nhwc(q(torch.randn(B, C, 7, 7, generator=g)))
+    gr_a, glin_a, gg_a = ops.mod_silu_drop_bwd(r7, lin.to(DEV), gain.to(DEV), ga7, pdrop, seed, sub, step)
+    gm7 = torch.zeros(B, C, device=DEV)
+    gr_b, _, _ = ops.mod_silu_drop_bwd(r7, lin.to(DEV), gain.to(DEV), ga7, pdrop, seed, sub, step, gm_out=gm7)
+    assert torch.equal(gr_a, gr_b) and rel((gm7 * gain.to(DEV)).cpu(), glin_a.cpu()) < 1e-5
 
 
 def test_scalelong_concat(ops):

@@ -30,6 +30,7 @@ SIGNATURES = {
     "edm_axpby": [P, F, P, F, P, L, P],
     "edm_mod_silu_drop_fwd": [P, P, L, P, P, I, I, I, F, U64, U, U, P, P],
     "edm_mod_silu_drop_bwd": [P, P, L, P, P, P, P, P, L, P, I, I, I, F, U64, U, U, P, P],
+    "edm_mod_silu_drop_bwd_raw": [P, P, L, P, P, P, P, L, I, I, I, F, U64, U, U, P, P],
     "edm_dropout_mask": [P, L, F, U64, U, U, P],
     "edm_pool2": [P, P, I, I, I, I, F, P],
     "edm_up2": [P, P, P, I, I, I, I, F, P],

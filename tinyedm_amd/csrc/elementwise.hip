@@ -340,7 +340,7 @@ __global__ void k_mod_silu_drop_fwd(const bf16* __restrict__ r, const float* __r
 // block = CL*PS threads (thread -> fixed channel chunk), grid = (B, ceil(HW/PIXW))
 __global__ void k_mod_silu_drop_bwd(const bf16* __restrict__ r, const float* __restrict__ lin,
                                     const float* __restrict__ gain, const bf16* __restrict__ ga,
-                                    bf16* __restrict__ gr, float* __restrict__ gm, int HW, int C, int PIXW,
+                                    bf16* __restrict__ gr, float* __restrict__ gm, long gm_stride, int HW, int C, int PIXW,
                                     long lin_stride, float pdrop, uint32_t seed_lo, uint32_t seed_hi, uint32_t sub, uint32_t step,
                                     const StepParams* __restrict__ dyn) {
   extern __shared__ __attribute__((aligned(16))) float red[];
@@ -382,7 +382,7 @@ __global__ void k_mod_silu_drop_bwd(const bf16* __restrict__ r, const float* __r
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float s = 0.f;
     for (int q = 0; q < PS; ++q) s += red[q * C + c];
-    atomicAdd(gm + (long)b * C + c, s);
+    atomicAdd(gm + (long)b * gm_stride + c, s);
   }
 }
 // glin = gm*gain ; ggain += sum gm*lin
@@ -428,12 +428,32 @@ extern "C" int edm_mod_silu_drop_bwd(const void* r, const float* lin, long lin_s
   int CL = C / 8, block = block_for_chunks(CL), PS = block / CL;
   int PIXW = HW >= 256 ? 128 : HW;
   hipLaunchKernelGGL(k_mod_silu_drop_bwd, dim3(B, cdiv(HW, PIXW)), dim3(block), PS * C * sizeof(float), st,
-                     (const bf16*)r, lin, gain, (const bf16*)ga, (bf16*)gr, gm, HW, C, PIXW, lin_stride, pdrop,
+                     (const bf16*)r, lin, gain, (const bf16*)ga, (bf16*)gr, gm, (long)C, HW, C, PIXW, lin_stride, pdrop,
                      (uint32_t)seed, (uint32_t)(seed >> 32), sub, step, (const StepParams*)dyn);
   EDM_CHECK_LAUNCH("mod_silu_drop_bwd");
   hipLaunchKernelGGL(k_mod_finish, dim3(grid_for((long)B * C, 256, 64)), dim3(256), 0, st, gm, lin, gain, glin,
                      ggain, (long)B * C, C, lin_stride, glin_stride);
   EDM_CHECK_LAUNCH("mod_finish");
+  return EDM_OK;
+}
+
+// The first half of edm_mod_silu_drop_bwd alone: gr, and the RAW modulation gradient accumulated into gm (zero-filled fp32 rows
+// of gm_stride floats -- a column slice of the buffer all blocks share); ONE edm_mod_finish_multi at the end of the backward
+// pass finishes every block (as after edm_conv3x3_modbwd with a shared buffer, which refuses maps with H*W % 32 != 0: MNIST's
+// 28x28 / 14x14 / 7x7 levels took 27 separate finish launches per step before this).
+extern "C" int edm_mod_silu_drop_bwd_raw(const void* r, const float* lin, long lin_stride, const float* gain,
+                                         const void* ga, void* gr, float* gm, long gm_stride, int B, int HW, int C,
+                                         float pdrop, unsigned long long seed, unsigned sub, unsigned step,
+                                         const void* dyn, hipStream_t st) {
+  EDM_REQUIRE(r && lin && gain && ga && gr && gm, "mod_silu_drop_bwd_raw: null pointer");
+  EDM_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && C > 0 && C <= 1024 && lin_stride >= C && gm_stride >= C,
+              "mod_silu_drop_bwd_raw: bad args");
+  int CL = C / 8, block = block_for_chunks(CL), PS = block / CL;
+  int PIXW = HW >= 256 ? 128 : HW;
+  hipLaunchKernelGGL(k_mod_silu_drop_bwd, dim3(B, cdiv(HW, PIXW)), dim3(block), PS * C * sizeof(float), st,
+                     (const bf16*)r, lin, gain, (const bf16*)ga, (bf16*)gr, gm, gm_stride, HW, C, PIXW, lin_stride, pdrop,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), sub, step, (const StepParams*)dyn);
+  EDM_CHECK_LAUNCH("mod_silu_drop_bwd_raw");
   return EDM_OK;
 }
 

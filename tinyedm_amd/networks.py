@@ -166,6 +166,7 @@ _bwd_end_queued = set()     # devices whose end-of-backward callback is queued f
 # ScaleLong gates: the batch sums that form the gate MLPs' weight gradients (the second launch of ops.skip_gate_bwd), for ALL
 # the gates of a backward pass in ONE launch behind it (round 6: nine launches less on the backward's chain); their finish
 # rides in the last multi-tensor finish.  Arena mode only; EDM_SG_DEFER=0: per gate, as round 5.
+MOD_DEFER_UNFUSED = os.environ.get("EDM_MOD_DEFER_UNFUSED", "1") != "0"   # unfused modulation backward: finish with the others (A/B)
 SG_MULTI = os.environ.get("EDM_SG_MULTI", "1") != "0"     # every decoder gate of a forward pass in one launch (round 6)
 SG_HALVES = os.environ.get("EDM_SG_HALVES", "1") != "0"       # ... which also writes the gated-skip halves of cat / mp_silu(cat)
 SG_BWD_MULTI = os.environ.get("EDM_SG_BWD_MULTI", "1") != "0"   # ... and their backward, deferred to the last of them
@@ -1032,9 +1033,15 @@ class _ResBlockFn(torch.autograd.Function):
             if deferred:
                 gp._edm_deferred = True
         else:
+            # (maps whose H*W is no multiple of 32 -- MNIST's 28x28 / 14x14 / 7x7 levels: the fused epilogue's 32-pixel MFMA row
+            # blocks would straddle samples.)  The raw modulation gradient still goes to the shared buffer when there is one:
+            # no finish launch per block (round 6: 27 launches of 6 us per MNIST step)
+            deferred = MOD_DEFER_UNFUSED and ctx.gm_view is not None and gdirect
             ga2 = ops.conv_igemm(gout, wd2, 9, alpha=b)
             gr1, glin, ggain = ops.mod_silu_drop_bwd(r1, lin, gain, ga2, pdrop, seed, sub, step, glin_out=glin_out,
-                                                        ggain_out=ggain_out, dyn=dyn)
+                                                        ggain_out=ggain_out, dyn=dyn, gm_out=ctx.gm_view if deferred else None)
+            if deferred:
+                gp._edm_deferred = True
         if gdirect:
             ggain = None
             if not deferred:

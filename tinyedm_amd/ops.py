@@ -438,13 +438,22 @@ def mod_silu_drop_fwd(r, lin, gain, pdrop, seed, sub, step, dyn=None):
     return a
 
 
-def mod_silu_drop_bwd(r, lin, gain, ga, pdrop, seed, sub, step, glin_out=None, ggain_out=None, dyn=None):
+def mod_silu_drop_bwd(r, lin, gain, ga, pdrop, seed, sub, step, glin_out=None, ggain_out=None, dyn=None, gm_out=None):
     """glin_out: optional (B, C) strided fp32 view to receive d loss / d lin (else a fresh tensor);
-    ggain_out: optional 0-dim fp32 tensor that d loss / d gain is ACCUMULATED into (else a fresh zero scalar)."""
+    ggain_out: optional 0-dim fp32 tensor that d loss / d gain is ACCUMULATED into (else a fresh zero scalar).
+    gm_out: a zero-filled (B, C) fp32 view with unit column stride (a column slice of the buffer all blocks share): the raw
+    modulation gradient is accumulated there and NOT finished -- returns (gr, None, None); one mod_finish_multi over the
+    shared buffer finishes every block (as conv3x3_modbwd(gm_out=...))."""
     B, H, W, C = _nhwc(r, "r")
     ls = _lin_view(lin, B, C, "lin")
     _chk(ga, bf16, "ga", r.shape)
     gr = torch.empty_like(r)
+    if gm_out is not None:
+        gms = _lin_view(gm_out, B, C, "gm_out")
+        _chk(gain, f32, "gain")
+        _lib.call("edm_mod_silu_drop_bwd_raw", _p(r), _p(lin), ls, _p(gain), _p(ga), _p(gr), _p(gm_out), gms, B, H * W, C,
+                  float(pdrop), int(seed), int(sub), int(step), _dyn(dyn), _stream())
+        return gr, None, None
     gm = zeros_f32((B, C), r.device)
     glin = torch.empty(B, C, device=r.device, dtype=f32) if glin_out is None else glin_out
     gs = _lin_view(glin, B, C, "glin")
